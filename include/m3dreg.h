@@ -1,0 +1,186 @@
+/*
+ * m3dreg.h — C ABI of libm3dreg.so, the MI355X (gfx950) scan-registration engine that fills the
+ * `gpu_6dslam_node` slot of the m3d pipeline.
+ *
+ * What this boundary replaces in the reference (all paths relative to /root/reference):
+ *   - The reference has NO function-level API for this path: `gpu_6dslam/` is an empty, un-vendored
+ *     git submodule (.gitmodules:1-3) and the only coupling is a ROS1 process boundary —
+ *     m3d/m3d_husky_launch/launch/m3d_husky_bringup.launch:13 starts `gpu_6dslam_node`, which
+ *     consumes the `sensor_msgs/PointCloud2` that m3d_aggregator publishes
+ *     (m3d/m3d_aggregator/src/m3d_aggregator.cpp:188-212, advertise at :174).
+ *   - Therefore every entry point below takes the raw PointCloud2 payload (`data` pointer,
+ *     `point_step`, byte offsets of the FLOAT32 x/y/z fields — the layout pcl::toPCLPointCloud2
+ *     produces for pcl::PointXYZ at m3d_aggregator.cpp:196-201: step 16, x@0 y@4 z@8) and returns a
+ *     column-major float[16] pose (Eigen::Matrix4f storage order), so a ROS shim needs no copies
+ *     or conversions (see INTEGRATION.md and ros/gpu_6dslam_node.cpp).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary, every function
+ *     returns an int status (0 = M3DREG_OK, <0 = m3dreg_error).
+ *   - One handle = one device + one HIP stream; a handle is not thread-safe, different handles are
+ *     independent (no global mutable state).
+ *   - Poses map SOURCE-frame points into the TARGET frame: p_target = T * p_source.
+ *   - All results are bit-reproducible: they do not depend on launch geometry, scheduling or
+ *     atomics order (integer fixed-point normal-equation sums).
+ *   - There is no CPU fallback: without a usable HIP device m3dreg_create fails with
+ *     M3DREG_ERR_NO_DEVICE.
+ */
+#ifndef M3DREG_H
+#define M3DREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3DREG_ABI_VERSION 1
+#define M3DREG_MAX_LEVELS 4
+#define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
+
+typedef enum m3dreg_error {
+    M3DREG_OK = 0,
+    M3DREG_ERR_INVALID_ARG = -1,
+    M3DREG_ERR_NO_DEVICE = -2,      /* no HIP device / extension unusable: never falls back to CPU */
+    M3DREG_ERR_HIP = -3,            /* a HIP runtime call failed (see m3dreg_last_error) */
+    M3DREG_ERR_GRID_TOO_LARGE = -4, /* voxel key needs more than 31 bits: coarsen leaf or crop cloud */
+    M3DREG_ERR_EMPTY_CLOUD = -5,    /* no finite point in the cloud */
+    M3DREG_ERR_NO_TARGET = -6,      /* m3dreg_align before m3dreg_set_target_xyz */
+    M3DREG_ERR_LEVEL_MISMATCH = -7  /* cloud was bucketed with other leaf sizes than the handle's */
+} m3dreg_error;
+
+typedef enum m3dreg_metric {
+    M3DREG_POINT_TO_POINT = 0,
+    M3DREG_POINT_TO_PLANE = 1
+} m3dreg_metric;
+
+/* Per-registration termination status (m3dreg_stats.status). */
+typedef enum m3dreg_status {
+    M3DREG_CONVERGED = 0,       /* |d_rot| < eps_rot and |d_trans| < eps_trans at the finest level */
+    M3DREG_MAX_ITERATIONS = 1,  /* ran all iterations (normal for fixed-iteration runs) */
+    M3DREG_TOO_FEW_CORR = 2,    /* fewer than min_correspondences matches: pose left at last good value */
+    M3DREG_RANK_DEFICIENT = 3,  /* 6x6 normal matrix had a pivot <= pivot_rel_tol * max diagonal */
+    M3DREG_DIVERGED = 4         /* update rotation > 2 rad or non-finite */
+} m3dreg_status;
+
+/*
+ * Registration parameters. `gpu_6dslam_node` is launched with no params in the reference
+ * (m3d_husky_bringup.launch:13), so all of these are this library's own; m3dreg_default_params
+ * fills the defaults quoted in DESIGN.md. Multi-resolution: level 0 is the coarsest and is run
+ * first; each level has its own voxel leaf and iteration budget.
+ */
+typedef struct m3dreg_params {
+    int32_t n_levels;                        /* 1..M3DREG_MAX_LEVELS */
+    float leaf[M3DREG_MAX_LEVELS];           /* voxel edge [m]; the NN search covers the 27 cells around the query */
+    int32_t iterations[M3DREG_MAX_LEVELS];   /* max Gauss-Newton iterations per level */
+    float max_corr_dist[M3DREG_MAX_LEVELS];  /* reject a match when d^2 > max_corr_dist^2 */
+    int32_t metric;                          /* m3dreg_metric, used at every level */
+    int32_t min_correspondences;             /* below this -> M3DREG_TOO_FEW_CORR */
+    double eps_rot;                          /* [rad]  convergence threshold on |omega| */
+    double eps_trans;                        /* [m]    convergence threshold on |v| */
+    double pivot_rel_tol;                    /* LDL^T pivot threshold relative to max diagonal */
+    float plane_ratio;                       /* normal valid iff lambda3 <= plane_ratio * lambda2 */
+    int32_t normal_min_pts;                  /* normal valid iff >= this many points in the 27 cells */
+    float normal_leaf;                       /* voxel edge of the dedicated normal-estimation grid [m] */
+    float normal_min_spread;                 /* normal valid iff sqrt(lambda2) >= this * normal_leaf */
+} m3dreg_params;
+
+typedef struct m3dreg_stats {
+    int32_t status;       /* m3dreg_status */
+    int32_t iterations;   /* Gauss-Newton iterations actually executed, all levels */
+    int64_t n_corr;       /* correspondences used by the last executed iteration */
+    double rms;           /* sqrt(sum r^2 / n_corr) of the last executed iteration (before its update) */
+    double last_rot;      /* |omega| of the last update [rad] */
+    double last_trans;    /* |v| of the last update [m] */
+} m3dreg_stats;
+
+typedef struct m3dreg_handle m3dreg_handle; /* opaque: device, stream, params, workspaces */
+typedef struct m3dreg_cloud m3dreg_cloud;   /* opaque: one bucketed cloud resident in HBM */
+
+/* One entry of a batch: both clouds already bucketed and resident on the handle's device. */
+typedef struct m3dreg_pair {
+    const m3dreg_cloud* source;
+    const m3dreg_cloud* target;
+    float init_T[16]; /* column-major initial guess, source -> target */
+} m3dreg_pair;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int m3dreg_default_params(m3dreg_params* out);
+/* `stream`: a hipStream_t passed as void* (NULL = the library creates its own non-blocking stream). */
+int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_handle** out);
+int m3dreg_destroy(m3dreg_handle* h);
+const char* m3dreg_backend_name(void);            /* "hip-gfx950" */
+const char* m3dreg_last_error(const m3dreg_handle* h); /* text of the last failure on this handle */
+int m3dreg_abi_version(void);
+
+/* ---- the gpu_6dslam_node call surface: PointCloud2 bytes in, 4x4 pose out ------------------- */
+/* Copies the cloud to the device, buckets it (all levels) and, for point-to-plane, estimates normals.
+ * `data` is the PointCloud2 `data` buffer (host memory, caller keeps ownership), `n` = width*height. */
+int m3dreg_set_target_xyz(m3dreg_handle* h, const void* data, size_t n, size_t point_step,
+                          size_t off_x, size_t off_y, size_t off_z);
+/* Registers the source cloud against the current target. init_T/out_T: column-major float[16]. */
+int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step, size_t off_x,
+                 size_t off_y, size_t off_z, const float init_T[16], float out_T[16],
+                 m3dreg_stats* stats);
+
+/* ---- resident clouds (loop-closure batches, scan-to-scan chains, benchmarks) ---------------- */
+/* `data_is_device` != 0: `data` is a device pointer on the handle's device (no PCIe copy). */
+int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step,
+                        size_t off_x, size_t off_y, size_t off_z, int data_is_device,
+                        m3dreg_cloud** out);
+int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c);
+int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
+                        const float init_T[16], float out_T[16], m3dreg_stats* stats);
+/* Registers n_pairs independent pairs on this handle's device: one launch per Gauss-Newton
+ * iteration covers the whole batch (grid.y = pair). out_T: 16*n_pairs floats. */
+int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T,
+                       m3dreg_stats* stats);
+/* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. Used by bench.py to time
+ * the device work with HIP events on the handle's stream. */
+int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs);
+int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats);
+int m3dreg_synchronize(m3dreg_handle* h);
+void* m3dreg_get_stream(m3dreg_handle* h);
+
+/* ---- introspection used by the parity tests (stage-by-stage comparison with oracle/) -------- */
+typedef struct m3dreg_grid_info {
+    int32_t n;          /* points in the input cloud */
+    int32_t n_valid;    /* finite points */
+    int32_t n_cells;    /* occupied voxels */
+    int32_t dims[3];    /* grid extent in cells */
+    int32_t bits[3];    /* key bit-field widths: key = ix | iy<<bits[0] | iz<<(bits[0]+bits[1]) */
+    float mn[3];        /* AABB min (grid origin) */
+    float mx[3];        /* AABB max */
+    float center[3];    /* linearisation centre c */
+    float leaf;
+    float inv_leaf;
+    float lbound;       /* bound on |w| components used to derive the fixed-point scales */
+    int32_t has_normals;
+} m3dreg_grid_info;
+
+int m3dreg_cloud_levels(const m3dreg_cloud* c);
+int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m3dreg_grid_info* out);
+/* Any output pointer may be NULL. Arrays are sized by the cloud's n:
+ *   keys[n]       voxel key per input point, input order (0xFFFFFFFF for non-finite points)
+ *   sorted_keys[n], perm[n]   stable sort by key; perm[j] = input index of the j-th sorted point
+ *   sorted_xyz[3n]            x,y,z of sorted points (interleaved)
+ *   normals[3n]               unit normal per sorted point, (0,0,0) = invalid; only if has_normals */
+int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint32_t* keys,
+                        uint32_t* sorted_keys, int32_t* perm, float* sorted_xyz, float* normals);
+/* NN of arbitrary queries (already in the target frame; host float xyz interleaved) against one
+ * level of a bucketed cloud: out_idx[i] = INPUT index of the match or -1, out_d2[i] = squared distance. */
+int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, const float* queries_xyz,
+                    size_t nq, float max_corr_dist, int32_t* out_idx, float* out_d2);
+/* One linearisation at pose T (no update): the 29 fixed-point sums and their power-of-two exponents
+ * (value = sum * 2^-exp; exps[6] = rr, rt, tt, gr, gt, ss). */
+int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
+                            int level, const float T[16], int64_t sums[M3DREG_NSUMS], int32_t exps[6]);
+/* Per-iteration pose trace of the most recent m3dreg_align/align_clouds on this handle:
+ * column-major double[16] after each executed iteration; returns count via *n_out (<= cap). */
+int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3DREG_H */

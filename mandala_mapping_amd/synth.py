@@ -1,0 +1,211 @@
+"""Seeded synthetic workloads for BASELINE.json `configs`.
+
+No dataset ships with the reference and the GPU box has no network, so every cloud is generated
+from a seed by the functions below; the same numpy version runs here and on the GPU box, so both
+see identical bytes. All clouds are returned as float32 [n,3] in the SENSOR frame of their scan,
+the way a lidar driver (and m3d_aggregator, whose output frame is the unit's m3d_link) hands them on.
+
+Pose convention: T_gt maps SOURCE-frame points into the TARGET frame (what m3dreg_align returns).
+"""
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------
+# SE(3) helpers (float64)
+# ------------------------------------------------------------------------------------------------
+def rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def make_T(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def inv_T(T):
+    R, t = T[:3, :3], T[:3, 3]
+    return make_T(R.T, -R.T @ t)
+
+
+def apply_T(T, xyz):
+    return (xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3])
+
+
+def pose_error(T_est, T_gt):
+    """(rotation error [deg], translation error [m]) of T_est against T_gt."""
+    D = inv_T(np.asarray(T_gt, dtype=np.float64)) @ np.asarray(T_est, dtype=np.float64)
+    c = np.clip((np.trace(D[:3, :3]) - 1.0) * 0.5, -1.0, 1.0)
+    return float(np.degrees(np.arccos(c))), float(np.linalg.norm(D[:3, 3]))
+
+
+def random_T(rng, max_deg, max_trans):
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = np.radians(rng.uniform(0.3 * max_deg, max_deg))
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = rng.normal(size=3)
+    t *= rng.uniform(0.3 * max_trans, max_trans) / np.linalg.norm(t)
+    return make_T(R, t)
+
+
+# ------------------------------------------------------------------------------------------------
+# config 1: three mutually orthogonal 10 m x 10 m planes, 10 k points, sigma = 1 cm
+# ------------------------------------------------------------------------------------------------
+def planes_cloud(n, seed, sigma=0.01, size=10.0):
+    rng = np.random.default_rng(seed)
+    counts = [n - 2 * (n // 3), n // 3, n // 3]  # 3334/3333/3333 at n = 10 000
+    parts = []
+    for axis, m in enumerate(counts):
+        uv = rng.uniform(0.0, size, size=(m, 2))
+        w = rng.normal(0.0, sigma, size=m)
+        p = np.empty((m, 3))
+        others = [a for a in range(3) if a != (2, 0, 1)[axis]]
+        p[:, (2, 0, 1)[axis]] = w  # planes z=0, x=0, y=0
+        p[:, others[0]] = uv[:, 0]
+        p[:, others[1]] = uv[:, 1]
+        parts.append(p)
+    return np.concatenate(parts).astype(np.float32)
+
+
+def config1_T_gt():
+    R = rot_z(np.radians(3.0)) @ rot_y(np.radians(-1.5)) @ rot_x(np.radians(2.0))
+    return make_T(R, np.array([0.10, -0.05, 0.08]))
+
+
+def config1(n=10000):
+    """(source, target, T_gt): target = planes(seed 42); source = independent resample (seed 43)
+    expressed in a frame displaced by T_gt, i.e. source = T_gt^-1 * resample."""
+    tgt = planes_cloud(n, 42)
+    res = planes_cloud(n, 43)
+    T = config1_T_gt()
+    src = apply_T(inv_T(T), res).astype(np.float32)
+    return src, tgt, T
+
+
+# ------------------------------------------------------------------------------------------------
+# configs 2-5: synthetic Velodyne HDL-32E in a box room with box obstacles (analytic ray casting)
+# ------------------------------------------------------------------------------------------------
+ROOM = (np.array([-20.0, -15.0, 0.0]), np.array([20.0, 15.0, 6.0]))  # 40 x 30 x 6 m
+OBSTACLES = [  # (min, max) axis-aligned boxes standing on the floor
+    (np.array([4.0, 3.0, 0.0]), np.array([6.5, 5.0, 2.2])),
+    (np.array([-9.0, -6.0, 0.0]), np.array([-6.0, -4.5, 1.6])),
+    (np.array([10.0, -10.0, 0.0]), np.array([13.0, -7.0, 3.0])),
+    (np.array([-14.0, 6.0, 0.0]), np.array([-11.5, 10.0, 2.6])),
+    (np.array([1.0, -9.0, 0.0]), np.array([2.5, -7.5, 1.2])),
+    (np.array([-3.0, 8.0, 0.0]), np.array([0.5, 9.5, 4.0])),
+]
+HDL32_ELEV_DEG = 10.67 - (4.0 / 3.0) * np.arange(32)  # +10.67 ... -30.67 deg
+SENSOR_HEIGHT = 1.8
+
+
+def _ray_box_exit(o, d, bmin, bmax):
+    """distance along rays (origin inside the box) to the box surface."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (bmin - o) / d
+        t2 = (bmax - o) / d
+    tfar = np.nanmin(np.maximum(t1, t2), axis=1)
+    return tfar
+
+
+def _ray_box_enter(o, d, bmin, bmax):
+    """distance to the first hit of a box seen from outside (inf when missed)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (bmin - o) / d
+        t2 = (bmax - o) / d
+    tn = np.nanmax(np.minimum(t1, t2), axis=1)
+    tf = np.nanmin(np.maximum(t1, t2), axis=1)
+    hit = (tn <= tf) & (tn > 0.0)
+    return np.where(hit, tn, np.inf)
+
+
+def hdl32_scan(pose, n_azimuth, seed, sigma=0.02, rmin=0.4, rmax=100.0):
+    """One sweep of a 32-beam lidar at world pose `pose` (4x4, sensor -> world); returns points in the
+    SENSOR frame, firing order (azimuth-major, 32 beams per azimuth step)."""
+    rng = np.random.default_rng(seed)
+    az = (2.0 * np.pi / n_azimuth) * np.arange(n_azimuth)
+    el = np.radians(HDL32_ELEV_DEG)
+    ca, sa = np.cos(az)[:, None], np.sin(az)[:, None]
+    ce, se = np.cos(el)[None, :], np.sin(el)[None, :]
+    d_s = np.stack([ca * ce, sa * ce, np.broadcast_to(se, (n_azimuth, 32))], axis=-1).reshape(-1, 3)
+    R, o = pose[:3, :3], pose[:3, 3]
+    d_w = d_s @ R.T
+    o_w = np.broadcast_to(o, d_w.shape)
+    t = _ray_box_exit(o_w, d_w, *ROOM)
+    for bmin, bmax in OBSTACLES:
+        t = np.minimum(t, _ray_box_enter(o_w, d_w, bmin, bmax))
+    r = t + rng.normal(0.0, sigma, size=t.shape)
+    keep = (r >= rmin) & (r <= rmax) & np.isfinite(r)
+    return (d_s[keep] * r[keep, None]).astype(np.float32)
+
+
+def sensor_pose(x, y, yaw_deg, z=SENSOR_HEIGHT):
+    return make_T(rot_z(np.radians(yaw_deg)), np.array([x, y, z]))
+
+
+def hdl32_pair(n_azimuth, seed_tgt, seed_src, dx=0.5, dy=0.1, dyaw_deg=3.0, base=(0.0, 0.0, 0.0)):
+    """(source, target, T_gt) for two sweeps taken at poses P1 (target) and P2 (source)."""
+    P1 = sensor_pose(base[0], base[1], base[2])
+    P2 = P1 @ make_T(rot_z(np.radians(dyaw_deg)), np.array([dx, dy, 0.0]))
+    tgt = hdl32_scan(P1, n_azimuth, seed_tgt)
+    src = hdl32_scan(P2, n_azimuth, seed_src)
+    return src, tgt, inv_T(P1) @ P2
+
+
+def config2():
+    """32 x 2188 = 70 016 rays per sweep."""
+    return hdl32_pair(2188, 100, 101)
+
+
+def config3():
+    """32 x 3125 = 100 000 rays per sweep."""
+    return hdl32_pair(3125, 100, 101)
+
+
+def config4_pair(k, n_azimuth=3125):
+    """k-th loop-closure candidate pair of config 4 (seeds 1000+k): random base pose in the room,
+    random relative motion <= 5 deg / <= 0.5 m (yaw + planar translation dominate, as for a ground robot)."""
+    rng = np.random.default_rng(1000 + k)
+    base = (rng.uniform(-6.0, 6.0), rng.uniform(-4.0, 4.0), rng.uniform(-180.0, 180.0))
+    dyaw = rng.uniform(-5.0, 5.0)
+    dx, dy = rng.uniform(-0.35, 0.35, size=2)
+    return hdl32_pair(n_azimuth, 2000 + 2 * k, 2001 + 2 * k, dx=dx, dy=dy, dyaw_deg=dyaw, base=base)
+
+
+def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
+    """(live scan, map, T_gt): map = n_scans sweeps along a 10 m straight trajectory merged in the frame
+    of the first sweep and de-duplicated on a `dedup` grid (~2 M points at the defaults); live scan = one
+    more sweep 0.3 m / 2 deg off the trajectory's midpoint."""
+    P0 = sensor_pose(-5.0, 0.0, 0.0)
+    parts = []
+    for i in range(n_scans):
+        Pi = sensor_pose(-5.0 + 10.0 * i / max(1, n_scans - 1), 0.0, 0.0)
+        s = hdl32_scan(Pi, n_azimuth, 500 + i)
+        parts.append(apply_T(inv_T(P0) @ Pi, s))
+    m = np.concatenate(parts)
+    if dedup > 0:
+        q = np.floor(m / dedup).astype(np.int64)
+        key = (q[:, 0] + 4096) + ((q[:, 1] + 4096) << 14) + ((q[:, 2] + 4096) << 28)
+        _, first = np.unique(key, return_index=True)
+        m = m[np.sort(first)]
+    Pl = sensor_pose(0.3, 0.2, 2.0)
+    live = hdl32_scan(Pl, n_azimuth, 777)
+    return live, m.astype(np.float32), inv_T(P0) @ Pl
+
+
+def perturb(T, rng, deg, trans):
+    """A noisy initial guess around T (odometry prior)."""
+    return T @ random_T(rng, deg, trans)

@@ -1,0 +1,139 @@
+"""ctypes wrapper of oracle/libm3d_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product package
+(mandala_mapping_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mandala_mapping_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few hundred ms). Called by __graft_entry__.build()."""
+    targets = ["libm3d_oracle.so", "libm3d_oracle_omp.so"]
+    if force or not all(os.path.exists(os.path.join(_HERE, t)) for t in targets):
+        subprocess.run(["make", "-C", _HERE, "-s"] + targets, check=True)
+
+
+def _lib(omp=False):
+    name = "libm3d_oracle_omp.so" if omp else "libm3d_oracle.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        vp, i32p, u32p, f32p, f64p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+        L.orc_default_params.argtypes = [C.POINTER(abi.Params)]
+        L.orc_cloud_create.argtypes = [C.POINTER(abi.Params), vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+        L.orc_cloud_destroy.argtypes = [vp]
+        L.orc_cloud_destroy.restype = None
+        L.orc_cloud_grid_info.argtypes = [vp, C.c_int, C.POINTER(abi.GridInfo)]
+        L.orc_cloud_export.argtypes = [vp, C.c_int, u32p, u32p, i32p, f32p, f32p, u32p, i32p]
+        L.orc_debug_nn.argtypes = [vp, C.c_int, f32p, C.c_size_t, C.c_float, i32p, f32p]
+        L.orc_debug_accumulate.argtypes = [C.POINTER(abi.Params), vp, vp, C.c_int, f32p, i64p, i32p, i32p, f32p]
+        L.orc_align_clouds.argtypes = [C.POINTER(abi.Params), vp, vp, f32p, f32p, C.POINTER(abi.Stats), f64p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _LIBS[name] = L
+    return _LIBS[name]
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
+
+
+def default_params():
+    p = abi.Params()
+    _lib().orc_default_params(C.byref(p))
+    return p
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise abi.M3dregError(rc, "oracle." + where)
+
+
+class Cloud:
+    """A bucketed cloud held by the oracle."""
+
+    def __init__(self, params, data, n=None, point_step=16, offsets=(0, 4, 8), omp=False):
+        self._L = _lib(omp)
+        if isinstance(data, np.ndarray) and data.dtype == np.float32 and data.ndim == 2 and data.shape[1] == 3:
+            from mandala_mapping_amd.pointcloud2 import encode_xyz
+            msg = encode_xyz(data, point_step, offsets)
+            data, n = msg.data, msg.n
+        self.n = int(n)
+        self.params = params
+        self._h = C.c_void_p()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        _check(self._L.orc_cloud_create(C.byref(params), buf, self.n, point_step, offsets[0], offsets[1], offsets[2], C.byref(self._h)), "cloud_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_cloud_destroy(self._h)
+            self._h = None
+
+    def grid_info(self, level=0):
+        g = abi.GridInfo()
+        _check(self._L.orc_cloud_grid_info(self._h, level, C.byref(g)), "grid_info")
+        return g
+
+    def export(self, level=0):
+        g = self.grid_info(level)
+        n = self.n
+        out = {
+            "keys": np.empty(n, np.uint32), "sorted_keys": np.empty(n, np.uint32), "perm": np.empty(n, np.int32),
+            "sorted_xyz": np.empty((n, 3), np.float32),
+            "normals": np.empty((n, 3), np.float32) if g.has_normals else None,
+            "cell_key": np.empty(g.n_cells, np.uint32), "cell_start": np.empty(g.n_cells + 1, np.int32),
+        }
+        _check(self._L.orc_cloud_export(self._h, level, _ptr(out["keys"], C.c_uint32), _ptr(out["sorted_keys"], C.c_uint32),
+                                        _ptr(out["perm"], C.c_int32), _ptr(out["sorted_xyz"], C.c_float),
+                                        _ptr(out["normals"], C.c_float), _ptr(out["cell_key"], C.c_uint32),
+                                        _ptr(out["cell_start"], C.c_int32)), "cloud_export")
+        return out
+
+    def nn(self, queries, max_corr_dist, level=0):
+        q = np.ascontiguousarray(queries, np.float32)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float32)
+        _check(self._L.orc_debug_nn(self._h, level, _ptr(q, C.c_float), len(q), max_corr_dist, _ptr(idx, C.c_int32), _ptr(d2, C.c_float)), "debug_nn")
+        return idx, d2
+
+
+def _T16(T):
+    """4x4 (row-major numpy) -> column-major float32[16]."""
+    return np.ascontiguousarray(np.asarray(T, np.float64).T.reshape(16), np.float32)
+
+
+def _from16(t, dtype=np.float64):
+    return np.asarray(t, dtype).reshape(4, 4).T.copy()
+
+
+def accumulate(params, src, tgt, T, level=0, want_nn=False):
+    sums = np.zeros(abi.NSUMS, np.int64)
+    exps = np.zeros(6, np.int32)
+    nn = np.empty(src.n, np.int32) if want_nn else None
+    d2 = np.empty(src.n, np.float32) if want_nn else None
+    t = _T16(T)
+    _check(tgt._L.orc_debug_accumulate(C.byref(params), src._h, tgt._h, level, _ptr(t, C.c_float), _ptr(sums, C.c_int64),
+                                       _ptr(exps, C.c_int32), _ptr(nn, C.c_int32), _ptr(d2, C.c_float)), "debug_accumulate")
+    return (sums, exps, nn, d2) if want_nn else (sums, exps)
+
+
+def align(params, src, tgt, init_T=None, trace_cap=0):
+    """Returns (T 4x4 float32-valued float64 array, Stats, trace [k,4,4] float64)."""
+    t0 = _T16(np.eye(4) if init_T is None else init_T)
+    out = np.zeros(16, np.float32)
+    st = abi.Stats()
+    trace = np.zeros((max(trace_cap, 1), 16), np.float64)
+    tn = C.c_size_t(0)
+    _check(tgt._L.orc_align_clouds(C.byref(params), src._h, tgt._h, _ptr(t0, C.c_float), _ptr(out, C.c_float), C.byref(st),
+                                   _ptr(trace, C.c_double) if trace_cap else None, trace_cap, C.byref(tn)), "align_clouds")
+    k = min(tn.value, trace_cap)
+    return _from16(out), st, np.stack([_from16(trace[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))

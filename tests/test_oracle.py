@@ -1,0 +1,217 @@
+"""Pins the CPU oracle (oracle/m3d_oracle.c). The reference holds no golden vectors for this path
+(parity unpinned), so the oracle is pinned by ground truth by construction, by an
+independent NN implementation (scipy cKDTree) and by brute force in numpy."""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from mandala_mapping_amd import abi, synth
+
+
+def _valid_normals(e):
+    return np.abs(e["normals"]).sum(1) > 0
+
+
+def test_voxel_keys_match_numpy_restatement(orc):
+    rng = np.random.default_rng(7)
+    xyz = rng.uniform(-5, 7, size=(5000, 3)).astype(np.float32)
+    xyz[17] = [np.nan, 0, 0]
+    xyz[99] = [0, np.inf, 0]
+    p = abi.Params.make(leaf=0.3, metric=abi.POINT_TO_POINT)
+    c = orc.Cloud(p, xyz)
+    g, e = c.grid_info(), c.export()
+    ok = np.isfinite(xyz).all(1)
+    assert g.n == 5000 and g.n_valid == ok.sum()
+    mn = xyz[ok].min(0)
+    mx = xyz[ok].max(0)
+    assert np.array_equal(np.array(g.mn, np.float32), mn) and np.array_equal(np.array(g.mx, np.float32), mx)
+    inv = np.float32(1.0) / np.float32(0.3)
+    assert np.float32(g.inv_leaf) == inv
+    ijk = np.floor((xyz[ok] - mn) * inv).astype(np.int64)  # float32 sub, float32 mul, floor
+    dims = np.floor((mx - mn) * inv).astype(np.int64) + 1
+    assert list(g.dims) == list(dims)
+    bits = [max(1, int(np.ceil(np.log2(d)))) for d in dims]
+    assert list(g.bits) == bits
+    key = ijk[:, 0] | (ijk[:, 1] << bits[0]) | (ijk[:, 2] << (bits[0] + bits[1]))
+    assert np.array_equal(e["keys"][ok], key.astype(np.uint32))
+    assert (e["keys"][~ok] == 0xFFFFFFFF).all()
+    # stable sort
+    perm = np.argsort(e["keys"], kind="stable")
+    assert np.array_equal(e["perm"], perm.astype(np.int32))
+    assert np.array_equal(e["sorted_keys"], e["keys"][perm])
+    assert np.array_equal(e["sorted_xyz"][: g.n_valid], xyz[perm][: g.n_valid])
+    # cell table
+    sk = e["sorted_keys"][: g.n_valid]
+    uk, start = np.unique(sk, return_index=True)
+    assert g.n_cells == len(uk)
+    assert np.array_equal(e["cell_key"], uk) and np.array_equal(e["cell_start"][:-1], start)
+    assert e["cell_start"][-1] == g.n_valid
+
+
+def test_nn_against_ckdtree_and_bruteforce(orc):
+    src, tgt, T = synth.config1(4000)
+    leaf = 0.25
+    p = abi.Params.make(leaf=leaf, metric=abi.POINT_TO_POINT)
+    ct = orc.Cloud(p, tgt)
+    q = synth.apply_T(T, src).astype(np.float32) + np.float32(0.03)
+    idx, d2 = ct.nn(q, 10.0)
+    tree = cKDTree(tgt.astype(np.float64))
+    dk, ik = tree.query(q.astype(np.float64))
+    # (1) whenever the true NN is closer than one leaf it lies inside the 27 cells => same answer
+    near = dk < leaf * 0.999
+    assert near.sum() > 1000
+    assert (idx[near] >= 0).all()
+    same = idx[near] == ik[near]
+    # ties aside, distances must agree
+    d_or = np.sqrt(d2[near].astype(np.float64))
+    assert np.allclose(d_or, dk[near], rtol=1e-5, atol=1e-6)
+    assert same.mean() > 0.999
+    # (2) d2 is exactly the spec's fma chain on float32
+    m = idx >= 0
+    e = (q[m] - tgt[idx[m]]).astype(np.float32)
+    ex, ey, ez = e[:, 0].astype(np.float64), e[:, 1].astype(np.float64), e[:, 2].astype(np.float64)
+    t0 = (ex * ex).astype(np.float32).astype(np.float64)          # float32 product, rounded
+    t1 = (ey * ey + t0).astype(np.float32).astype(np.float64)     # fma: exact product + add, one rounding
+    t2 = (ez * ez + t1).astype(np.float32)
+    assert np.array_equal(t2, d2[m])
+    # (3) brute force over the 27 cells for a sample of queries
+    g = ct.grid_info()
+    mn, inv = np.array(g.mn, np.float32), np.float32(g.inv_leaf)
+    tc = np.floor((tgt - mn) * inv).astype(np.int64)
+    for i in range(0, len(q), 97):
+        qc = np.floor((q[i] - mn) * inv).astype(np.int64)
+        cand = np.where((np.abs(tc - qc) <= 1).all(1))[0]
+        if len(cand) == 0:
+            assert idx[i] == -1
+            continue
+        dd = ((q[i] - tgt[cand]).astype(np.float64) ** 2).sum(1)
+        assert idx[i] in cand
+        assert dd.min() >= (float(d2[i]) * (1 - 1e-5) - 1e-9)
+
+
+def test_nn_max_distance_and_outside_grid(orc):
+    tgt = synth.planes_cloud(3000, 1)
+    p = abi.Params.make(leaf=0.25, metric=abi.POINT_TO_POINT)
+    ct = orc.Cloud(p, tgt)
+    q = np.array([[100.0, 100.0, 100.0], [5.0, 5.0, 0.2], [np.nan, 0, 0]], np.float32)
+    idx, d2 = ct.nn(q, 0.05)
+    assert idx[0] == -1 and idx[2] == -1
+    assert idx[1] == -1  # a match exists in the 27 cells but is farther than 5 cm
+    idx, d2 = ct.nn(q, 0.5)
+    assert idx[1] >= 0 and d2[1] <= 0.25
+
+
+def test_nn_tie_breaks_to_lowest_input_index(orc):
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0.5, 0.5, 0], [1, 0, 0], [0, 0, 0]], np.float32)
+    p = abi.Params.make(leaf=1.0, metric=abi.POINT_TO_POINT)
+    ct = orc.Cloud(p, pts)
+    idx, _ = ct.nn(np.array([[0.5, 0.0, 0.0], [1.0, 0.0, 0.0]], np.float32), 5.0)
+    assert idx[0] == 0  # equidistant to inputs 0,1,3,4 -> lowest
+    assert idx[1] == 1  # duplicates 1 and 3 -> lowest
+
+
+@pytest.mark.parametrize("metric,iters,tol_deg,tol_m", [
+    (abi.POINT_TO_PLANE, 30, 0.05, 0.005),
+    (abi.POINT_TO_POINT, 60, 0.25, 0.02),
+])
+def test_config1_recovers_known_transform(orc, metric, iters, tol_deg, tol_m):
+    """BASELINE config 1: two 10k-point clouds on three orthogonal planes, sigma 1 cm."""
+    src, tgt, Tgt = synth.config1()
+    p = abi.Params.make(leaf=0.25, iterations=iters, max_corr_dist=0.5, metric=metric, normal_leaf=0.5)
+    T, st, tr = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), trace_cap=64)
+    rot, tra = synth.pose_error(T, Tgt)
+    assert st.status in (abi.CONVERGED, abi.MAX_ITERATIONS)
+    assert rot <= tol_deg and tra <= tol_m, (rot, tra, st.as_dict())
+    assert len(tr) == st.iterations
+
+
+def test_noise_free_is_recovered_tightly(orc):
+    tgt = synth.planes_cloud(6000, 5, sigma=0.0)
+    Tgt = synth.make_T(synth.rot_z(0.01) @ synth.rot_x(-0.008), [0.03, -0.02, 0.025])
+    src = synth.apply_T(synth.inv_T(Tgt), synth.planes_cloud(6000, 6, sigma=0.0)).astype(np.float32)
+    p = abi.Params.make(leaf=0.25, iterations=30, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    T, st, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    rot, tra = synth.pose_error(T, Tgt)
+    assert rot < 5e-3 and tra < 1e-3, (rot, tra)  # limited by contaminated normals at the plane edges
+
+
+def test_single_plane_is_rank_deficient(orc):
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 10, size=(4000, 2))
+    tgt = np.c_[xy, np.zeros(4000)].astype(np.float32)
+    src = (tgt + np.float32([0.0, 0.0, 0.02])).astype(np.float32)
+    p = abi.Params.make(leaf=0.5, iterations=5, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    T, st, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    assert st.status == abi.RANK_DEFICIENT
+    assert np.array_equal(T, np.eye(4))
+
+
+def test_too_few_correspondences(orc):
+    tgt = synth.planes_cloud(2000, 1)
+    src = (tgt + np.float32(50.0)).astype(np.float32)
+    p = abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_POINT)
+    T, st, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    assert st.status == abi.TOO_FEW_CORR and st.iterations == 1 and st.n_corr == 0
+
+
+def test_result_is_invariant_to_source_order(orc):
+    """Integer fixed-point sums make the whole trajectory independent of summation order."""
+    src, tgt, _ = synth.config1(3000)
+    p = abi.Params.make(leaf=0.25, iterations=8, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    ct = orc.Cloud(p, tgt)
+    T0, _, tr0 = orc.align(p, orc.Cloud(p, src), ct, trace_cap=16)
+    perm = np.random.default_rng(0).permutation(len(src))
+    T1, _, tr1 = orc.align(p, orc.Cloud(p, src[perm]), ct, trace_cap=16)
+    assert np.array_equal(tr0, tr1) and np.array_equal(T0, T1)
+
+
+def test_openmp_build_is_bit_identical(orc):
+    src, tgt, _ = synth.config1(3000)
+    p = abi.Params.make(leaf=0.25, iterations=6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    a = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), trace_cap=8)
+    b = orc.align(p, orc.Cloud(p, src, omp=True), orc.Cloud(p, tgt, omp=True), trace_cap=8)
+    assert np.array_equal(a[2], b[2])
+
+
+def test_normals_on_planes_and_scanline_rejection(orc):
+    tgt = synth.planes_cloud(9000, 11, sigma=0.005)
+    p = abi.Params.make(leaf=0.25, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    e = orc.Cloud(p, tgt).export()
+    ok = _valid_normals(e)
+    assert ok.mean() > 0.85
+    n, x = e["normals"][ok], e["sorted_xyz"][ok]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+    # away from the plane intersections the normal is the plane's axis
+    inner = (x > 1.0).sum(1) == 2
+    dom = np.abs(n[inner]).max(1)
+    assert (dom > 0.99).mean() > 0.98
+    assert (n[np.arange(len(n)), np.abs(n).argmax(1)] > 0).all()  # canonical sign
+    # a single scan line (all points on one line + noise across it) has no usable normal
+    t = np.linspace(0, 5, 2000)
+    line = np.c_[t, 0.01 * np.sin(40 * t), np.zeros_like(t)].astype(np.float32)
+    e = orc.Cloud(p, line).export()
+    assert not _valid_normals(e).any()
+
+
+def test_pointcloud2_layouts_give_identical_clouds(orc):
+    from mandala_mapping_amd import pointcloud2 as pc2
+    xyz = synth.planes_cloud(1500, 2)
+    p = abi.Params.make(leaf=0.25, metric=abi.POINT_TO_POINT)
+    a = orc.Cloud(p, xyz).export()
+    m = pc2.encode_xyz(xyz, point_step=32, offsets=(4, 12, 20))
+    b = orc.Cloud(p, m.data, m.n, 32, (4, 12, 20)).export()
+    assert all(np.array_equal(a[k], b[k]) for k in ("keys", "perm", "sorted_xyz"))
+    be = pc2.encode_xyz(xyz, big_endian=True)
+    assert np.array_equal(pc2.decode_xyz(be), xyz)
+    assert pc2.to_little_endian(be).data == pc2.encode_xyz(xyz).data
+
+
+def test_grid_too_large_and_empty(orc):
+    p = abi.Params.make(leaf=0.001, metric=abi.POINT_TO_POINT)
+    far = np.array([[0, 0, 0], [5000, 5000, 5000]], np.float32)
+    with pytest.raises(abi.M3dregError) as ei:
+        orc.Cloud(p, far)
+    assert ei.value.code == abi.ERR_GRID_TOO_LARGE
+    with pytest.raises(abi.M3dregError) as ei:
+        orc.Cloud(p, np.full((4, 3), np.nan, np.float32))
+    assert ei.value.code == abi.ERR_EMPTY_CLOUD
