@@ -1,0 +1,284 @@
+"""ctypes binding of libm3dreg.so (include/m3dreg.h) and the host-side mirror of the
+`gpu_6dslam_node` call surface.
+
+The reference couples the aggregator to the registration node through a ROS topic
+(/root/reference/m3d/m3d_husky_launch/launch/m3d_husky_bringup.launch:13 starts `gpu_6dslam_node`;
+/root/reference/m3d/m3d_aggregator/src/m3d_aggregator.cpp:174,209 publishes the PointCloud2 it
+consumes). `Gpu6dSlamNode` below is that consumer: `on_cloud(msg)` is the topic callback.
+
+There is no CPU fallback anywhere in this module: if the HIP library is missing or no MI355X is
+visible, loading/creating fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .pointcloud2 import PointCloud2, encode_xyz, to_little_endian
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libm3dreg.so")
+_lib = None
+
+EXPORTS = [
+    "m3dreg_default_params", "m3dreg_create", "m3dreg_destroy", "m3dreg_backend_name", "m3dreg_last_error",
+    "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
+    "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
+    "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
+    "m3dreg_debug_accumulate", "m3dreg_debug_trace",
+]
+
+
+def lib():
+    """Load libm3dreg.so once. torch (when installed) is imported first so that this process ends up
+    with a single HIP runtime: torch bundles libamdhip64.so.7 under the same soname the library needs."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the registration path)")
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, sz = C.c_void_p, C.c_size_t
+    f32p, f64p, i32p, u32p, i64p = (C.POINTER(t) for t in (C.c_float, C.c_double, C.c_int32, C.c_uint32, C.c_int64))
+    L.m3dreg_default_params.argtypes = [C.POINTER(abi.Params)]
+    L.m3dreg_create.argtypes = [C.POINTER(abi.Params), C.c_int, vp, C.POINTER(vp)]
+    L.m3dreg_destroy.argtypes = [vp]
+    L.m3dreg_backend_name.restype = C.c_char_p
+    L.m3dreg_last_error.argtypes = [vp]
+    L.m3dreg_last_error.restype = C.c_char_p
+    L.m3dreg_set_target_xyz.argtypes = [vp, vp, sz, sz, sz, sz, sz]
+    L.m3dreg_align.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p, f32p, C.POINTER(abi.Stats)]
+    L.m3dreg_cloud_create.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
+    L.m3dreg_cloud_destroy.argtypes = [vp, vp]
+    L.m3dreg_align_clouds.argtypes = [vp, vp, vp, f32p, f32p, C.POINTER(abi.Stats)]
+    L.m3dreg_align_batch.argtypes = [vp, C.POINTER(abi.Pair), sz, f32p, C.POINTER(abi.Stats)]
+    L.m3dreg_align_batch_async.argtypes = [vp, C.POINTER(abi.Pair), sz]
+    L.m3dreg_batch_wait.argtypes = [vp, f32p, C.POINTER(abi.Stats)]
+    L.m3dreg_synchronize.argtypes = [vp]
+    L.m3dreg_get_stream.argtypes = [vp]
+    L.m3dreg_get_stream.restype = vp
+    L.m3dreg_cloud_levels.argtypes = [vp]
+    L.m3dreg_cloud_grid_info.argtypes = [vp, vp, C.c_int, C.POINTER(abi.GridInfo)]
+    L.m3dreg_cloud_export.argtypes = [vp, vp, C.c_int, u32p, u32p, i32p, f32p, f32p]
+    L.m3dreg_debug_nn.argtypes = [vp, vp, C.c_int, f32p, sz, C.c_float, i32p, f32p]
+    L.m3dreg_debug_accumulate.argtypes = [vp, vp, vp, C.c_int, f32p, i64p, i32p]
+    L.m3dreg_debug_trace.argtypes = [vp, f64p, sz, C.POINTER(sz)]
+    if L.m3dreg_abi_version() != abi.ABI_VERSION:
+        raise RuntimeError("libm3dreg.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def default_params():
+    p = abi.Params()
+    lib().m3dreg_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
+
+
+def T_to_colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, np.float64).T.reshape(16), np.float32)
+
+
+def colmajor16_to_T(t, dtype=np.float64):
+    return np.asarray(t, dtype).reshape(4, 4).T.copy()
+
+
+class Cloud:
+    """A bucketed cloud resident in HBM (m3dreg_cloud)."""
+
+    def __init__(self, reg, ptr, n):
+        self._reg, self._p, self.n = reg, ptr, n
+
+    def free(self):
+        if self._p:
+            lib().m3dreg_cloud_destroy(self._reg._h, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            if self._p and self._reg._h:
+                self.free()
+        except Exception:
+            pass
+
+    def grid_info(self, level=0):
+        g = abi.GridInfo()
+        self._reg._check(lib().m3dreg_cloud_grid_info(self._reg._h, self._p, level, C.byref(g)), "cloud_grid_info")
+        return g
+
+    def export(self, level=0):
+        g = self.grid_info(level)
+        n = self.n
+        out = {"keys": np.empty(n, np.uint32), "sorted_keys": np.empty(n, np.uint32), "perm": np.empty(n, np.int32),
+               "sorted_xyz": np.empty((n, 3), np.float32), "normals": np.empty((n, 3), np.float32) if g.has_normals else None}
+        self._reg._check(lib().m3dreg_cloud_export(self._reg._h, self._p, level, _ptr(out["keys"], C.c_uint32),
+                                                   _ptr(out["sorted_keys"], C.c_uint32), _ptr(out["perm"], C.c_int32),
+                                                   _ptr(out["sorted_xyz"], C.c_float), _ptr(out["normals"], C.c_float)), "cloud_export")
+        return out
+
+    def nn(self, queries, max_corr_dist, level=0):
+        q = np.ascontiguousarray(queries, np.float32)
+        idx, d2 = np.empty(len(q), np.int32), np.empty(len(q), np.float32)
+        self._reg._check(lib().m3dreg_debug_nn(self._reg._h, self._p, level, _ptr(q, C.c_float), len(q), max_corr_dist,
+                                               _ptr(idx, C.c_int32), _ptr(d2, C.c_float)), "debug_nn")
+        return idx, d2
+
+
+class Registrar:
+    """One m3dreg_handle: a device, a stream, a parameter set."""
+
+    def __init__(self, params=None, device=0, stream=None):
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        rc = lib().m3dreg_create(C.byref(self.params), device, stream, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise abi.M3dregError(rc, "m3dreg_create", "no usable MI355X / HIP runtime (no CPU fallback exists)" if rc == abi.ERR_NO_DEVICE else "")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().m3dreg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise abi.M3dregError(rc, where, lib().m3dreg_last_error(self._h).decode())
+
+    @property
+    def stream(self):
+        return lib().m3dreg_get_stream(self._h)
+
+    def synchronize(self):
+        self._check(lib().m3dreg_synchronize(self._h), "synchronize")
+
+    # ---- clouds -------------------------------------------------------------------------------
+    def cloud(self, data, n=None, point_step=16, offsets=(0, 4, 8)):
+        """data: float32 [n,3] array, PointCloud2, or raw payload bytes."""
+        if isinstance(data, np.ndarray):
+            data = encode_xyz(data)
+        if isinstance(data, PointCloud2):
+            msg = to_little_endian(data)
+            data, n, point_step, offsets = msg.data, msg.n, msg.point_step, msg.xyz_offsets()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        p = C.c_void_p()
+        self._check(lib().m3dreg_cloud_create(self._h, buf, n, point_step, offsets[0], offsets[1], offsets[2], 0, C.byref(p)), "cloud_create")
+        return Cloud(self, p, n)
+
+    def cloud_from_device(self, dev_ptr, n, point_step=16, offsets=(0, 4, 8)):
+        """dev_ptr: integer device address of a PointCloud2-layout payload already in HBM."""
+        p = C.c_void_p()
+        self._check(lib().m3dreg_cloud_create(self._h, C.c_void_p(dev_ptr), n, point_step, offsets[0], offsets[1], offsets[2], 1, C.byref(p)), "cloud_create(device)")
+        return Cloud(self, p, n)
+
+    # ---- registration -------------------------------------------------------------------------
+    def align(self, source: Cloud, target: Cloud, init_T=None):
+        t0 = T_to_colmajor16(np.eye(4) if init_T is None else init_T)
+        out = np.zeros(16, np.float32)
+        st = abi.Stats()
+        self._check(lib().m3dreg_align_clouds(self._h, source._p, target._p, _ptr(t0, C.c_float), _ptr(out, C.c_float), C.byref(st)), "align_clouds")
+        return colmajor16_to_T(out), st
+
+    def _pairs(self, pairs):
+        arr = (abi.Pair * len(pairs))()
+        for i, pr in enumerate(pairs):
+            s, t = pr[0], pr[1]
+            T0 = pr[2] if len(pr) > 2 and pr[2] is not None else np.eye(4)
+            arr[i].source, arr[i].target = s._p.value, t._p.value
+            arr[i].init_T[:] = T_to_colmajor16(T0).tolist()
+        return arr
+
+    def align_batch(self, pairs):
+        """pairs: list of (source Cloud, target Cloud[, init_T]). Returns ([k,4,4] poses, [Stats])."""
+        arr = self._pairs(pairs)
+        k = len(pairs)
+        out = np.zeros((k, 16), np.float32)
+        st = (abi.Stats * k)()
+        self._check(lib().m3dreg_align_batch(self._h, arr, k, _ptr(out, C.c_float), st), "align_batch")
+        return np.stack([colmajor16_to_T(out[i]) for i in range(k)]), list(st)
+
+    def align_batch_async(self, pairs_arr, k):
+        self._check(lib().m3dreg_align_batch_async(self._h, pairs_arr, k), "align_batch_async")
+
+    def batch_wait(self, k):
+        out = np.zeros((k, 16), np.float32)
+        st = (abi.Stats * k)()
+        self._check(lib().m3dreg_batch_wait(self._h, _ptr(out, C.c_float), st), "batch_wait")
+        return np.stack([colmajor16_to_T(out[i]) for i in range(k)]), list(st)
+
+    # ---- the gpu_6dslam_node surface ------------------------------------------------------------
+    def set_target(self, msg: PointCloud2):
+        msg = to_little_endian(msg)
+        ox, oy, oz = msg.xyz_offsets()
+        buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+        self._check(lib().m3dreg_set_target_xyz(self._h, buf, msg.n, msg.point_step, ox, oy, oz), "set_target_xyz")
+
+    def align_msg(self, msg: PointCloud2, init_T=None):
+        msg = to_little_endian(msg)
+        ox, oy, oz = msg.xyz_offsets()
+        buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+        t0 = T_to_colmajor16(np.eye(4) if init_T is None else init_T)
+        out = np.zeros(16, np.float32)
+        st = abi.Stats()
+        self._check(lib().m3dreg_align(self._h, buf, msg.n, msg.point_step, ox, oy, oz, _ptr(t0, C.c_float), _ptr(out, C.c_float), C.byref(st)), "align")
+        return colmajor16_to_T(out), st
+
+    # ---- introspection --------------------------------------------------------------------------
+    def accumulate(self, source: Cloud, target: Cloud, T, level=0):
+        sums, exps = np.zeros(abi.NSUMS, np.int64), np.zeros(6, np.int32)
+        t = T_to_colmajor16(T)
+        self._check(lib().m3dreg_debug_accumulate(self._h, source._p, target._p, level, _ptr(t, C.c_float), _ptr(sums, C.c_int64), _ptr(exps, C.c_int32)), "debug_accumulate")
+        return sums, exps
+
+    def trace(self, cap=256):
+        buf = np.zeros((cap, 16), np.float64)
+        n = C.c_size_t(0)
+        self._check(lib().m3dreg_debug_trace(self._h, _ptr(buf, C.c_double), cap, C.byref(n)), "debug_trace")
+        k = min(n.value, cap)
+        return np.stack([colmajor16_to_T(buf[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))
+
+
+class Gpu6dSlamNode:
+    """Host-side mirror of the node the reference launches as `gpu_6dslam_node`
+    (m3d_husky_bringup.launch:13): it receives the aggregator's clouds one at a time (queue depth 1,
+    m3d_aggregator.cpp:174) and registers every cloud against the previous one, chaining the poses
+    into an odometry estimate. The ROS wiring itself (subscriber, tf broadcaster) is the source-only
+    shim in ros/gpu_6dslam_node.cpp; this class is what tests and bench drive."""
+
+    def __init__(self, params=None, device=0):
+        self.reg = Registrar(params, device)
+        self.pose = np.eye(4)          # pose of the latest cloud in the frame of the first
+        self.last_delta = np.eye(4)    # constant-velocity prior for the next registration
+        self._have_target = False
+        self.history = []
+
+    def on_cloud(self, msg: PointCloud2):
+        """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None)."""
+        if not self._have_target:
+            self.reg.set_target(msg)
+            self._have_target = True
+            self.history.append((self.pose.copy(), None))
+            return self.pose.copy(), None
+        T, st = self.reg.align_msg(msg, self.last_delta)
+        if st.status in (abi.CONVERGED, abi.MAX_ITERATIONS):
+            self.last_delta = T
+            self.pose = self.pose @ T
+        self.reg.set_target(msg)
+        self.history.append((self.pose.copy(), st))
+        return self.pose.copy(), st

@@ -1,0 +1,357 @@
+// bucket.hip — SURVEY.md §8 rows a2 (decode), a3 (voxel keys), a4 (bucketing) and a9 (normals) as
+// hand-written HIP for gfx950. No reference source exists for these stages (the reference's
+// gpu_6dslam is an empty submodule); the nearest in-tree analogue is the pcl::VoxelGrid(0.1) use at
+// /root/reference/m3d/m3d_calibration/src/m3d_calibration_twiddle.cpp:279-286. The normative
+// arithmetic is DESIGN.md §Spec; oracle/m3d_oracle.c restates it on the CPU.
+//
+// All of this is HBM-bound integer/byte work: coalesced 4-B/16-B streams, LDS histograms and
+// wave64 ballots for the stable in-block ranks; no MFMA (nothing here is a contraction).
+#include "m3d_kernels.h"
+
+#define RS_THREADS 256
+#define RS_ROUNDS 8
+#define RS_TILE (RS_THREADS * RS_ROUNDS)
+#define RS_WAVES (RS_THREADS / 64)
+
+// ---- a2: PointCloud2 payload -> SoA + exact AABB ------------------------------------------------
+__device__ __forceinline__ uint32_t ord_f32(float f) {   // order-preserving float -> uint map
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unord_f32(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    union { uint32_t u; float f; } c; c.u = u; return c.f;
+}
+float m3d_unord_f32(uint32_t u) { return unord_f32(u); }
+
+// aabb[0..2] = ordered min, aabb[3..5] = ordered max, aabb[6] = n_valid
+__global__ __launch_bounds__(256) void k_decode_aabb(const uint8_t* __restrict__ raw, int n, int step, int ox, int oy, int oz,
+                                                     float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                                                     uint32_t* __restrict__ aabb) {
+    uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0u, 0u, 0u };
+    uint32_t cnt = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint8_t* p = raw + (size_t)i * step;
+        float px = *reinterpret_cast<const float*>(p + ox);
+        float py = *reinterpret_cast<const float*>(p + oy);
+        float pz = *reinterpret_cast<const float*>(p + oz);
+        x[i] = px; y[i] = py; z[i] = pz;
+        if (m3d_finite3(px, py, pz)) {
+            uint32_t a = ord_f32(px), b = ord_f32(py), c = ord_f32(pz);
+            mn[0] = min(mn[0], a); mx[0] = max(mx[0], a);
+            mn[1] = min(mn[1], b); mx[1] = max(mx[1], b);
+            mn[2] = min(mn[2], c); mx[2] = max(mx[2], c);
+            cnt++;
+        }
+    }
+    // wave64 shuffle reduction, then one set of integer atomics per wave (exact, order-independent)
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int a = 0; a < 3; a++) {
+            mn[a] = min(mn[a], (uint32_t)__shfl_down((int)mn[a], o));
+            mx[a] = max(mx[a], (uint32_t)__shfl_down((int)mx[a], o));
+        }
+        cnt += __shfl_down((int)cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        for (int a = 0; a < 3; a++) { atomicMin(&aabb[a], mn[a]); atomicMax(&aabb[3 + a], mx[a]); }
+        atomicAdd(&aabb[6], cnt);
+    }
+}
+
+// ---- a3: voxel key per point ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voxel_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                    int n, M3dGrid g, uint32_t* __restrict__ keys, uint32_t* __restrict__ skey,
+                                                    uint32_t* __restrict__ sval) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float px = x[i], py = y[i], pz = z[i];
+    uint32_t key = M3D_INVALID_KEY;
+    if (m3d_finite3(px, py, pz)) {
+        uint32_t ix = (uint32_t)(int)m3d_cell_f(px, g.mn[0], g.inv_leaf);
+        uint32_t iy = (uint32_t)(int)m3d_cell_f(py, g.mn[1], g.inv_leaf);
+        uint32_t iz = (uint32_t)(int)m3d_cell_f(pz, g.mn[2], g.inv_leaf);
+        key = ix | (iy << g.sy) | (iz << g.sz);
+    }
+    keys[i] = key; skey[i] = key; sval[i] = (uint32_t)i;
+}
+
+// ---- a4: stable LSD radix sort, 8-bit digits ------------------------------------------------------
+// pass = histogram per tile -> exclusive scan over [digit][tile] -> stable scatter
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                        uint32_t* __restrict__ hist, int ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        int i = base + r * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// single-workgroup exclusive scan of `total` counters (total = 256 * ntiles, a few 10^5 at most)
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ hist, int total) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    const int b = t * per, e = min(b + per, total);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += hist[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan in LDS
+        uint32_t v = (t >= o) ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int i = b; i < e; i++) { uint32_t v = hist[i]; hist[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                           uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int n, int shift,
+                                                           const uint32_t* __restrict__ scanned, int ntiles) {
+    __shared__ uint32_t cnt[RS_ROUNDS * RS_WAVES][256];   // 32 KiB: per (round, wave) digit counts
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+    uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rank[RS_ROUNDS];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int i = base + r * RS_THREADS + t;
+        const bool ok = i < n;
+        key[r] = ok ? kin[i] : 0u;
+        val[r] = ok ? vin[i] : 0u;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        // lanes of this wave holding the same digit: 8 ballots (wave64 "match_any")
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(ok && bit);
+            m &= bit ? bal : ~bal;
+        }
+        rank[r] = (uint32_t)__popcll(m & lt);
+        if (ok && rank[r] == 0) cnt[r * RS_WAVES + wave][d] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    {   // thread t owns digit t: exclusive scan over the (round, wave) slots, seeded with the global offset
+        uint32_t run = scanned[t * ntiles + blockIdx.x];
+        for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) { uint32_t v = cnt[s][t]; cnt[s][t] = run; run += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int i = base + r * RS_THREADS + t;
+        if (i < n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = cnt[r * RS_WAVES + wave][d] + rank[r];
+            kout[pos] = key[r]; vout[pos] = val[r];
+        }
+    }
+}
+
+// ---- a4: cell heads -> hash table, cell-sorted float4 points (+ normals gathered into the same order)
+__global__ __launch_bounds__(256) void k_finalize_level(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval, int n,
+                                                        const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                        const float4* __restrict__ nrm_in, float4* __restrict__ pts, float4* __restrict__ nrm,
+                                                        uint2* __restrict__ htab, uint32_t hmask, int hshift, uint32_t* __restrict__ n_cells) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = skey[j];
+    const uint32_t oi = sval[j];
+    const bool valid = k != M3D_INVALID_KEY;
+    const bool head = valid && (j == 0 || skey[j - 1] != k);
+    const bool last = valid && (j == n - 1 || skey[j + 1] != k);
+    float4 p;
+    p.x = x[oi]; p.y = y[oi]; p.z = z[oi];
+    p.w = __uint_as_float(oi | (last ? M3D_LAST_FLAG : 0u));
+    pts[j] = p;
+    if (nrm) nrm[j] = valid ? nrm_in[oi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (head) {
+        uint32_t h = m3d_hash_slot(k, hshift);
+        for (;;) {   // keys are unique here, so a successful CAS owns the slot
+            uint32_t old = atomicCAS(&htab[h].x, M3D_INVALID_KEY, k);
+            if (old == M3D_INVALID_KEY) { htab[h].y = (uint32_t)j; break; }
+            h = (h + 1) & hmask;
+        }
+        atomicAdd(n_cells, 1u);
+    }
+}
+
+// ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
+__device__ __forceinline__ void sym3_square(const double m[6], double o[6]) {
+    o[0] = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+    o[1] = m[0] * m[1] + m[1] * m[3] + m[2] * m[4];
+    o[2] = m[0] * m[2] + m[1] * m[4] + m[2] * m[5];
+    o[3] = m[1] * m[1] + m[3] * m[3] + m[4] * m[4];
+    o[4] = m[1] * m[2] + m[3] * m[4] + m[4] * m[5];
+    o[5] = m[2] * m[2] + m[4] * m[4] + m[5] * m[5];
+}
+__device__ __forceinline__ double sym3_maxabs(const double m[6]) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double v = fabs(m[i]); if (v > a) a = v; }
+    return a;
+}
+__device__ __forceinline__ double det_rsqrt(double x) {   // spec: bit-trick seed + 5 Newton steps, no sqrt
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    b = 0x5FE6EB50C7B537A9ull - (b >> 1);
+    double y = __longlong_as_double((long long)b);
+    const double hx = 0.5 * x;
+#pragma unroll
+    for (int i = 0; i < 5; i++) y = y * (1.5 - hx * y * y);
+    return y;
+}
+
+__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, float plane_ratio, int min_pts, float min_spread,
+                                                 float4* __restrict__ nrm_in) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L.g.n_valid) return;
+    const M3dGrid& g = L.g;
+    const float4 pj = L.pts[j];
+    const uint32_t oi = __float_as_uint(pj.w) & ~M3D_LAST_FLAG;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf);
+    const int icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf);
+    const int icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
+    double s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+    int k = 0;
+    for (int dz = -1; dz <= 1; dz++) { const int cz = icz + dz; if (cz < 0 || cz >= g.dims[2]) continue;
+    for (int dy = -1; dy <= 1; dy++) { const int cy = icy + dy; if (cy < 0 || cy >= g.dims[1]) continue;
+    for (int dx = -1; dx <= 1; dx++) { const int cx = icx + dx; if (cx < 0 || cx >= g.dims[0]) continue;
+        const uint32_t ck = (uint32_t)cx | ((uint32_t)cy << g.sy) | ((uint32_t)cz << g.sz);
+        int t = m3d_find_cell(L.htab, g.hmask, g.hshift, ck);
+        if (t < 0) continue;
+        for (;;) {
+            const float4 q = L.pts[t];
+            const double ex = (double)(q.x - pj.x), ey = (double)(q.y - pj.y), ez = (double)(q.z - pj.z);
+            s0 += ex; s1 += ey; s2 += ez;
+            q0 += ex * ex; q1 += ex * ey; q2 += ex * ez; q3 += ey * ey; q4 += ey * ez; q5 += ez * ez;
+            k++;
+            if (__float_as_uint(q.w) & M3D_LAST_FLAG) break;
+            t++;
+        }
+    }}}
+    do {
+        if (k < min_pts || k < 3) break;
+        const double inv = 1.0 / (double)k;
+        const double m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
+        double c[6] = { q0 * inv - m0 * m0, q1 * inv - m0 * m1, q2 * inv - m0 * m2,
+                        q3 * inv - m1 * m1, q4 * inv - m1 * m2, q5 * inv - m2 * m2 };
+        const double cm = sym3_maxabs(c);
+        if (!(cm > 0.0)) break;
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] = c[i] / cm;
+        const double a[6] = { c[3] * c[5] - c[4] * c[4], c[2] * c[4] - c[1] * c[5], c[1] * c[4] - c[2] * c[3],
+                              c[0] * c[5] - c[2] * c[2], c[1] * c[2] - c[0] * c[4], c[0] * c[3] - c[1] * c[1] };
+        const double am = sym3_maxabs(a);
+        if (!(am > 1e-12)) break;
+        double p[6], t2[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) p[i] = a[i] / am;
+        for (int it = 0; it < 5; it++) {
+            sym3_square(p, t2);
+            const double tm = sym3_maxabs(t2);
+#pragma unroll
+            for (int i = 0; i < 6; i++) p[i] = t2[i] / tm;
+        }
+        double v0, v1, v2;
+        if (p[0] >= p[3] && p[0] >= p[5]) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+        else if (p[3] >= p[5]) { v0 = p[1]; v1 = p[3]; v2 = p[4]; }
+        else { v0 = p[2]; v1 = p[4]; v2 = p[5]; }
+        const double nn = v0 * v0 + v1 * v1 + v2 * v2;
+        if (!(nn > 0.0)) break;
+        const double rn = det_rsqrt(nn);
+        v0 = v0 * rn; v1 = v1 * rn; v2 = v2 * rn;
+        const double cv0 = c[0] * v0 + c[1] * v1 + c[2] * v2, cv1 = c[1] * v0 + c[3] * v1 + c[4] * v2, cv2 = c[2] * v0 + c[4] * v1 + c[5] * v2;
+        double l3 = v0 * cv0 + v1 * cv1 + v2 * cv2;
+        const double av0 = a[0] * v0 + a[1] * v1 + a[2] * v2, av1 = a[1] * v0 + a[3] * v1 + a[4] * v2, av2 = a[2] * v0 + a[4] * v1 + a[5] * v2;
+        const double pr = v0 * av0 + v1 * av1 + v2 * av2;
+        const double sm = (c[0] + c[3] + c[5]) - l3;
+        if (l3 < 0.0) l3 = 0.0;
+        const double mth = l3 / (double)plane_ratio;
+        if (!((mth <= 0.5 * sm) && ((mth * mth - sm * mth) + pr >= 0.0))) break;
+        const double spread_abs = (double)min_spread * (double)g.leaf;
+        const double mw = (spread_abs * spread_abs) / cm;
+        if (!((mw <= 0.5 * sm) && ((mw * mw - sm * mw) + pr >= 0.0))) break;
+        int im = 0;
+        double vm = fabs(v0);
+        if (fabs(v1) > vm) { im = 1; vm = fabs(v1); }
+        if (fabs(v2) > vm) { im = 2; }
+        const double lead = im == 0 ? v0 : (im == 1 ? v1 : v2);
+        if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
+        out = make_float4((float)v0, (float)v1, (float)v2, 0.f);
+    } while (0);
+    nrm_in[oi] = out;
+}
+
+// ---- export helpers (introspection API) -----------------------------------------------------------
+__global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __restrict__ nrm, int n, float* __restrict__ xyz,
+                                float* __restrict__ nxyz) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float4 p = pts[j];
+    xyz[3 * j] = p.x; xyz[3 * j + 1] = p.y; xyz[3 * j + 2] = p.z;
+    if (nrm && nxyz) { const float4 q = nrm[j]; nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z; }
+}
+
+// ---- host-side launchers ----------------------------------------------------------------------------
+#define HIP_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return _e; } while (0)
+
+hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int step, int ox, int oy, int oz, float* x, float* y,
+                                  float* z, uint32_t* aabb) {
+    HIP_TRY(hipMemsetAsync(aabb, 0xFF, 3 * sizeof(uint32_t), s));      // ordered min = +max
+    HIP_TRY(hipMemsetAsync(aabb + 3, 0, 5 * sizeof(uint32_t), s));     // ordered max = 0, count = 0
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_decode_aabb, dim3(blocks), dim3(256), 0, s, raw, n, step, ox, oy, oz, x, y, z, aabb);
+    return hipGetLastError();
+}
+
+hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a) {
+    const int n = a.n;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks), dim3(256), 0, s, a.x, a.y, a.z, n, a.grid, a.keys, a.ka, a.va);
+    HIP_TRY(hipGetLastError());
+    const int ntiles = (n + RS_TILE - 1) / RS_TILE;
+    uint32_t *kin = a.ka, *vin = a.va, *kout = a.kb, *vout = a.vb;
+    for (int pass = 0; pass < a.sort_passes; pass++) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, a.hist, ntiles);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, a.hist, 256 * ntiles);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, a.hist, ntiles);
+        HIP_TRY(hipGetLastError());
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    // keep the sorted keys / permutation for the introspection API
+    HIP_TRY(hipMemcpyAsync(a.skey_out, kin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(a.perm_out, vin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(a.htab, 0xFF, sizeof(uint2) * ((size_t)a.grid.hmask + 1), s));
+    HIP_TRY(hipMemsetAsync(a.n_cells, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_finalize_level, dim3(blocks), dim3(256), 0, s, kin, vin, n, a.x, a.y, a.z, a.nrm_in, a.pts, a.nrm, a.htab,
+                       a.grid.hmask, a.grid.hshift, a.n_cells);
+    return hipGetLastError();
+}
+
+int m3d_sort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }
+
+hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, float plane_ratio, int min_pts, float min_spread, float4* nrm_in,
+                              int n) {
+    HIP_TRY(hipMemsetAsync(nrm_in, 0, sizeof(float4) * (size_t)n, s));
+    const int nv = L.g.n_valid;
+    hipLaunchKernelGGL(k_normals, dim3((nv + 255) / 256), dim3(256), 0, s, L, plane_ratio, min_pts, min_spread, nrm_in);
+    return hipGetLastError();
+}
+
+hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz) {
+    hipLaunchKernelGGL(k_export_sorted, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, n, xyz, nxyz);
+    return hipGetLastError();
+}

@@ -462,7 +462,7 @@ static void accumulate(const float* src_xyz, int32_t n_src, const orc_level* L, 
 /* a8: 6x6 LDL^T solve and SE(3) update about the centre c (all double, fixed operation order)  */
 /* ------------------------------------------------------------------------------------------- */
 static int solve_update(const int64_t sums[ORC_NSUMS], const int32_t exps[6], const float center[3], double pivot_rel_tol,
-                        double T[16], double* rot_out, double* trans_out) {
+                        double T[16], double* th2_out, double* tr2_out) {
     double A[6][6], b[6];
     for (int k = 0; k < 6; k++) for (int l = k; l < 6; l++) {
         int cls = (l < 3) ? 0 : (k < 3 ? 1 : 2);
@@ -492,7 +492,7 @@ static int solve_update(const int64_t sums[ORC_NSUMS], const int32_t exps[6], co
     const double w0 = x[0], w1 = x[1], w2 = x[2], v0 = x[3], v1 = x[4], v2 = x[5];
     const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
     const double tr2 = v0 * v0 + v1 * v1 + v2 * v2;
-    *rot_out = sqrt(th2); *trans_out = sqrt(tr2);
+    *th2_out = th2; *tr2_out = tr2;
     if (!(th2 <= 4.0) || !(tr2 < 1e300)) return ORC_DIVERGED;
     /* nested series in th2: A = sin(th)/th, B = (1-cos th)/th^2, C = (th - sin th)/th^3 */
     double sa = 1.0, sb = 1.0, sc = 1.0;
@@ -630,19 +630,21 @@ int orc_align_clouds(const orc_params* p, const orc_cloud* src, const orc_cloud*
         const orc_level* L = &tgt->lv[l];
         for (int it = 0; it < p->iterations[l]; it++) {
             int64_t sums[ORC_NSUMS]; int32_t exps[6];
+            double th2 = 0.0, tr2 = 0.0;
             accumulate(src->xyz, src->n, L, T, p->metric, p->max_corr_dist[l], sums, exps, NULL, NULL);
             s.iterations++;
             s.n_corr = sums[28];
             s.rms = sums[28] > 0 ? sqrt(ldexp((double)sums[27], -exps[5]) / (double)sums[28]) : 0.0;
             if (sums[28] < (int64_t)p->min_correspondences) { s.status = ORC_TOO_FEW_CORR; stop = 1; }
             else {
-                int rc = solve_update(sums, exps, L->g.center, p->pivot_rel_tol, T, &s.last_rot, &s.last_trans);
+                int rc = solve_update(sums, exps, L->g.center, p->pivot_rel_tol, T, &th2, &tr2);
+                s.last_rot = sqrt(th2); s.last_trans = sqrt(tr2);
                 if (rc >= 0) { s.status = rc; stop = 1; }
             }
             if (trace && tn < trace_cap) memcpy(&trace[16 * tn], T, sizeof(double) * 16);
             tn++;
             if (stop) break;
-            if (s.last_rot * s.last_rot < p->eps_rot * p->eps_rot && s.last_trans * s.last_trans < p->eps_trans * p->eps_trans) {
+            if (th2 < p->eps_rot * p->eps_rot && tr2 < p->eps_trans * p->eps_trans) {
                 if (l == p->n_levels - 1) { s.status = ORC_CONVERGED; stop = 1; }
                 break; /* level converged: move to the next finer level */
             }

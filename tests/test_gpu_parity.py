@@ -1,0 +1,188 @@
+"""HIP path vs CPU oracle on the same seeded inputs — BIT-EXACT at every stage (no tolerance):
+voxel keys, stable permutation, cell-sorted points, normals, NN indices and distances, the 29
+fixed-point sums, every per-iteration pose and the final pose/stats. Everything goes through the
+C ABI (ctypes). Run on the GPU box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from mandala_mapping_amd import abi, synth
+from mandala_mapping_amd import pointcloud2 as pc2
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(**kw):
+    return abi.Params.make(**kw)
+
+
+def _same_stats(a, b):
+    assert (a.status, a.iterations, a.n_corr) == (b.status, b.iterations, b.n_corr)
+    assert a.rms == b.rms and a.last_rot == b.last_rot and a.last_trans == b.last_trans
+
+
+def _check_bucketing(reg_cloud, orc_cloud, levels):
+    for l in range(levels):
+        g, go = reg_cloud.grid_info(l), orc_cloud.grid_info(l)
+        assert bytes(g) == bytes(go), (g.as_dict(), go.as_dict())
+        e, eo = reg_cloud.export(l), orc_cloud.export(l)
+        nv = g.n_valid
+        assert np.array_equal(e["keys"], eo["keys"])
+        assert np.array_equal(e["sorted_keys"], eo["sorted_keys"])
+        assert np.array_equal(e["perm"], eo["perm"])
+        assert np.array_equal(e["sorted_xyz"][:nv].view(np.uint32), eo["sorted_xyz"][:nv].view(np.uint32))
+        if g.has_normals:
+            assert np.array_equal(e["normals"][:nv].view(np.uint32), eo["normals"][:nv].view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
+def test_config1_every_stage_bit_exact(reg, orc, metric):
+    src, tgt, Tgt = synth.config1()
+    p = _params(leaf=0.25, iterations=12, max_corr_dist=0.5, metric=metric, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    cs, ct = R.cloud(src), R.cloud(tgt)
+    os_, ot = orc.Cloud(p, src), orc.Cloud(p, tgt)
+    _check_bucketing(ct, ot, 1)
+    _check_bucketing(cs, os_, 1)
+    # NN of the transformed source
+    q = synth.apply_T(Tgt, src).astype(np.float32)
+    i1, d1 = ct.nn(q, 0.5)
+    i2, d2 = ot.nn(q, 0.5)
+    assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    # one linearisation at identity and at the ground truth
+    for T in (np.eye(4), Tgt):
+        s1, e1 = R.accumulate(cs, ct, T)
+        s2, e2 = orc.accumulate(p, os_, ot, T)
+        assert np.array_equal(e1, e2)
+        assert np.array_equal(s1, s2), (s1 - s2)
+    # full run
+    T1, st1 = R.align(cs, ct)
+    tr1 = R.trace()
+    T2, st2, tr2 = orc.align(p, os_, ot, trace_cap=64)
+    assert np.array_equal(tr1, tr2)
+    assert np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+    rot, tra = synth.pose_error(T1, Tgt)
+    if metric == abi.POINT_TO_PLANE:
+        assert rot < 0.05 and tra < 0.005
+
+
+def test_nonfinite_points_and_odd_layout(reg, orc):
+    src, tgt, _ = synth.config1(5000)
+    tgt = tgt.copy()
+    tgt[::97] = np.nan
+    tgt[5] = [np.inf, 0, 0]
+    src = src.copy()
+    src[::131, 1] = np.nan
+    p = _params(leaf=0.25, iterations=6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    mt = pc2.encode_xyz(tgt, point_step=32, offsets=(4, 12, 20))
+    ms = pc2.encode_xyz(src, point_step=20, offsets=(8, 0, 4))
+    ct, cs = R.cloud(mt), R.cloud(ms)
+    ot = orc.Cloud(p, mt.data, mt.n, 32, (4, 12, 20))
+    os_ = orc.Cloud(p, ms.data, ms.n, 20, (8, 0, 4))
+    _check_bucketing(ct, ot, 1)
+    T1, st1 = R.align(cs, ct)
+    T2, st2, _ = orc.align(p, os_, ot)
+    assert np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+
+
+def test_unaligned_payload_is_repacked(reg, orc):
+    xyz = synth.planes_cloud(2000, 9)
+    m = pc2.encode_xyz(xyz, point_step=13, offsets=(1, 5, 9))
+    p = _params(leaf=0.25, metric=abi.POINT_TO_POINT)
+    R = reg.Registrar(p)
+    c = R.cloud(m)
+    o = orc.Cloud(p, m.data, m.n, 13, (1, 5, 9))
+    _check_bucketing(c, o, 1)
+
+
+def test_multiresolution_hdl32_bit_exact(reg, orc):
+    src, tgt, Tgt = synth.hdl32_pair(700, 100, 101)   # 22 400 rays: the oracle finishes in about a second
+    p = _params(leaf=(0.4, 0.2), iterations=(8, 8), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    cs, ct = R.cloud(src), R.cloud(tgt)
+    os_, ot = orc.Cloud(p, src), orc.Cloud(p, tgt)
+    _check_bucketing(ct, ot, 2)
+    T1, st1 = R.align(cs, ct)
+    tr1 = R.trace()
+    T2, st2, tr2 = orc.align(p, os_, ot, trace_cap=64)
+    assert np.array_equal(tr1, tr2) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+    rot, tra = synth.pose_error(T1, Tgt)
+    assert rot < 0.1 and tra < 0.03, (rot, tra)
+
+
+def test_batch_equals_single_and_oracle(reg, orc):
+    p = _params(leaf=0.25, iterations=8, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    pairs, ref = [], []
+    for k in range(5):
+        tgt = synth.planes_cloud(3000 + 500 * k, 50 + k)
+        Tg = synth.random_T(np.random.default_rng(k), 2.0, 0.1)
+        src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(2500 + 300 * k, 80 + k)).astype(np.float32)
+        pairs.append((R.cloud(src), R.cloud(tgt), None))
+        ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+    Tb, stb = R.align_batch(pairs)
+    for k in range(5):
+        assert np.array_equal(Tb[k], ref[k][0])
+        _same_stats(stb[k], ref[k][1])
+        T1, st1 = R.align(pairs[k][0], pairs[k][1])
+        assert np.array_equal(T1, Tb[k])
+
+
+def test_status_codes(reg, orc):
+    p = _params(leaf=0.5, iterations=5, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    rng = np.random.default_rng(3)
+    plane = np.c_[rng.uniform(0, 10, size=(4000, 2)), np.zeros(4000)].astype(np.float32)
+    T, st = R.align(R.cloud(plane + np.float32([0, 0, 0.02])), R.cloud(plane))
+    assert st.status == abi.RANK_DEFICIENT and np.array_equal(T, np.eye(4))
+    far = R.cloud(plane + np.float32(60.0))
+    T, st = R.align(far, R.cloud(plane))
+    assert st.status == abi.TOO_FEW_CORR and st.iterations == 1 and st.n_corr == 0
+    with pytest.raises(abi.M3dregError) as ei:
+        R.cloud(np.full((8, 3), np.nan, np.float32))
+    assert ei.value.code == abi.ERR_EMPTY_CLOUD
+    Rf = reg.Registrar(_params(leaf=0.001, metric=abi.POINT_TO_POINT))
+    with pytest.raises(abi.M3dregError) as ei:
+        Rf.cloud(np.array([[0, 0, 0], [5000, 5000, 5000]], np.float32))
+    assert ei.value.code == abi.ERR_GRID_TOO_LARGE
+
+
+def test_node_surface_pointcloud2_in_pose_out(reg, orc):
+    """m3dreg_set_target_xyz / m3dreg_align with the aggregator's exact message layout."""
+    src, tgt, Tgt = synth.config1(6000)
+    p = _params(leaf=0.25, iterations=15, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    node = reg.Gpu6dSlamNode(p)
+    pose0, st0 = node.on_cloud(pc2.encode_xyz(tgt))
+    assert st0 is None and np.array_equal(pose0, np.eye(4))
+    pose1, st1 = node.on_cloud(pc2.encode_xyz(src))
+    T2, st2, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    assert np.array_equal(pose1, T2)
+    _same_stats(st1, st2)
+
+
+def test_full_size_properties_config3(reg):
+    """BASELINE config 3 at full size (100k points): properties that need no oracle run."""
+    src, tgt, Tgt = synth.config3()
+    p = _params(leaf=0.1, iterations=30, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    cs, ct = R.cloud(src), R.cloud(tgt)
+    e = ct.export()
+    assert (np.diff(e["sorted_keys"].astype(np.int64)) >= 0).all()           # sortedness
+    assert np.array_equal(np.sort(e["perm"]), np.arange(len(tgt)))           # a permutation
+    assert np.array_equal(e["sorted_xyz"], tgt[e["perm"]])                   # gather is exact
+    T, st = R.align(cs, ct)
+    rot, tra = synth.pose_error(T, Tgt)
+    assert st.status == abi.CONVERGED and rot < 0.02 and tra < 0.005, (rot, tra, st.as_dict())
+    # idempotence: restarting from the answer stays there
+    T2, st2 = R.align(cs, ct, T)
+    assert synth.pose_error(T2, T)[0] < 1e-3 and synth.pose_error(T2, T)[1] < 1e-4
+    # source order does not change a single bit of the result
+    perm = np.random.default_rng(1).permutation(len(src))
+    T3, st3 = R.align(R.cloud(src[perm]), ct)
+    assert np.array_equal(T3, T) and st3.n_corr == st.n_corr
+    # run-to-run determinism
+    T4, _ = R.align(cs, ct)
+    assert np.array_equal(T4, T)
