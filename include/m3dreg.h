@@ -143,6 +143,15 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats);
 int m3dreg_synchronize(m3dreg_handle* h);
 void* m3dreg_get_stream(m3dreg_handle* h);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled, every launch of the dominant kernel (the fused NN + residual + reduction kernel,
+ * `k_icp_accumulate`) is bracketed by two hipEvents recorded on the handle's stream, so bench.py can
+ * report that kernel's average launch duration from inside its timed region. */
+int m3dreg_profile_enable(m3dreg_handle* h, int on);
+/* Synchronises the stream, returns the number of bracketed launches and the sum of their durations
+ * since the last reset; `reset` != 0 clears the counters. */
+int m3dreg_profile_read(m3dreg_handle* h, uint64_t* n_launches, double* total_ms, int reset);
+
 /* ---- introspection used by the parity tests (stage-by-stage comparison with oracle/) -------- */
 typedef struct m3dreg_grid_info {
     int32_t n;          /* points in the input cloud */

@@ -26,7 +26,7 @@ EXPORTS = [
     "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
-    "m3dreg_debug_accumulate", "m3dreg_debug_trace",
+    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
     L.m3dreg_debug_nn.argtypes = [vp, vp, C.c_int, f32p, sz, C.c_float, i32p, f32p]
     L.m3dreg_debug_accumulate.argtypes = [vp, vp, vp, C.c_int, f32p, i64p, i32p]
     L.m3dreg_debug_trace.argtypes = [vp, f64p, sz, C.POINTER(sz)]
+    L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
+    L.m3dreg_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), f64p, C.c_int]
     if L.m3dreg_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libm3dreg.so ABI version mismatch")
     _lib = L
@@ -167,6 +169,15 @@ class Registrar:
 
     def synchronize(self):
         self._check(lib().m3dreg_synchronize(self._h), "synchronize")
+
+    def profile_enable(self, on=True):
+        self._check(lib().m3dreg_profile_enable(self._h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self, reset=True):
+        """(launches, total ms) of the dominant kernel since the last reset, from hipEvents on the stream."""
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        self._check(lib().m3dreg_profile_read(self._h, C.byref(n), C.byref(ms), 1 if reset else 0), "profile_read")
+        return n.value, ms.value
 
     # ---- clouds -------------------------------------------------------------------------------
     def cloud(self, data, n=None, point_step=16, offsets=(0, 4, 8)):

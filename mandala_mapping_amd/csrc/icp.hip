@@ -328,10 +328,13 @@ hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n
     return hipGetLastError();
 }
 
-hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level) {
+hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
+                                    hipEvent_t e0, hipEvent_t e1) {
     dim3 grid(icp_blocks(max_n_src), n_pairs);
+    if (e0) (void)hipEventRecord(e0, s);
     if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
     else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
+    if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_solve_update, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, first_of_level);
     return hipGetLastError();
 }

@@ -30,7 +30,9 @@ hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, float plane_r
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // icp.hip
-hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level);
+// e0/e1 (optional): events recorded immediately before / after the k_icp_accumulate launch
+hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
+                                    hipEvent_t e0, hipEvent_t e1);
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

@@ -66,6 +66,12 @@ struct m3dreg_handle {
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
+    // measurement: event pairs around the dominant kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    uint64_t prof_launches = 0;
+    double prof_ms = 0.0;
 };
 
 namespace {
@@ -289,6 +295,24 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
     return M3DREG_OK;
 }
 
+hipEvent_t next_event(m3dreg_handle* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+
+// fold the recorded event pairs into the running totals (requires the stream to be idle)
+void drain_events(m3dreg_handle* h) {
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { h->prof_ms += double(ms); h->prof_launches++; }
+    }
+    h->ev_used = 0;
+}
+
 void stats_from_state(const M3dPairState& S, m3dreg_stats* st) {
     st->status = S.status;
     st->iterations = S.iters;
@@ -348,6 +372,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
                      (void*)h->d_trace })
         if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return M3DREG_OK;
@@ -457,8 +482,11 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));
     for (int l = 0; l < P.n_levels; l++) {
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
-        for (int it = 0; it < P.iterations[l]; it++)
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0));
+        for (int it = 0; it < P.iterations[l]; it++) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->profiling) { e0 = next_event(h); e1 = next_event(h); }
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, e0, e1));
+        }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_trace, h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE, hipMemcpyDeviceToHost, h->stream));
@@ -469,6 +497,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
 int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     if (!h || h->pending_pairs == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "batch_wait: nothing pending");
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->ev_used) drain_events(h);
     for (size_t i = 0; i < h->pending_pairs; i++) {
         const M3dPairState& S = h->h_states[i];
         if (out_T) for (int k = 0; k < 16; k++) out_T[16 * i + k] = float(S.T[k]);
@@ -515,6 +544,23 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
     rc = m3dreg_align_clouds(h, s, h->target, init_T, out_T, stats);
     m3dreg_cloud_destroy(h, s);
     return rc;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------
+int m3dreg_profile_enable(m3dreg_handle* h, int on) {
+    if (!h) return M3DREG_ERR_INVALID_ARG;
+    h->profiling = on != 0;
+    return M3DREG_OK;
+}
+
+int m3dreg_profile_read(m3dreg_handle* h, uint64_t* n_launches, double* total_ms, int reset) {
+    if (!h) return M3DREG_ERR_INVALID_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drain_events(h);
+    if (n_launches) *n_launches = h->prof_launches;
+    if (total_ms) *total_ms = h->prof_ms;
+    if (reset) { h->prof_launches = 0; h->prof_ms = 0.0; }
+    return M3DREG_OK;
 }
 
 // ---- introspection ------------------------------------------------------------------------------------

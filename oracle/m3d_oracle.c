@@ -299,6 +299,10 @@ static void grid_normals(const orc_level* L, float plane_ratio, int32_t min_pts,
     const double l2_min_abs = spread_abs * spread_abs;
     const int sy = g->bits[0], sz = g->bits[0] + g->bits[1];
     const uint32_t mx = (1u << g->bits[0]) - 1u, my = (1u << g->bits[1]) - 1u;
+    /* every iteration writes only out[3*perm[j]..]: independent, so the OpenMP split changes nothing */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
     for (int32_t j = 0; j < nv; j++) {
         const float px = L->sxyz[3 * j], py = L->sxyz[3 * j + 1], pz = L->sxyz[3 * j + 2];
         uint32_t key = L->skey[j];
