@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const uint8_t* __restrict__
             cnt++;
         }
     }
-    // wave64 shuffle reduction, then one set of integer atomics per wave (exact, order-independent)
+    // wave64 shuffle reduction -> LDS across the 4 waves -> one set of integer atomics per block
+    // (exact and order-independent; per-wave atomics made this kernel contention-bound: 128 us -> see profiles/)
     for (int o = 32; o > 0; o >>= 1) {
         for (int a = 0; a < 3; a++) {
             mn[a] = min(mn[a], (uint32_t)__shfl_down((int)mn[a], o));
@@ -52,9 +53,15 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const uint8_t* __restrict__
         }
         cnt += __shfl_down((int)cnt, o);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        for (int a = 0; a < 3; a++) { atomicMin(&aabb[a], mn[a]); atomicMax(&aabb[3 + a], mx[a]); }
-        atomicAdd(&aabb[6], cnt);
+    __shared__ uint32_t red[4][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { for (int a = 0; a < 3; a++) { red[wave][a] = mn[a]; red[wave][3 + a] = mx[a]; } red[wave][6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        uint32_t v = red[0][a];
+        for (int w = 1; w < 4; w++) v = (a < 3) ? min(v, red[w][a]) : (a < 6 ? max(v, red[w][a]) : v + red[w][a]);
+        if (a < 3) atomicMin(&aabb[a], v); else if (a < 6) atomicMax(&aabb[a], v); else if (v) atomicAdd(&aabb[6], v);
     }
 }
 
@@ -210,41 +217,92 @@ __device__ __forceinline__ double det_rsqrt(double x) {   // spec: bit-trick see
     return y;
 }
 
-__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, float plane_ratio, int min_pts, float min_spread,
-                                                 float4* __restrict__ nrm_in) {
+// Spec §Normals (v2): positions quantised to 1/65536 voxel inside their voxel, exact int64 moments.
+// Pass 1: per-voxel moments {n, S[3], P[6]} by a segmented wave64 scan over the cell-sorted points
+// (a run of equal keys is a voxel), one set of 64-bit integer atomics per run and wave, stored at the
+// voxel's first sorted position.
+#define M3D_NQ 65536
+__device__ __forceinline__ int m3d_quant_frac(float v, float mn, float inv_leaf) {
+    const float sv = (v - mn) * inv_leaf;
+    const float fr = sv - floorf(sv);
+    return (int)rintf(fr * 65536.0f);
+}
+
+__global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint32_t* __restrict__ skey, long long* __restrict__ mom) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const M3dGrid& g = L.g;
+    const int lane = threadIdx.x & 63;
+    const bool ok = j < g.n_valid;
+    uint32_t key = M3D_INVALID_KEY;
+    long long v[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) v[i] = 0;
+    if (ok) {
+        key = skey[j];
+        const float4 p = L.pts[j];
+        const long long qx = m3d_quant_frac(p.x, g.mn[0], g.inv_leaf), qy = m3d_quant_frac(p.y, g.mn[1], g.inv_leaf),
+                        qz = m3d_quant_frac(p.z, g.mn[2], g.inv_leaf);
+        v[0] = 1; v[1] = qx; v[2] = qy; v[3] = qz;
+        v[4] = qx * qx; v[5] = qx * qy; v[6] = qx * qz; v[7] = qy * qy; v[8] = qy * qz; v[9] = qz * qz;
+    }
+    const uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = (lane == 0) || (kprev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int seg_start = 63 - __clzll((long long)(heads & le));
+    const bool tail = (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const bool take = (lane - o) >= seg_start;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const long long t = __shfl_up(v[i], o);
+            if (take) v[i] += t;
+        }
+    }
+    if (ok && tail) {
+        const int hp = m3d_find_cell(L.htab, g.hmask, g.hshift, key);   // first sorted position of this voxel
+#pragma unroll
+        for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
+    }
+}
+
+// Pass 2: per point, add the (shifted) moments of the 27 voxels around it and take the smallest
+// eigenvector of the covariance.
+__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, const uint32_t* __restrict__ skey, const long long* __restrict__ mom,
+                                                 float plane_ratio, int min_pts, float min_spread, float4* __restrict__ nrm_in) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L.g.n_valid) return;
     const M3dGrid& g = L.g;
-    const float4 pj = L.pts[j];
-    const uint32_t oi = __float_as_uint(pj.w) & ~M3D_LAST_FLAG;
+    const uint32_t oi = __float_as_uint(L.pts[j].w) & ~M3D_LAST_FLAG;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf);
-    const int icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf);
-    const int icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
-    double s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    int k = 0;
+    const uint32_t key = skey[j];
+    const int icx = (int)(key & ((1u << g.sy) - 1u)), icy = (int)((key >> g.sy) & ((1u << (g.sz - g.sy)) - 1u)), icz = (int)(key >> g.sz);
+    long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     for (int dz = -1; dz <= 1; dz++) { const int cz = icz + dz; if (cz < 0 || cz >= g.dims[2]) continue;
     for (int dy = -1; dy <= 1; dy++) { const int cy = icy + dy; if (cy < 0 || cy >= g.dims[1]) continue;
     for (int dx = -1; dx <= 1; dx++) { const int cx = icx + dx; if (cx < 0 || cx >= g.dims[0]) continue;
         const uint32_t ck = (uint32_t)cx | ((uint32_t)cy << g.sy) | ((uint32_t)cz << g.sz);
-        int t = m3d_find_cell(L.htab, g.hmask, g.hshift, ck);
-        if (t < 0) continue;
-        for (;;) {
-            const float4 q = L.pts[t];
-            const double ex = (double)(q.x - pj.x), ey = (double)(q.y - pj.y), ez = (double)(q.z - pj.z);
-            s0 += ex; s1 += ey; s2 += ez;
-            q0 += ex * ex; q1 += ex * ey; q2 += ex * ez; q3 += ey * ey; q4 += ey * ez; q5 += ez * ez;
-            k++;
-            if (__float_as_uint(q.w) & M3D_LAST_FLAG) break;
-            t++;
-        }
+        const int hp = m3d_find_cell(L.htab, g.hmask, g.hshift, ck);
+        if (hp < 0) continue;
+        const long long* m = &mom[10 * (size_t)hp];
+        const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
+        const long long Dx = (long long)dx * M3D_NQ, Dy = (long long)dy * M3D_NQ, Dz = (long long)dz * M3D_NQ;
+        k += n;
+        s0 += Sx + n * Dx; s1 += Sy + n * Dy; s2 += Sz + n * Dz;
+        q0 += m[4] + 2 * Dx * Sx + n * Dx * Dx;
+        q1 += m[5] + Dx * Sy + Dy * Sx + n * Dx * Dy;
+        q2 += m[6] + Dx * Sz + Dz * Sx + n * Dx * Dz;
+        q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
+        q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
+        q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
     }}}
     do {
-        if (k < min_pts || k < 3) break;
+        if (k < (long long)min_pts || k < 3) break;
         const double inv = 1.0 / (double)k;
-        const double m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
-        double c[6] = { q0 * inv - m0 * m0, q1 * inv - m0 * m1, q2 * inv - m0 * m2,
-                        q3 * inv - m1 * m1, q4 * inv - m1 * m2, q5 * inv - m2 * m2 };
+        const double m0 = (double)s0 * inv, m1 = (double)s1 * inv, m2 = (double)s2 * inv;
+        double c[6] = { (double)q0 * inv - m0 * m0, (double)q1 * inv - m0 * m1, (double)q2 * inv - m0 * m2,
+                        (double)q3 * inv - m1 * m1, (double)q4 * inv - m1 * m2, (double)q5 * inv - m2 * m2 };
         const double cm = sym3_maxabs(c);
         if (!(cm > 0.0)) break;
 #pragma unroll
@@ -278,8 +336,8 @@ __global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, float plane_rati
         if (l3 < 0.0) l3 = 0.0;
         const double mth = l3 / (double)plane_ratio;
         if (!((mth <= 0.5 * sm) && ((mth * mth - sm * mth) + pr >= 0.0))) break;
-        const double spread_abs = (double)min_spread * (double)g.leaf;
-        const double mw = (spread_abs * spread_abs) / cm;
+        const double spread_q = (double)min_spread * 65536.0;
+        const double mw = (spread_q * spread_q) / cm;
         if (!((mw <= 0.5 * sm) && ((mw * mw - sm * mw) + pr >= 0.0))) break;
         int im = 0;
         double vm = fabs(v0);
@@ -309,8 +367,9 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int 
                                   float* z, uint32_t* aabb) {
     HIP_TRY(hipMemsetAsync(aabb, 0xFF, 3 * sizeof(uint32_t), s));      // ordered min = +max
     HIP_TRY(hipMemsetAsync(aabb + 3, 0, 5 * sizeof(uint32_t), s));     // ordered max = 0, count = 0
-    int blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (n + 1023) / 1024;   // ~4 points per thread, one atomic set per block
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_decode_aabb, dim3(blocks), dim3(256), 0, s, raw, n, step, ox, oy, oz, x, y, z, aabb);
     return hipGetLastError();
 }
@@ -343,11 +402,14 @@ hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a) {
 
 int m3d_sort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, float plane_ratio, int min_pts, float min_spread, float4* nrm_in,
-                              int n) {
+hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
+                              float min_spread, float4* nrm_in, int n) {
     HIP_TRY(hipMemsetAsync(nrm_in, 0, sizeof(float4) * (size_t)n, s));
     const int nv = L.g.n_valid;
-    hipLaunchKernelGGL(k_normals, dim3((nv + 255) / 256), dim3(256), 0, s, L, plane_ratio, min_pts, min_spread, nrm_in);
+    HIP_TRY(hipMemsetAsync(mom, 0, sizeof(long long) * 10 * (size_t)nv, s));
+    const int blocks = (nv + 255) / 256;
+    hipLaunchKernelGGL(k_cell_moments, dim3(blocks), dim3(256), 0, s, L, skey, mom);
+    hipLaunchKernelGGL(k_normals, dim3(blocks), dim3(256), 0, s, L, skey, (const long long*)mom, plane_ratio, min_pts, min_spread, nrm_in);
     return hipGetLastError();
 }
 

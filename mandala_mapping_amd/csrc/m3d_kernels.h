@@ -25,8 +25,9 @@ int m3d_sort_tiles(int n);
 hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int step, int ox, int oy, int oz, float* x, float* y,
                                   float* z, uint32_t* aabb);
 hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a);
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, float plane_ratio, int min_pts, float min_spread, float4* nrm_in,
-                              int n);
+// mom: workspace of 10 * n_valid int64 (per-voxel moments, indexed by the voxel's first sorted position)
+hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
+                              float min_spread, float4* nrm_in, int n);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // icp.hip

@@ -54,6 +54,7 @@ struct m3dreg_handle {
     // sort workspace (grown on demand)
     size_t ws_n = 0;
     uint32_t *ka = nullptr, *va = nullptr, *kb = nullptr, *vb = nullptr, *hist = nullptr, *aabb = nullptr;
+    long long* mom = nullptr;          // [10 * ws_n] per-voxel moments of the normal grid
     // batch state
     size_t cap_pairs = 0;
     M3dJob* d_jobs = nullptr;          // [levels][cap_pairs]
@@ -172,13 +173,14 @@ int ensure_workspace(m3dreg_handle* h, size_t n) {
     if (!h->aabb) { int rc = dmalloc(h, nullptr, &h->aabb, 8); if (rc) return rc; }
     if (n <= h->ws_n) return M3DREG_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist }) if (p) hipFree(p);
-    h->ka = h->va = h->kb = h->vb = h->hist = nullptr;
+    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->mom }) if (p) hipFree(p);
+    h->ka = h->va = h->kb = h->vb = h->hist = nullptr; h->mom = nullptr;
     h->ws_n = 0;
     size_t cap = n + n / 4 + 1024;
     int rc;
     if ((rc = dmalloc(h, nullptr, &h->ka, cap)) || (rc = dmalloc(h, nullptr, &h->va, cap)) || (rc = dmalloc(h, nullptr, &h->kb, cap)) ||
-        (rc = dmalloc(h, nullptr, &h->vb, cap)) || (rc = dmalloc(h, nullptr, &h->hist, 256 * size_t(m3d_sort_tiles(int(cap)) + 1))))
+        (rc = dmalloc(h, nullptr, &h->vb, cap)) || (rc = dmalloc(h, nullptr, &h->hist, 256 * size_t(m3d_sort_tiles(int(cap)) + 1))) ||
+        (rc = dmalloc(h, nullptr, &h->mom, 10 * cap)))
         return rc;
     h->ws_n = cap;
     return M3DREG_OK;
@@ -368,7 +370,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     free_cloud(h->target);
-    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->aabb, (void*)h->d_jobs, (void*)h->d_states,
+    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->mom, (void*)h->aabb, (void*)h->d_jobs, (void*)h->d_states,
                      (void*)h->d_trace })
         if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
@@ -451,7 +453,7 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
         DevLevel NG;
         CLOUD_TRY(bucket_level(h, c, NG, P.normal_leaf, false, nullptr));
         CLOUD_TRY(dmalloc(h, c, &nrm_in, n));
-        CLOUD_HIP(m3d_launch_normals(h->stream, level_dev(NG), P.plane_ratio, P.normal_min_pts, P.normal_min_spread, nrm_in, int(n)));
+        CLOUD_HIP(m3d_launch_normals(h->stream, level_dev(NG), NG.skey, h->mom, P.plane_ratio, P.normal_min_pts, P.normal_min_spread, nrm_in, int(n)));
         c->has_normals = true;
     }
     for (int l = 0; l < P.n_levels; l++) CLOUD_TRY(bucket_level(h, c, c->lv[l], P.leaf[l], c->has_normals, nrm_in));

@@ -295,8 +295,13 @@ static double det_rsqrt(double x) {
 static void grid_normals(const orc_level* L, float plane_ratio, int32_t min_pts, float min_spread, float* out) {
     const orc_grid_info* g = &L->g;
     const int32_t nv = g->n_valid;
-    const double spread_abs = (double)min_spread * (double)g->leaf;
-    const double l2_min_abs = spread_abs * spread_abs;
+    /* Spec §Normals: positions are quantised to 1/65536 of a voxel INSIDE their voxel
+     * (q = rint(frac * 65536), frac = s - floor(s) is exact in float), neighbour voxels are shifted by
+     * whole multiples of 65536, and all first/second moments are accumulated as exact int64 — so any
+     * evaluation order (this naive per-neighbour loop, or the GPU's per-voxel moments shifted and added)
+     * gives the same integers. Units of the covariance below: (leaf/65536)^2. */
+    const double spread_q = (double)min_spread * 65536.0;
+    const double l2_min_abs = spread_q * spread_q;
     const int sy = g->bits[0], sz = g->bits[0] + g->bits[1];
     const uint32_t mx = (1u << g->bits[0]) - 1u, my = (1u << g->bits[1]) - 1u;
     /* every iteration writes only out[3*perm[j]..]: independent, so the OpenMP split changes nothing */
@@ -304,30 +309,34 @@ static void grid_normals(const orc_level* L, float plane_ratio, int32_t min_pts,
 #pragma omp parallel for schedule(dynamic, 256)
 #endif
     for (int32_t j = 0; j < nv; j++) {
-        const float px = L->sxyz[3 * j], py = L->sxyz[3 * j + 1], pz = L->sxyz[3 * j + 2];
         uint32_t key = L->skey[j];
         int32_t ic[3] = { (int32_t)(key & mx), (int32_t)((key >> sy) & my), (int32_t)(key >> sz) };
-        double s[3] = { 0, 0, 0 }, q[6] = { 0, 0, 0, 0, 0, 0 };
-        int32_t k = 0;
+        int64_t s[3] = { 0, 0, 0 }, q[6] = { 0, 0, 0, 0, 0, 0 };
+        int64_t k = 0;
         for (int dz = -1; dz <= 1; dz++) { int32_t cz = ic[2] + dz; if (cz < 0 || cz >= g->dims[2]) continue;
         for (int dy = -1; dy <= 1; dy++) { int32_t cy = ic[1] + dy; if (cy < 0 || cy >= g->dims[1]) continue;
         for (int dx = -1; dx <= 1; dx++) { int32_t cx = ic[0] + dx; if (cx < 0 || cx >= g->dims[0]) continue;
             uint32_t ck = (uint32_t)cx | ((uint32_t)cy << sy) | ((uint32_t)cz << sz);
             int32_t c = find_cell(L, ck);
             if (c < 0) continue;
+            const int dd[3] = { dx, dy, dz };
             for (int32_t t = L->cell_start[c]; t < L->cell_start[c + 1]; t++) {
-                /* offsets relative to the point itself (float sub), moments in double */
-                double ex = (double)(L->sxyz[3 * t] - px), ey = (double)(L->sxyz[3 * t + 1] - py), ez = (double)(L->sxyz[3 * t + 2] - pz);
-                s[0] += ex; s[1] += ey; s[2] += ez;
-                q[0] += ex * ex; q[1] += ex * ey; q[2] += ex * ez; q[3] += ey * ey; q[4] += ey * ez; q[5] += ez * ez;
+                int64_t Q[3];
+                for (int a = 0; a < 3; a++) {
+                    float sv = (L->sxyz[3 * t + a] - g->mn[a]) * g->inv_leaf;
+                    float fr = sv - floorf(sv);
+                    Q[a] = (int64_t)(int32_t)rintf(fr * 65536.0f) + (int64_t)dd[a] * 65536;
+                }
+                s[0] += Q[0]; s[1] += Q[1]; s[2] += Q[2];
+                q[0] += Q[0] * Q[0]; q[1] += Q[0] * Q[1]; q[2] += Q[0] * Q[2]; q[3] += Q[1] * Q[1]; q[4] += Q[1] * Q[2]; q[5] += Q[2] * Q[2];
                 k++;
             }
         }}}
-        if (k < min_pts || k < 3) continue;
+        if (k < (int64_t)min_pts || k < 3) continue;
         double inv = 1.0 / (double)k;
-        double m0 = s[0] * inv, m1 = s[1] * inv, m2 = s[2] * inv;
-        double c[6] = { q[0] * inv - m0 * m0, q[1] * inv - m0 * m1, q[2] * inv - m0 * m2,
-                        q[3] * inv - m1 * m1, q[4] * inv - m1 * m2, q[5] * inv - m2 * m2 };
+        double m0 = (double)s[0] * inv, m1 = (double)s[1] * inv, m2 = (double)s[2] * inv;
+        double c[6] = { (double)q[0] * inv - m0 * m0, (double)q[1] * inv - m0 * m1, (double)q[2] * inv - m0 * m2,
+                        (double)q[3] * inv - m1 * m1, (double)q[4] * inv - m1 * m2, (double)q[5] * inv - m2 * m2 };
         double cm = sym3_maxabs(c);
         if (!(cm > 0.0)) continue;
         for (int i = 0; i < 6; i++) c[i] = c[i] / cm;
