@@ -156,7 +156,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step"},
             "ms_per_icp_iter_batch": 1e3 * avg_launch_s,
             "ms_per_icp_iter_per_pair": 1e3 * avg_launch_s / B,
-            "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
+            "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr, "lds_chunks_vs_fallback_pair0": list(reg.counters()),
             "roofline": {"bound": "hbm", "kernel": "k_icp_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},

@@ -26,7 +26,7 @@ EXPORTS = [
     "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
-    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read",
+    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters",
 ]
 
 
@@ -69,6 +69,7 @@ def lib():
     L.m3dreg_debug_nn.argtypes = [vp, vp, C.c_int, f32p, sz, C.c_float, i32p, f32p]
     L.m3dreg_debug_accumulate.argtypes = [vp, vp, vp, C.c_int, f32p, i64p, i32p]
     L.m3dreg_debug_trace.argtypes = [vp, f64p, sz, C.POINTER(sz)]
+    L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), f64p, C.c_int]
     if L.m3dreg_abi_version() != abi.ABI_VERSION:
@@ -256,6 +257,11 @@ class Registrar:
         t = T_to_colmajor16(T)
         self._check(lib().m3dreg_debug_accumulate(self._h, source._p, target._p, level, _ptr(t, C.c_float), _ptr(sums, C.c_int64), _ptr(exps, C.c_int32)), "debug_accumulate")
         return sums, exps
+
+    def counters(self):
+        out = (C.c_uint64 * 2)()
+        self._check(lib().m3dreg_debug_counters(self._h, out), "debug_counters")
+        return int(out[0]), int(out[1])
 
     def trace(self, cap=256):
         buf = np.zeros((cap, 16), np.float64)

@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float* __restrict__ x,
     float px = x[i], py = y[i], pz = z[i];
     uint32_t key = M3D_INVALID_KEY;
     if (m3d_finite3(px, py, pz)) {
-        uint32_t ix = (uint32_t)(int)m3d_cell_f(px, g.mn[0], g.inv_leaf);
-        uint32_t iy = (uint32_t)(int)m3d_cell_f(py, g.mn[1], g.inv_leaf);
-        uint32_t iz = (uint32_t)(int)m3d_cell_f(pz, g.mn[2], g.inv_leaf);
-        key = ix | (iy << g.sy) | (iz << g.sz);
+        const int ix = (int)m3d_cell_f(px, g.mn[0], g.inv_leaf);
+        const int iy = (int)m3d_cell_f(py, g.mn[1], g.inv_leaf);
+        const int iz = (int)m3d_cell_f(pz, g.mn[2], g.inv_leaf);
+        key = m3d_voxel_key(g.cb, ix, iy, iz);
     }
     keys[i] = key; skey[i] = key; sval[i] = (uint32_t)i;
 }
@@ -164,32 +164,124 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __res
     }
 }
 
-// ---- a4: cell heads -> hash table, cell-sorted float4 points (+ normals gathered into the same order)
+// ---- a4: bucket heads -> exact-sized hash table, sorted float4 points -----------------------------
+// dyn[0] = occupied voxels, dyn[1] = hmask, dyn[2] = hshift, dyn[3] = occupied buckets, dyn[4] = big buckets
+// (table geometry is derived on the device: no host round trip between the sort and the table build)
+__global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict__ skey, int n, uint32_t* __restrict__ dyn) {
+    uint32_t c = 0, b = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t k = skey[j];
+        if (k == M3D_INVALID_KEY) continue;
+        const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
+        if (j == 0 || kp != k) c++;
+        if (j == 0 || (kp >> 3) != (k >> 3)) b++;
+    }
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_down((int)c, o); b += __shfl_down((int)b, o); }
+    __shared__ uint32_t red[4][2];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = c; red[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        if (c) atomicAdd(&dyn[0], c);
+        if (b) atomicAdd(&dyn[3], b);
+    }
+}
+
+__host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap, uint32_t& hmask, int& hshift) {
+    uint32_t hs = 16; int hb = 4;
+    while (hs < 2u * n_buckets && hs < hcap) { hs <<= 1; hb++; }
+    hmask = hs - 1; hshift = 32 - hb;
+}
+
+__global__ void k_table_params(uint32_t* __restrict__ dyn, uint32_t hcap) {
+    uint32_t hmask; int hshift;
+    m3d_table_size(dyn[3], hcap, hmask, hshift);
+    dyn[1] = hmask; dyn[2] = (uint32_t)hshift;
+}
+
+__global__ __launch_bounds__(256) void k_clear_table(M3dBucket* __restrict__ htab, const uint32_t* __restrict__ dyn) {
+    const uint32_t T2 = 2u * (dyn[1] + 1u);
+    uint4* t = reinterpret_cast<uint4*>(htab);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T2; i += gridDim.x * blockDim.x)
+        t[i] = (i & 1u) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+}
+
+__device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const float4& p) {
+    const int ix = (int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf), iy = (int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf),
+              iz = (int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf);
+    return m3d_bucket_key(g, ix >> 1, iy >> 1, iz >> 1);
+}
+
 __global__ __launch_bounds__(256) void k_finalize_level(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval, int n,
                                                         const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                        const float4* __restrict__ nrm_in, float4* __restrict__ pts, float4* __restrict__ nrm,
-                                                        uint2* __restrict__ htab, uint32_t hmask, int hshift, uint32_t* __restrict__ n_cells) {
+                                                        M3dGrid g, float4* __restrict__ pts, M3dBucket* __restrict__ htab,
+                                                        const uint32_t* __restrict__ dyn) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    const uint32_t hmask = dyn[1];
+    const int hshift = (int)dyn[2];
     const uint32_t k = skey[j];
     const uint32_t oi = sval[j];
     const bool valid = k != M3D_INVALID_KEY;
-    const bool head = valid && (j == 0 || skey[j - 1] != k);
+    const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
+    const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
     const bool last = valid && (j == n - 1 || skey[j + 1] != k);
     float4 p;
     p.x = x[oi]; p.y = y[oi]; p.z = z[oi];
     p.w = __uint_as_float(oi | (last ? M3D_LAST_FLAG : 0u));
     pts[j] = p;
-    if (nrm) nrm[j] = valid ? nrm_in[oi] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (head) {
-        uint32_t h = m3d_hash_slot(k, hshift);
-        for (;;) {   // keys are unique here, so a successful CAS owns the slot
-            uint32_t old = atomicCAS(&htab[h].x, M3D_INVALID_KEY, k);
-            if (old == M3D_INVALID_KEY) { htab[h].y = (uint32_t)j; break; }
+    if (bhead) {
+        const uint32_t bk = bucket_key_of_point(g, p);
+        uint32_t h = m3d_hash_slot(bk, hshift);
+        for (;;) {   // bucket keys are unique here, so a successful CAS owns the slot
+            uint32_t old = atomicCAS(&htab[h].key, M3D_INVALID_KEY, bk);
+            if (old == M3D_INVALID_KEY) { htab[h].start = (uint32_t)j; break; }
             h = (h + 1) & hmask;
         }
-        atomicAdd(n_cells, 1u);
     }
+}
+
+// second pass: the last point of every bucket writes the population (and claims a bigcum row when it
+// does not fit 16 bits)
+__global__ __launch_bounds__(256) void k_bucket_counts(const uint32_t* __restrict__ skey, int n, const float4* __restrict__ pts, M3dGrid g,
+                                                       M3dBucket* __restrict__ htab, uint32_t* __restrict__ dyn) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = skey[j];
+    if (k == M3D_INVALID_KEY) return;
+    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
+    if ((kn >> 3) == (k >> 3) && kn != M3D_INVALID_KEY) return;     // not the last point of its bucket
+    const uint32_t hmask = dyn[1];
+    const uint32_t bk = bucket_key_of_point(g, pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)dyn[2]);
+    while (htab[h].key != bk) h = (h + 1) & hmask;
+    const uint32_t cnt = (uint32_t)j - htab[h].start + 1u;
+    htab[h].count = cnt;
+    htab[h].big = (cnt > 65535u) ? (1u + atomicAdd(&dyn[4], 1u)) : 0u;
+}
+
+// third pass: the last point of every voxel writes the cumulative population of its voxel and of the
+// empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0)
+__global__ __launch_bounds__(256) void k_bucket_cum(const uint32_t* __restrict__ skey, int n, const float4* __restrict__ pts, M3dGrid g,
+                                                    M3dBucket* __restrict__ htab, uint32_t* __restrict__ bigcum, uint32_t bigcap,
+                                                    const uint32_t* __restrict__ dyn) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = skey[j];
+    if (k == M3D_INVALID_KEY) return;
+    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
+    if (kn == k) return;                                              // not the last point of its voxel
+    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
+    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
+    const uint32_t hmask = dyn[1];
+    const uint32_t bk = bucket_key_of_point(g, pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)dyn[2]);
+    while (htab[h].key != bk) h = (h + 1) & hmask;
+    const uint32_t v = (uint32_t)j - htab[h].start + 1u;
+    const uint32_t big = htab[h].big;
+    if (big == 0) { for (int t = s0; t < s1; t++) htab[h].cum[t] = (uint16_t)v; }
+    else if (big - 1u < bigcap) { for (int t = s0; t < s1; t++) bigcum[8 * (size_t)(big - 1u) + t] = v; }
 }
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
@@ -228,8 +320,10 @@ __device__ __forceinline__ int m3d_quant_frac(float v, float mn, float inv_leaf)
     return (int)rintf(fr * 65536.0f);
 }
 
-__global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint32_t* __restrict__ skey, long long* __restrict__ mom) {
+__global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint32_t* __restrict__ dyn, const uint32_t* __restrict__ skey,
+                                                      long long* __restrict__ mom) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    L.g.hmask = dyn[1]; L.g.hshift = (int)dyn[2];
     const M3dGrid& g = L.g;
     const int lane = threadIdx.x & 63;
     const bool ok = j < g.n_valid;
@@ -261,7 +355,10 @@ __global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint3
         }
     }
     if (ok && tail) {
-        const int hp = m3d_find_cell(L.htab, g.hmask, g.hshift, key);   // first sorted position of this voxel
+        // first sorted position of this voxel (the moments of a voxel live at that index)
+        const float4 pj = L.pts[j];
+        const int hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
+                                           (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
 #pragma unroll
         for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
     }
@@ -269,23 +366,25 @@ __global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint3
 
 // Pass 2: per point, add the (shifted) moments of the 27 voxels around it and take the smallest
 // eigenvector of the covariance.
-__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, const uint32_t* __restrict__ skey, const long long* __restrict__ mom,
-                                                 float plane_ratio, int min_pts, float min_spread, float4* __restrict__ nrm_in) {
+__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, const uint32_t* __restrict__ dyn, const uint32_t* __restrict__ skey,
+                                                 const long long* __restrict__ mom, float plane_ratio, int min_pts, float min_spread,
+                                                 float4* __restrict__ nrm_in) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L.g.n_valid) return;
+    L.g.hmask = dyn[1]; L.g.hshift = (int)dyn[2];
     const M3dGrid& g = L.g;
-    const uint32_t oi = __float_as_uint(L.pts[j].w) & ~M3D_LAST_FLAG;
+    const float4 pj = L.pts[j];
+    const uint32_t oi = __float_as_uint(pj.w) & ~M3D_LAST_FLAG;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t key = skey[j];
-    const int icx = (int)(key & ((1u << g.sy) - 1u)), icy = (int)((key >> g.sy) & ((1u << (g.sz - g.sy)) - 1u)), icz = (int)(key >> g.sz);
+    const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
+              icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     for (int dz = -1; dz <= 1; dz++) { const int cz = icz + dz; if (cz < 0 || cz >= g.dims[2]) continue;
     for (int dy = -1; dy <= 1; dy++) { const int cy = icy + dy; if (cy < 0 || cy >= g.dims[1]) continue;
     for (int dx = -1; dx <= 1; dx++) { const int cx = icx + dx; if (cx < 0 || cx >= g.dims[0]) continue;
-        const uint32_t ck = (uint32_t)cx | ((uint32_t)cy << g.sy) | ((uint32_t)cz << g.sz);
-        const int hp = m3d_find_cell(L.htab, g.hmask, g.hshift, ck);
-        if (hp < 0) continue;
-        const long long* m = &mom[10 * (size_t)hp];
+        const uint2 vr = m3d_find_voxel(L, cx, cy, cz);
+        if (vr.y <= vr.x) continue;
+        const long long* m = &mom[10 * (size_t)vr.x];
         const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
         const long long Dx = (long long)dx * M3D_NQ, Dy = (long long)dy * M3D_NQ, Dz = (long long)dz * M3D_NQ;
         k += n;
@@ -357,7 +456,10 @@ __global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __
     if (j >= n) return;
     const float4 p = pts[j];
     xyz[3 * j] = p.x; xyz[3 * j + 1] = p.y; xyz[3 * j + 2] = p.z;
-    if (nrm && nxyz) { const float4 q = nrm[j]; nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z; }
+    if (nrm && nxyz) {   // normals are stored by input index: gather into sorted order for the export
+        const float4 q = nrm[__float_as_uint(p.w) & ~M3D_LAST_FLAG];
+        nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z;
+    }
 }
 
 // ---- host-side launchers ----------------------------------------------------------------------------
@@ -393,23 +495,27 @@ hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a) {
     // keep the sorted keys / permutation for the introspection API
     HIP_TRY(hipMemcpyAsync(a.skey_out, kin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(a.perm_out, vin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(a.htab, 0xFF, sizeof(uint2) * ((size_t)a.grid.hmask + 1), s));
-    HIP_TRY(hipMemsetAsync(a.n_cells, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_finalize_level, dim3(blocks), dim3(256), 0, s, kin, vin, n, a.x, a.y, a.z, a.nrm_in, a.pts, a.nrm, a.htab,
-                       a.grid.hmask, a.grid.hshift, a.n_cells);
+    HIP_TRY(hipMemsetAsync(a.n_cells, 0, 8 * sizeof(uint32_t), s));
+    int cb = blocks > 256 ? 256 : blocks;
+    hipLaunchKernelGGL(k_count_cells, dim3(cb), dim3(256), 0, s, kin, n, a.n_cells);
+    hipLaunchKernelGGL(k_table_params, dim3(1), dim3(1), 0, s, a.n_cells, a.hcap);
+    hipLaunchKernelGGL(k_clear_table, dim3(cb), dim3(256), 0, s, a.htab, a.n_cells);
+    hipLaunchKernelGGL(k_finalize_level, dim3(blocks), dim3(256), 0, s, kin, vin, n, a.x, a.y, a.z, a.grid, a.pts, a.htab, a.n_cells);
+    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks), dim3(256), 0, s, kin, n, a.pts, a.grid, a.htab, a.n_cells);
+    hipLaunchKernelGGL(k_bucket_cum, dim3(blocks), dim3(256), 0, s, kin, n, a.pts, a.grid, a.htab, a.bigcum, a.bigcap, a.n_cells);
     return hipGetLastError();
 }
 
 int m3d_sort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
+hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* dyn, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
                               float min_spread, float4* nrm_in, int n) {
     HIP_TRY(hipMemsetAsync(nrm_in, 0, sizeof(float4) * (size_t)n, s));
     const int nv = L.g.n_valid;
     HIP_TRY(hipMemsetAsync(mom, 0, sizeof(long long) * 10 * (size_t)nv, s));
     const int blocks = (nv + 255) / 256;
-    hipLaunchKernelGGL(k_cell_moments, dim3(blocks), dim3(256), 0, s, L, skey, mom);
-    hipLaunchKernelGGL(k_normals, dim3(blocks), dim3(256), 0, s, L, skey, (const long long*)mom, plane_ratio, min_pts, min_spread, nrm_in);
+    hipLaunchKernelGGL(k_cell_moments, dim3(blocks), dim3(256), 0, s, L, dyn, skey, mom);
+    hipLaunchKernelGGL(k_normals, dim3(blocks), dim3(256), 0, s, L, dyn, skey, (const long long*)mom, plane_ratio, min_pts, min_spread, nrm_in);
     return hipGetLastError();
 }
 

@@ -14,59 +14,103 @@
 
 #define ICP_THREADS 256
 #define ICP_WAVES (ICP_THREADS / 64)
+// LDS staging capacity per wave (k_icp_lds): buckets of the wave's query box / target points staged
+#define ICP_CCAP 256
+#define ICP_PCAP 512
+#define ICP_ROUNDS (ICP_CCAP / 64)
 
 // ---- a6: exact NN over the 27 voxels around u --------------------------------------------------
-// Returns the sorted position of the match (or -1) and its squared distance / input index.
-// Pruning only ever skips a voxel whose box is provably farther than the current best (or than
-// d_max), so the result is identical to the exhaustive walk of the oracle.
-__device__ __forceinline__ int m3d_nn27(const M3dLevelDev& L, float ux, float uy, float uz, float dmax2, float& out_d2,
-                                        float4& out_q) {
-    const M3dGrid& g = L.g;
-    const float fx = m3d_cell_f(ux, g.mn[0], g.inv_leaf);
-    const float fy = m3d_cell_f(uy, g.mn[1], g.inv_leaf);
-    const float fz = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
-    if (!(fx >= -1.0f && fx <= (float)g.dims[0])) return -1;
-    if (!(fy >= -1.0f && fy <= (float)g.dims[1])) return -1;
-    if (!(fz >= -1.0f && fz <= (float)g.dims[2])) return -1;
-    const int icx = (int)fx, icy = (int)fy, icz = (int)fz;
-    // distance from u to the lower / upper faces of its own voxel (conservative by prune_slack)
-    const float rx = (ux - g.mn[0]) - fx * g.leaf, ry = (uy - g.mn[1]) - fy * g.leaf, rz = (uz - g.mn[2]) - fz * g.leaf;
-    const float lox = fmaxf(rx - g.prune_slack, 0.f), hix = fmaxf((g.leaf - rx) - g.prune_slack, 0.f);
-    const float loy = fmaxf(ry - g.prune_slack, 0.f), hiy = fmaxf((g.leaf - ry) - g.prune_slack, 0.f);
-    const float loz = fmaxf(rz - g.prune_slack, 0.f), hiz = fmaxf((g.leaf - rz) - g.prune_slack, 0.f);
-    int best = -1;
-    float bd = 3.0e38f;
-    uint32_t boi = 0;
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    float bound = dmax2 * 1.0001f;
-    for (int k = 0; k < 27; k++) {
-        int idx = k + 13; if (idx >= 27) idx -= 27;     // own voxel first
-        const int dz = idx / 9 - 1, dy = (idx / 3) % 3 - 1, dx = idx % 3 - 1;
-        const int cx = icx + dx, cy = icy + dy, cz = icz + dz;
-        if (cx < 0 || cx >= g.dims[0] || cy < 0 || cy >= g.dims[1] || cz < 0 || cz >= g.dims[2]) continue;
-        const float gx = dx < 0 ? lox : (dx > 0 ? hix : 0.f);
-        const float gy = dy < 0 ? loy : (dy > 0 ? hiy : 0.f);
-        const float gz = dz < 0 ? loz : (dz > 0 ? hiz : 0.f);
-        if (gx * gx + gy * gy + gz * gz > bound) continue;
-        const uint32_t key = (uint32_t)cx | ((uint32_t)cy << g.sy) | ((uint32_t)cz << g.sz);
-        int t = m3d_find_cell(L.htab, g.hmask, g.hshift, key);
-        if (t < 0) continue;
-        for (;;) {
-            const float4 q = L.pts[t];
-            const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
-            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            const uint32_t w = __float_as_uint(q.w);
-            const uint32_t oi = w & ~M3D_LAST_FLAG;
-            if (best < 0 || d2 < bd || (d2 == bd && oi < boi)) { best = t; bd = d2; boi = oi; bq = q; }
-            if (w & M3D_LAST_FLAG) break;
-            t++;
-        }
-        bound = fminf(bound, bd * 1.0001f);
+// The 27 voxels live in at most 2x2x2 buckets: up to 8 independent hash probes are issued first
+// (memory-level parallelism instead of a 27-step dependent chain), then only the voxels of the hit
+// buckets that belong to the neighbourhood are walked. Pruning only ever skips a voxel whose box is
+// provably farther than the current best (or than d_max), so the result is identical to the
+// exhaustive walk of the oracle. Returns 1 (match) or -1; out_q = matched point (w = input index bits).
+struct M3dQuery {          // per-query geometry shared by the global and the LDS search
+    int ic[3];             // voxel of the query (may be -1 or dims: one voxel outside the grid)
+    int lo[3], hi[3];      // neighbourhood clamped to the grid (voxel coordinates)
+    float gl[3], gh[3];    // conservative distance to the lower / upper faces of the query's own voxel
+};
+
+__device__ __forceinline__ bool m3d_query_setup(const M3dGrid& g, float ux, float uy, float uz, M3dQuery& Q) {
+    const float u[3] = { ux, uy, uz };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float f = m3d_cell_f(u[a], g.mn[a], g.inv_leaf);
+        if (!(f >= -1.0f && f <= (float)g.dims[a])) return false;
+        Q.ic[a] = (int)f;
+        Q.lo[a] = max(Q.ic[a] - 1, 0);
+        Q.hi[a] = min(Q.ic[a] + 1, g.dims[a] - 1);
+        const float r = (u[a] - g.mn[a]) - f * g.leaf;
+        Q.gl[a] = fmaxf(r - g.prune_slack, 0.f);
+        Q.gh[a] = fmaxf((g.leaf - r) - g.prune_slack, 0.f);
     }
-    if (best < 0 || !(bd <= dmax2)) return -1;
-    out_d2 = bd;
-    out_q = bq;
-    return best;
+    return true;
+}
+// squared lower bound of the distance from the query to voxel (vx,vy,vz) of its neighbourhood
+__device__ __forceinline__ float m3d_voxel_lb2(const M3dQuery& Q, int vx, int vy, int vz) {
+    const int dx = vx - Q.ic[0], dy = vy - Q.ic[1], dz = vz - Q.ic[2];
+    const float gx = dx < 0 ? Q.gl[0] : (dx > 0 ? Q.gh[0] : 0.f);
+    const float gy = dy < 0 ? Q.gl[1] : (dy > 0 ? Q.gh[1] : 0.f);
+    const float gz = dz < 0 ? Q.gl[2] : (dz > 0 ? Q.gh[2] : 0.f);
+    return gx * gx + gy * gy + gz * gz;
+}
+
+struct M3dBest { int found; float d2; uint32_t oi; float4 q; };
+
+__device__ __forceinline__ void m3d_consider(M3dBest& B, const float4& c4, float ux, float uy, float uz) {
+    const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
+    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    const uint32_t oi = __float_as_uint(c4.w) & ~M3D_LAST_FLAG;
+    if (B.found < 0 || dd < B.d2 || (dd == B.d2 && oi < B.oi)) { B.found = 1; B.d2 = dd; B.oi = oi; B.q = c4; }
+}
+
+__device__ __forceinline__ int m3d_nn27(const M3dLevelDev& L, float ux, float uy, float uz, float dmax2, float& out_d2, float4& out_q) {
+    const M3dGrid& g = L.g;
+    M3dQuery Q;
+    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
+    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+    const uint4* tab = reinterpret_cast<const uint4*>(L.htab);
+    // phase 1: issue every probe (independent loads)
+    uint4 lo[8]; uint32_t slot[8], key[8]; bool act[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+        act[b] = (ox <= nbx) && (oy <= nby) && (oz <= nbz);
+        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+        slot[b] = m3d_hash_slot(key[b], g.hshift);
+        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+        if (act[b]) lo[b] = tab[2 * (size_t)slot[b]];
+    }
+    // phase 2: linear probing for the rare collisions
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        if (act[b]) {
+            while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) { slot[b] = (slot[b] + 1) & g.hmask; lo[b] = tab[2 * (size_t)slot[b]]; }
+        }
+    }
+    // phase 3: walk the neighbourhood voxels of the hit buckets
+    M3dBest B; B.found = -1; B.d2 = 3.0e38f; B.oi = 0; B.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bound = dmax2 * 1.0001f;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        if (!act[b] || lo[b].x != key[b]) continue;
+        const uint4 hi = tab[2 * (size_t)slot[b] + 1];
+        const int vx0 = 2 * (b0x + (b & 1)), vy0 = 2 * (b0y + ((b >> 1) & 1)), vz0 = 2 * (b0z + (b >> 2));
+#pragma unroll
+        for (int sub = 0; sub < 8; sub++) {
+            const int vx = vx0 + (sub & 1), vy = vy0 + ((sub >> 1) & 1), vz = vz0 + (sub >> 2);
+            if (vx < Q.lo[0] || vx > Q.hi[0] || vy < Q.lo[1] || vy > Q.hi[1] || vz < Q.lo[2] || vz > Q.hi[2]) continue;
+            if (m3d_voxel_lb2(Q, vx, vy, vz) > bound) continue;
+            const uint2 rg = m3d_sub_range(lo[b], hi, L.bigcum, sub);
+            for (uint32_t t = rg.x; t < rg.y; t++) m3d_consider(B, L.pts[t], ux, uy, uz);
+            bound = fminf(bound, B.d2 * 1.0001f);
+        }
+    }
+    if (B.found < 0 || !(B.d2 <= dmax2)) return -1;
+    out_d2 = B.d2;
+    out_q = B.q;
+    return 1;
 }
 
 __device__ __forceinline__ long long m3d_quant(float term, float scale) {
@@ -96,86 +140,424 @@ __device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], l
     }
 }
 
-// One linearisation of every pair of the batch: grid = (blocks per pair, pairs).
-template <int METRIC>
-__global__ __launch_bounds__(ICP_THREADS) void k_icp_accumulate(const M3dJob* __restrict__ jobs, int first_of_level) {
-    const M3dJob& J = jobs[blockIdx.y];
-    M3dPairState* st = J.st;
-    if (st->done || (!first_of_level && st->level_done)) return;
+// a7: contribution of one correspondence (u matched to q, normal nq) to the running sums
+template <int METRIC, int NACC>
+__device__ __forceinline__ void m3d_accumulate_match(long long (&acc)[NACC], float ux, float uy, float uz, const float4& q, float d2,
+                                                     const float4& nq, float cx, float cy, float cz, const float (&S)[6]) {
+    const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
+    const float wx = ux - cx, wy = uy - cy, wz = uz - cz;
+    if (METRIC == 1) {
+        const float nx = nq.x, ny = nq.y, nz = nq.z;
+        if (nx == 0.0f && ny == 0.0f && nz == 0.0f) return;   // no usable normal: match rejected
+        float Jv[6];
+        Jv[0] = wy * nz - wz * ny; Jv[1] = wz * nx - wx * nz; Jv[2] = wx * ny - wy * nx;
+        Jv[3] = nx; Jv[4] = ny; Jv[5] = nz;
+        const float r = nx * ex + ny * ey + nz * ez;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int l = k; l < 6; l++) {
+                const float sc = (l < 3) ? S[0] : (k < 3 ? S[1] : S[2]);
+                acc[hslot21(k, l)] += m3d_quant(Jv[k] * Jv[l], sc);
+            }
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S[3]);
+#pragma unroll
+        for (int k = 3; k < 6; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S[4]);
+        acc[27] += m3d_quant(r * r, S[5]);
+        acc[28] += 1;
+    } else {
+        // 17 running sums: Hrr(6) | sum w (3) | g(6) | ssr | count
+        acc[0] += m3d_quant(wy * wy + wz * wz, S[0]);
+        acc[1] += m3d_quant(-(wx * wy), S[0]);
+        acc[2] += m3d_quant(-(wx * wz), S[0]);
+        acc[3] += m3d_quant(wx * wx + wz * wz, S[0]);
+        acc[4] += m3d_quant(-(wy * wz), S[0]);
+        acc[5] += m3d_quant(wx * wx + wy * wy, S[0]);
+        acc[6] += m3d_quant(wx, S[1]);
+        acc[7] += m3d_quant(wy, S[1]);
+        acc[8] += m3d_quant(wz, S[1]);
+        acc[9] += m3d_quant(wy * ez - wz * ey, S[3]);
+        acc[10] += m3d_quant(wz * ex - wx * ez, S[3]);
+        acc[11] += m3d_quant(wx * ey - wy * ex, S[3]);
+        acc[12] += m3d_quant(ex, S[4]);
+        acc[13] += m3d_quant(ey, S[4]);
+        acc[14] += m3d_quant(ez, S[4]);
+        acc[15] += m3d_quant(d2, S[5]);
+        acc[16] += 1;
+    }
+}
+
+__device__ __forceinline__ void m3d_load_pose(const M3dPairState* st, float (&R)[9], float (&tt)[3]) {
     // current pose rounded to float (spec: R row-major from the column-major double pose)
-    float R[9], tt[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int c = 0; c < 3; c++) R[3 * r + c] = (float)st->T[c * 4 + r];
         tt[r] = (float)st->T[12 + r];
     }
+}
+
+// ---- variant 0 (kept for A/B and as the reference structure): one thread per query, every voxel of the
+// 27-neighbourhood probed in global memory. grid = (blocks per pair, pairs). Latency-bound: see profiles/.
+template <int METRIC>
+__global__ __launch_bounds__(ICP_THREADS) void k_icp_accumulate(const M3dJob* __restrict__ jobs, int first_of_level) {
+    const M3dJob& J = jobs[blockIdx.y];
+    M3dPairState* st = J.st;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
     const M3dLevelDev& L = J.tgt;
     const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
     const float dmax2 = J.dmax2;
-    const float S0 = J.S[0], S1 = J.S[1], S2 = J.S[2], S3 = J.S[3], S4 = J.S[4], S5 = J.S[5];
+    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
+    constexpr int NACC = (METRIC == 1) ? 29 : 17;
+    long long acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    const int n = J.n_src;
+    for (int i = blockIdx.x * ICP_THREADS + threadIdx.x; i < n; i += gridDim.x * ICP_THREADS) {
+        const float4 p = J.src[i];
+        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        if (!m3d_finite3(ux, uy, uz)) continue;
+        float d2; float4 q;
+        const int j = m3d_nn27(L, ux, uy, uz, dmax2, d2, q);
+        if (j < 0) continue;
+        float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & ~M3D_LAST_FLAG];
+        m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
+    }
+    block_reduce_to_global<NACC>(acc, st->sums);
+}
 
+// ---- variant 1: wave-cooperative, LDS-staged voxel buckets ------------------------------------------
+// A wave takes 64 consecutive source points (the source cloud is streamed in ITS OWN voxel-sorted order,
+// so the 64 transformed queries fall into a compact box of target voxels). The wave (1) reduces the box
+// of its queries' voxel coordinates, (2) probes every voxel of the box (+1 halo) in the hash table — all
+// probes independent, 64 per instruction —, (3) stages the occupied voxels' points into LDS with fully
+// parallel 16-B loads, (4) lets every lane search its own 27 voxels in LDS only. Boxes that do not fit
+// the LDS budget (ICP_CCAP voxels / ICP_PCAP points) fall back to the global walk for that chunk.
+// The result is bit-identical to variant 0 (exact argmin with index tie-break, integer sums).
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, int& blk) {
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so with a multiple of 8 pairs the
+    // blocks of one pair are kept on one XCD (its L2 then holds one pair's clouds, not all eight).
+    const int id = blockIdx.x;
+    if ((n_pairs & 7) == 0) { const int slot = id >> 3; pair = (slot / bpp) * 8 + (id & 7); blk = slot % bpp; }
+    else { pair = id / bpp; blk = id % bpp; }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(ICP_THREADS) void k_icp_lds(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level) {
+    __shared__ uint4 s_cum[ICP_WAVES][ICP_CCAP];       // per box bucket: its 8 cumulative voxel populations (uint16 x 8)
+    __shared__ uint32_t s_off[ICP_WAVES][ICP_CCAP];    // per box bucket: LDS offset of its first staged point, 0xFFFFFFFF = empty
+    __shared__ float4 s_pts[ICP_WAVES][ICP_PCAP];      // staged target points
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk);
+    const M3dJob& J = jobs[pair];
+    M3dPairState* st = J.st;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
+    const M3dLevelDev& L = J.tgt;
+    const M3dGrid& g = L.g;
+    const float cx = g.center[0], cy = g.center[1], cz = g.center[2];
+    const float dmax2 = J.dmax2;
+    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
     long long acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0;
 
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* cumt = s_cum[wave];
+    uint32_t* offt = s_off[wave];
+    float4* spt = s_pts[wave];
+    const uint4* tab = reinterpret_cast<const uint4*>(L.htab);
     const int n = J.n_src;
-    for (int i = blockIdx.x * ICP_THREADS + threadIdx.x; i < n; i += gridDim.x * ICP_THREADS) {
-        const float px = J.sx[i], py = J.sy[i], pz = J.sz[i];
-        if (!m3d_finite3(px, py, pz)) continue;
-        const float ux = fmaf(R[0], px, fmaf(R[1], py, fmaf(R[2], pz, tt[0])));
-        const float uy = fmaf(R[3], px, fmaf(R[4], py, fmaf(R[5], pz, tt[1])));
-        const float uz = fmaf(R[6], px, fmaf(R[7], py, fmaf(R[8], pz, tt[2])));
-        if (!m3d_finite3(ux, uy, uz)) continue;
-        float d2; float4 q;
-        const int j = m3d_nn27(L, ux, uy, uz, dmax2, d2, q);
-        if (j < 0) continue;
-        const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
-        const float wx = ux - cx, wy = uy - cy, wz = uz - cz;
-        if (METRIC == 1) {
-            const float4 nq = L.nrm[j];
-            const float nx = nq.x, ny = nq.y, nz = nq.z;
-            if (nx == 0.0f && ny == 0.0f && nz == 0.0f) continue;
-            float Jv[6];
-            Jv[0] = wy * nz - wz * ny; Jv[1] = wz * nx - wx * nz; Jv[2] = wx * ny - wy * nx;
-            Jv[3] = nx; Jv[4] = ny; Jv[5] = nz;
-            const float r = nx * ex + ny * ey + nz * ez;
+    const int n_chunks = (n + 63) >> 6;
+    const int cpb = (n_chunks + bpp - 1) / bpp;          // chunks per block: contiguous range per block
+    const int c_end = min(n_chunks, (blk + 1) * cpb);
+    for (int chunk = blk * cpb + wave; chunk < c_end; chunk += ICP_WAVES) {
+        const int i = (chunk << 6) + lane;
+        const bool v = i < n;
+        const float4 p = v ? J.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        M3dQuery Q;
+        const bool inside = v && m3d_finite3(ux, uy, uz) && m3d_query_setup(g, ux, uy, uz, Q);
+        // (1) bucket box of the wave's neighbourhoods
+        const int BIG = 0x3FFFFFFF;
+        const int x0 = wave_min_i32(inside ? (Q.lo[0] >> 1) : BIG), x1 = wave_max_i32(inside ? (Q.hi[0] >> 1) : -BIG);
+        if (x1 < x0) continue;                            // no query of this chunk is near the grid (wave-uniform)
+        const int y0 = wave_min_i32(inside ? (Q.lo[1] >> 1) : BIG), y1 = wave_max_i32(inside ? (Q.hi[1] >> 1) : -BIG);
+        const int z0 = wave_min_i32(inside ? (Q.lo[2] >> 1) : BIG), z1 = wave_max_i32(inside ? (Q.hi[2] >> 1) : -BIG);
+        const int bx = x1 - x0 + 1, by = y1 - y0 + 1, bz = z1 - z0 + 1;
+        const int bxy = bx * by;
+        const long long nb_ll = (long long)bxy * bz;
+        bool fast = nb_ll <= ICP_CCAP;                    // wave-uniform
+        M3dBest B; B.found = -1; B.d2 = 3.0e38f; B.oi = 0; B.q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fast) {
+            const int nb = (int)nb_ll;
+            // (2) probe every bucket of the box: 64 independent probes per round
+            const float rbx = 1.0f / (float)bx, rbxy = 1.0f / (float)bxy;
+            uint32_t stt[ICP_ROUNDS], cnn[ICP_ROUNDS];
+            uint32_t mytotal = 0;
+            bool anybig = false;
 #pragma unroll
-            for (int k = 0; k < 6; k++)
-#pragma unroll
-                for (int l = k; l < 6; l++) {
-                    const float sc = (l < 3) ? S0 : (k < 3 ? S1 : S2);
-                    acc[hslot21(k, l)] += m3d_quant(Jv[k] * Jv[l], sc);
+            for (int r = 0; r < ICP_ROUNDS; r++) {
+                const int c = r * 64 + lane;
+                stt[r] = 0; cnn[r] = 0;
+                if (c < nb) {
+                    const int qz = (int)(((float)c + 0.5f) * rbxy);
+                    const int rem = c - qz * bxy;
+                    const int qy = (int)(((float)rem + 0.5f) * rbx);
+                    const int qx = rem - qy * bx;
+                    uint4 lo;
+                    const int h = m3d_find_bucket(L.htab, g.hmask, g.hshift, m3d_bucket_key(g, x0 + qx, y0 + qy, z0 + qz), lo);
+                    if (h >= 0) {
+                        stt[r] = lo.y; cnn[r] = lo.z;
+                        anybig = anybig || (lo.w != 0);
+                        cumt[c] = tab[2 * (size_t)h + 1];
+                        mytotal += lo.z;
+                    }
                 }
+            }
+            // lane-major LDS layout: one exclusive scan over the lanes' totals
+            uint32_t incl = mytotal;
 #pragma unroll
-            for (int k = 0; k < 3; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S3);
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+            const uint32_t P = (uint32_t)__shfl((int)incl, 63);
+            fast = (P <= ICP_PCAP) && (__ballot(anybig) == 0ull);   // wave-uniform
+            if (fast) {
+                uint32_t off = incl - mytotal;
 #pragma unroll
-            for (int k = 3; k < 6; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S4);
-            acc[27] += m3d_quant(r * r, S5);
-            acc[28] += 1;
-        } else {
-            // 17 running sums: Hrr(6) | sum w (3) | g(6) | ssr | count
-            acc[0] += m3d_quant(wy * wy + wz * wz, S0);
-            acc[1] += m3d_quant(-(wx * wy), S0);
-            acc[2] += m3d_quant(-(wx * wz), S0);
-            acc[3] += m3d_quant(wx * wx + wz * wz, S0);
-            acc[4] += m3d_quant(-(wy * wz), S0);
-            acc[5] += m3d_quant(wx * wx + wy * wy, S0);
-            acc[6] += m3d_quant(wx, S1);
-            acc[7] += m3d_quant(wy, S1);
-            acc[8] += m3d_quant(wz, S1);
-            acc[9] += m3d_quant(wy * ez - wz * ey, S3);
-            acc[10] += m3d_quant(wz * ex - wx * ez, S3);
-            acc[11] += m3d_quant(wx * ey - wy * ex, S3);
-            acc[12] += m3d_quant(ex, S4);
-            acc[13] += m3d_quant(ey, S4);
-            acc[14] += m3d_quant(ez, S4);
-            acc[15] += m3d_quant(d2, S5);
-            acc[16] += 1;
+                for (int r = 0; r < ICP_ROUNDS; r++) {
+                    const int c = r * 64 + lane;
+                    if (c < nb) {
+                        offt[c] = cnn[r] ? off : 0xFFFFFFFFu;
+                        for (uint32_t k = 0; k < cnn[r]; k++) spt[off + k].w = __uint_as_float(stt[r] + k);   // global index, resolved below
+                        off += cnn[r];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // (3) stage: all lanes busy, every load independent
+                for (uint32_t f = lane; f < P; f += 64) {
+                    const uint32_t idx = __float_as_uint(spt[f].w);
+                    spt[f] = L.pts[idx];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // (4) every lane searches its neighbourhood in LDS only
+                if (inside) {
+                    float bound = dmax2 * 1.0001f;
+                    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+                    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
+                    for (int b = 0; b < 8; b++) {
+                        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+                        if (ox > nbx || oy > nby || oz > nbz) continue;
+                        const int c = (b0x + ox - x0) + bx * (b0y + oy - y0) + bxy * (b0z + oz - z0);
+                        const uint32_t o0 = offt[c];
+                        if (o0 == 0xFFFFFFFFu) continue;
+                        const uint4 hi = cumt[c];
+                        const uint4 lo = make_uint4(0u, o0, 0u, 0u);
+                        const int vx0 = 2 * (b0x + ox), vy0 = 2 * (b0y + oy), vz0 = 2 * (b0z + oz);
+#pragma unroll
+                        for (int sub = 0; sub < 8; sub++) {
+                            const int vx = vx0 + (sub & 1), vy = vy0 + ((sub >> 1) & 1), vz = vz0 + (sub >> 2);
+                            if (vx < Q.lo[0] || vx > Q.hi[0] || vy < Q.lo[1] || vy > Q.hi[1] || vz < Q.lo[2] || vz > Q.hi[2]) continue;
+                            if (m3d_voxel_lb2(Q, vx, vy, vz) > bound) continue;
+                            const uint2 rg = m3d_sub_range(lo, hi, nullptr, sub);
+                            for (uint32_t t = rg.x; t < rg.y; t++) m3d_consider(B, spt[t], ux, uy, uz);
+                            bound = fminf(bound, B.d2 * 1.0001f);
+                        }
+                    }
+                    if (B.found >= 0 && !(B.d2 <= dmax2)) B.found = -1;
+                }
+                __builtin_amdgcn_wave_barrier();          // LDS of this wave is reused by its next chunk
+            }
+        }
+        if (!fast) {
+            if (inside) B.found = m3d_nn27(L, ux, uy, uz, dmax2, B.d2, B.q);
+        }
+        if (lane == 0) atomicAdd(&st->ctr[fast ? 0 : 1], 1u);
+        if (B.found >= 0) {
+            float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (METRIC == 1) nq = L.nrm[__float_as_uint(B.q.w) & ~M3D_LAST_FLAG];
+            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, B.q, B.d2, nq, cx, cy, cz, S);
         }
     }
-    // point-to-plane: the 29 spec slots; point-to-point: 17 transport slots (see expand_pt2pt)
+    block_reduce_to_global<NACC>(acc, st->sums);
+}
+
+// ---- variant 2 (default): the two stages as two kernels -------------------------------------------
+// k_nn_search: a6 only. One thread per query, nothing but the search state in registers, so the kernel
+// runs at high occupancy and its dependent gathers overlap across many waves; it writes one int32 per
+// query (sorted position of the match, -1 = none). k_accumulate_matches: a7 as a pure streaming
+// reduction over (source point, match) pairs. The extra traffic is 8 B per query and iteration.
+// per-axis conservative gap from the query to the voxel range [v0, v1] of its neighbourhood
+__device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, float gh) {
+    return (v1 < ic) ? gl : ((v0 > ic) ? gh : 0.f);
+}
+
+// Search state kept deliberately small (high occupancy). `g` is a by-value copy of the grid (SGPRs),
+// tab/pts/bigcum are global-address-space pointers (global_load, not flat_load).
+__device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
+                                            float dmax2) {
+    M3dQuery Q;
+    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
+    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+    int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
+    float bound = dmax2 * 1.0001f;
+    // all (up to eight) bucket entries, both halves, are requested before the first one is used: 16 loads in flight
+    uint4 lo[8], hi[8]; uint32_t key[8]; bool act[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+        act[b] = (ox <= nbx) && (oy <= nby) && (oz <= nbz);
+        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+        const uint32_t slot = m3d_hash_slot(key[b], g.hshift);
+        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+        hi[b] = make_uint4(0u, 0u, 0u, 0u);
+        if (act[b]) { lo[b] = m3d_ld(tab, 2 * (size_t)slot); hi[b] = m3d_ld(tab, 2 * (size_t)slot + 1); }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        if (!act[b]) continue;
+        if (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+            uint32_t slot = m3d_hash_slot(key[b], g.hshift);
+            do { slot = (slot + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot); } while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY);
+            hi[b] = m3d_ld(tab, 2 * (size_t)slot + 1);
+        }
+        if (lo[b].x != key[b]) continue;
+        // voxels of this bucket inside the neighbourhood: a sub-box, per axis [s0, s1] with s in {0,1}
+        const int vx0 = 2 * (b0x + (b & 1)), vy0 = 2 * (b0y + ((b >> 1) & 1)), vz0 = 2 * (b0z + (b >> 2));
+        const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
+        const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
+        const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
+        const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
+        const float gx2 = gx * gx;
+        const uint32_t base = lo[b].y;
+        const bool big = lo[b].w != 0;
+        // the four (y,z) rows of a bucket; the x-adjacent voxels of a row are adjacent runs: one merged range
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sy = r & 1, sz = r >> 1;
+            if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
+            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
+            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
+            if (gx2 + gy * gy + gz * gz > bound) continue;
+            uint32_t c0, c1;
+            if (!big) {
+                const uint32_t w = (r == 0) ? hi[b].x : (r == 1 ? hi[b].y : (r == 2 ? hi[b].z : hi[b].w));
+                const uint32_t wp = (r == 0) ? 0u : (r == 1 ? hi[b].x : (r == 2 ? hi[b].y : hi[b].z));
+                c1 = sx1 ? (w >> 16) : (w & 0xFFFFu);
+                c0 = sx0 ? (w & 0xFFFFu) : (wp >> 16);
+            } else {
+                const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo[b].w - 1);
+                c1 = bc[2 * r + sx1];
+                c0 = (2 * r + sx0) ? bc[2 * r + sx0 - 1] : 0u;
+            }
+            const uint32_t t1 = base + c1;
+            for (uint32_t t = base + c0; t < t1; t += 4) {
+                // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
+                float4 c4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
+                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
+                    if (best < 0 || dd < bd || (dd == bd && oi < boi)) { best = (int)min(t + k, t1 - 1); bd = dd; boi = oi; }
+                }
+            }
+            bound = fminf(bound, bd * 1.0001f);
+        }
+    }
+    if (best < 0 || !(bd <= dmax2)) return -1;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_nn_search(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
+                                                   int* __restrict__ match, int match_stride) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk);
+    const M3dJob& J = jobs[pair];
+    const M3dPairState* st = J.st;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
+    // hoist everything wave-uniform out of the loop (scalar registers), re-type the pointers as global
+    const M3dGrid g = J.tgt.g;
+    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts);
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
+    const m3d_gf4 src = m3d_as_global(J.src);
+    const float dmax2 = J.dmax2;
+    const int n = J.n_src;
+    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(match + (size_t)pair * match_stride);
+    for (int i = blk * 256 + threadIdx.x; i < n; i += bpp * 256) {
+        const float4 p = m3d_ld(src, i);
+        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        int m = -1;
+        if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_pos(g, tab, pts, bigcum, ux, uy, uz, dmax2);
+        out[i] = m;
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
+                                                                    const int* __restrict__ match, int match_stride) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk);
+    const M3dJob& J = jobs[pair];
+    M3dPairState* st = J.st;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
+    const M3dLevelDev& L = J.tgt;
+    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
+    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
+    constexpr int NACC = (METRIC == 1) ? 29 : 17;
+    long long acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    const int n = J.n_src;
+    const int* in = match + (size_t)pair * match_stride;
+    for (int i = blk * ICP_THREADS + threadIdx.x; i < n; i += bpp * ICP_THREADS) {
+        const int m = in[i];
+        if (m < 0) continue;
+        const float4 p = J.src[i];
+        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        const float4 q = L.pts[m];
+        const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
+        const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
+        float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & ~M3D_LAST_FLAG];
+        m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
+    }
     block_reduce_to_global<NACC>(acc, st->sums);
 }
 
@@ -320,20 +702,48 @@ static inline int icp_blocks(int max_n_src) {
     int b = (max_n_src + ICP_THREADS - 1) / ICP_THREADS;
     return b < 1 ? 1 : b;
 }
+// blocks per pair of the LDS variant: fill the chip about once (256 CUs x 3 resident blocks), at least one
+// chunk per wave, and amortise the 29-term reduction over several chunks per wave when the batch is large
+static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
+    const int n_chunks = (max_n_src + 63) / 64;
+    int need = (n_chunks + ICP_WAVES - 1) / ICP_WAVES;
+    int cap = (256 * 3) / (n_pairs < 1 ? 1 : n_pairs);
+    if (cap < 8) cap = 8;
+    int b = need < cap ? need : cap;
+    return b < 1 ? 1 : b;
+}
 
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric) {
-    dim3 grid(icp_blocks(max_n_src), n_pairs);
-    if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, 1);
-    else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, 1);
+static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
+                              int* match, int match_stride) {
+    if (variant == 2) {
+        // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
+        int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
+        hipLaunchKernelGGL(k_nn_search, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, match, match_stride);
+        int bpp_a = (max_n_src + 256 * 8 - 1) / (256 * 8); if (bpp_a < 1) bpp_a = 1;
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, match, match_stride);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, match, match_stride);
+    } else if (variant == 0) {
+        dim3 grid(icp_blocks(max_n_src), n_pairs);
+        if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
+        else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
+    } else {
+        const int bpp = icp_lds_bpp(max_n_src, n_pairs);
+        dim3 grid(bpp * n_pairs);
+        if (metric == 1) hipLaunchKernelGGL(k_icp_lds<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
+        else hipLaunchKernelGGL(k_icp_lds<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
+    }
+}
+
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant, int* match,
+                                      int match_stride) {
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, 1, variant, match, match_stride);
     return hipGetLastError();
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    hipEvent_t e0, hipEvent_t e1) {
-    dim3 grid(icp_blocks(max_n_src), n_pairs);
+                                    int variant, int* match, int match_stride, hipEvent_t e0, hipEvent_t e1) {
     if (e0) (void)hipEventRecord(e0, s);
-    if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
-    else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, match, match_stride);
     if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_solve_update, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, first_of_level);
     return hipGetLastError();

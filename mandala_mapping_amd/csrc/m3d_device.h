@@ -1,11 +1,17 @@
 // m3d_device.h — device-visible data layout of libm3dreg (gfx950 only; no CUDA/dual path).
 //
 // HBM layout of one bucketed cloud level (DESIGN.md §Data layout):
-//   pts  float4[n]  cell-sorted points {x, y, z, bits(input_index | last_in_cell << 31)} — one 16-B
-//                   gather per candidate, a cell is a contiguous run terminated by the flag bit
-//   nrm  float4[n]  unit normals in the same order ({0,0,0,0} = no usable normal), point-to-plane only
-//   htab uint2[T]   open-addressing hash of occupied voxels {key, first sorted position}, T = 2^k >= 2n
-// The source side of a registration is plain SoA x[n], y[n], z[n] in input order (coalesced stream).
+//   pts   float4[n]   points sorted by voxel key {x, y, z, bits(input_index | last_in_voxel << 31)}: one
+//                     16-B gather per candidate. Voxels are grouped in 2x2x2 BUCKETS; buckets follow a
+//                     compact Morton curve, the 8 voxels of a bucket are consecutive runs.
+//   htab  M3dBucket[T] open-addressing hash of occupied buckets, 32 B per entry (two 16-B halves):
+//                     {bucket key, first sorted position, population, big index} + 8 cumulative
+//                     per-voxel populations (uint16). T = smallest power of two >= 2 * occupied buckets,
+//                     derived on the device after the sort (no host round trip).
+//                     A query's 27 voxels live in at most 2x2x2 buckets: 8 probes instead of 27.
+//   nrm   float4[n]   unit normals by INPUT index ({0,0,0,0} = no usable normal), point-to-plane only
+// The source side of a registration streams the source cloud's own sorted float4 array (16 B per lane,
+// 1 KiB per wave instruction: fully coalesced), so the 64 lanes of a wave hold spatially adjacent queries.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,18 +26,27 @@ struct M3dGrid {           // geometry of one voxel grid (host computes it from 
     float inv_leaf;
     float center[3];
     float leaf;
-    int32_t dims[3];
-    int32_t sy, sz;        // key = ix | iy << sy | iz << sz
-    int32_t hshift;        // hash slot = (key * 0x9E3779B1u) >> hshift
+    int32_t dims[3];       // extent in voxels
+    int32_t cb[3];         // bit widths of the bucket coordinates (bucket = voxel >> 1)
+    int32_t hshift;        // hash slot = (bucket key * 0x9E3779B1u) >> hshift
     uint32_t hmask;
     int32_t n_valid;
-    float prune_slack;     // absolute slack [m] subtracted from cell-box gaps before pruning
+    float prune_slack;     // absolute slack [m] subtracted from voxel-box gaps before pruning
+};
+
+struct M3dBucket {         // 32 bytes, 32-byte aligned
+    uint32_t key;          // cx | cy << cb[0] | cz << (cb[0]+cb[1]); M3D_INVALID_KEY = empty slot
+    uint32_t start;        // first sorted position of the bucket's points
+    uint32_t count;        // points in the bucket
+    uint32_t big;          // 0, or 1 + index into the level's bigcum table when count > 65535
+    uint16_t cum[8];       // cum[s] = points of the bucket in voxels 0..s (s = (ix&1)|(iy&1)<<1|(iz&1)<<2)
 };
 
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* pts;
     const float4* nrm;
-    const uint2* htab;
+    const M3dBucket* htab;
+    const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
     M3dGrid g;
 };
 
@@ -46,13 +61,11 @@ struct M3dPairState {      // per-registration state, lives in HBM for the whole
     int32_t done;                  // final: no further iteration may run
     int32_t level_done;            // current level converged: skip its remaining iterations
     uint32_t ticket;
-    int32_t pad[2];
+    uint32_t ctr[2];               // diagnostics: chunks served from LDS / chunks that fell back to the global walk
 };
 
 struct M3dJob {            // one pair at one level
-    const float* sx;
-    const float* sy;
-    const float* sz;
+    const float4* src;     // source points in the source cloud's own sorted order (finest level), n_src finite points
     int32_t n_src;
     int32_t metric;
     M3dLevelDev tgt;
@@ -75,16 +88,71 @@ __device__ __forceinline__ float m3d_cell_f(float v, float mn, float inv_leaf) {
     float s = d * inv_leaf;
     return floorf(s);
 }
+// Spec §Grid: voxel sort key = compact Morton code of the bucket coordinates << 3 | position in the bucket
+__device__ __forceinline__ uint32_t m3d_voxel_key(const int32_t (&cb)[3], int ix, int iy, int iz) {
+    const uint32_t cx = (uint32_t)ix >> 1, cy = (uint32_t)iy >> 1, cz = (uint32_t)iz >> 1;
+    uint32_t code = 0; int pos = 0;
+#pragma unroll
+    for (int b = 0; b < 11; b++) {
+        if (b < cb[0]) { code |= ((cx >> b) & 1u) << pos; pos++; }
+        if (b < cb[1]) { code |= ((cy >> b) & 1u) << pos; pos++; }
+        if (b < cb[2]) { code |= ((cz >> b) & 1u) << pos; pos++; }
+    }
+    return (code << 3) | ((uint32_t)ix & 1u) | (((uint32_t)iy & 1u) << 1) | (((uint32_t)iz & 1u) << 2);
+}
+__device__ __forceinline__ uint32_t m3d_bucket_key(const M3dGrid& g, int cx, int cy, int cz) {
+    return (uint32_t)cx | ((uint32_t)cy << g.cb[0]) | ((uint32_t)cz << (g.cb[0] + g.cb[1]));
+}
 __device__ __forceinline__ uint32_t m3d_hash_slot(uint32_t key, int hshift) {
     return (key * 0x9E3779B1u) >> hshift;
 }
-// first sorted position of the voxel `key`, or -1
-__device__ __forceinline__ int m3d_find_cell(const uint2* __restrict__ htab, uint32_t hmask, int hshift, uint32_t key) {
+// Pointers that arrive inside descriptors loaded from memory are "generic" to the compiler, which then
+// emits flat_load (slower, and every wait drains both counters). They all point to hipMalloc'ed HBM,
+// so the kernels re-type them as global (address space 1) before use.
+#define M3D_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t m3d_u32x4 __attribute__((ext_vector_type(4)));
+typedef float m3d_f32x4 __attribute__((ext_vector_type(4)));
+typedef const M3D_GLOBAL m3d_u32x4* m3d_gu4;
+typedef const M3D_GLOBAL m3d_f32x4* m3d_gf4;
+typedef const M3D_GLOBAL uint32_t* m3d_gu32;
+__device__ __forceinline__ m3d_gu4 m3d_as_global(const uint4* p) { return (m3d_gu4)(const void M3D_GLOBAL*)p; }
+__device__ __forceinline__ m3d_gf4 m3d_as_global(const float4* p) { return (m3d_gf4)(const void M3D_GLOBAL*)p; }
+__device__ __forceinline__ m3d_gu32 m3d_as_global(const uint32_t* p) { return (m3d_gu32)(const void M3D_GLOBAL*)p; }
+__device__ __forceinline__ uint4 m3d_ld(m3d_gu4 p, size_t i) { const m3d_u32x4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 m3d_ld(m3d_gf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
+// slot of the bucket `key` or -1; `lo` receives the first half of its entry {key, start, count, big}
+__device__ __forceinline__ int m3d_find_bucket(const M3dBucket* __restrict__ htab, uint32_t hmask, int hshift, uint32_t key, uint4& lo) {
     uint32_t h = m3d_hash_slot(key, hshift);
     for (;;) {
-        uint2 e = htab[h];
-        if (e.x == key) return (int)e.y;
-        if (e.x == M3D_INVALID_KEY) return -1;
+        lo = reinterpret_cast<const uint4*>(htab)[2 * (size_t)h];
+        if (lo.x == key) return (int)h;
+        if (lo.x == M3D_INVALID_KEY) return -1;
         h = (h + 1) & hmask;
     }
+}
+// [begin, end) sorted positions of voxel `sub` of a found bucket (lo = first half, hi = second half of the entry)
+__device__ __forceinline__ uint2 m3d_sub_range(const uint4& lo, const uint4& hi, const uint32_t* __restrict__ bigcum, int sub) {
+    uint32_t c0, c1;
+    if (lo.w == 0) {
+        const unsigned long long a = ((unsigned long long)hi.y << 32) | hi.x, b = ((unsigned long long)hi.w << 32) | hi.z;
+        const unsigned long long w1 = (sub < 4) ? a : b;
+        c1 = (uint32_t)(w1 >> (16 * (sub & 3))) & 0xFFFFu;
+        const int sm = sub - 1;
+        const unsigned long long w0 = (sm < 4) ? a : b;
+        c0 = sub ? ((uint32_t)(w0 >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
+    } else {
+        const uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
+        c1 = bc[sub];
+        c0 = sub ? bc[sub - 1] : 0u;
+    }
+    return make_uint2(lo.y + c0, lo.y + c1);
+}
+// [begin, end) of an arbitrary voxel (ix,iy,iz inside the grid); empty range when the voxel is unoccupied
+__device__ __forceinline__ uint2 m3d_find_voxel(const M3dLevelDev& L, int ix, int iy, int iz) {
+    uint4 lo;
+    const int h = m3d_find_bucket(L.htab, L.g.hmask, L.g.hshift, m3d_bucket_key(L.g, ix >> 1, iy >> 1, iz >> 1), lo);
+    if (h < 0) return make_uint2(0u, 0u);
+    const uint4 hi = reinterpret_cast<const uint4*>(L.htab)[2 * (size_t)h + 1];
+    return m3d_sub_range(lo, hi, L.bigcum, (ix & 1) | ((iy & 1) << 1) | ((iz & 1) << 2));
 }

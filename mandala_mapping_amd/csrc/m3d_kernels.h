@@ -13,11 +13,12 @@ struct M3dBucketArgs {
     uint32_t* hist;              // [256 * tiles]
     uint32_t* skey_out;          // [n] out: sorted keys
     uint32_t* perm_out;          // [n] out: permutation
-    const float4* nrm_in;        // [n] normals in input order or null
     float4* pts;                 // [n] out
-    float4* nrm;                 // [n] out or null
-    uint2* htab;                 // [hmask+1] out
-    uint32_t* n_cells;           // out: occupied voxel count
+    M3dBucket* htab;             // [hcap] out (hcap = worst-case allocation; the used size is derived on the device)
+    uint32_t hcap;
+    uint32_t* bigcum;            // [bigcap][8] out: 32-bit cumulative populations of buckets with > 65535 points
+    uint32_t bigcap;
+    uint32_t* n_cells;           // [8] out: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
 };
 
 float m3d_unord_f32(uint32_t u);
@@ -26,14 +27,19 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int 
                                   float* z, uint32_t* aabb);
 hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a);
 // mom: workspace of 10 * n_valid int64 (per-voxel moments, indexed by the voxel's first sorted position)
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
+// dyn: the level's device-side {occupied voxels, hmask, hshift} (the host copy is not known yet at this point)
+hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* dyn, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
                               float min_spread, float4* nrm_in, int n);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // icp.hip
-// e0/e1 (optional): events recorded immediately before / after the k_icp_accumulate launch
+// variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
+//          2 = split: k_nn_search (one int32 match per query into `match`) + k_accumulate_matches (default)
+// match: workspace of n_pairs * match_stride int32 (variant 2)
+// e0/e1 (optional): events recorded immediately before / after the launch(es) of the linearisation
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    hipEvent_t e0, hipEvent_t e1);
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric);
+                                    int variant, int* match, int match_stride, hipEvent_t e0, hipEvent_t e1);
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant, int* match,
+                                      int match_stride);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,12 +24,15 @@ struct DevLevel {
     float mx[3]{};
     float lbound = 0.f;
     float4* pts = nullptr;
-    float4* nrm = nullptr;
-    uint2* htab = nullptr;
+    M3dBucket* htab = nullptr;
+    uint32_t* bigcum = nullptr;
+    uint32_t bigcap = 0;
+    uint32_t hcap = 0;             // allocated entries (worst case); the used size lives in n_cells[1..2]
+    uint32_t n_cells_host = 0;
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
     uint32_t* perm = nullptr;
-    uint32_t* n_cells = nullptr;   // device counter
+    uint32_t* n_cells = nullptr;   // device: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
 };
 
 }  // namespace
@@ -40,6 +44,7 @@ struct m3dreg_cloud {
     float leaf[M3DREG_MAX_LEVELS]{};
     bool has_normals = false;
     float *x = nullptr, *y = nullptr, *z = nullptr;
+    float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
     std::vector<void*> allocs;
@@ -67,6 +72,10 @@ struct m3dreg_handle {
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
+    int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
+    int* d_match = nullptr;            // [match_pairs * match_stride] NN result per query (variant 2)
+    size_t match_cap = 0;
+    int match_stride = 0;
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -125,7 +134,9 @@ int make_grid(const float mn[3], const float mx[3], float leaf, int32_t n, int32
         float fc = cell_f(mx[a], mn[a], g.inv_leaf);
         if (!(fc < 1073741824.0f)) return M3DREG_ERR_GRID_TOO_LARGE;
         g.dims[a] = int32_t(fc) + 1;
-        L.bits[a] = bits_for(g.dims[a]);
+        L.bits[a] = bits_for((g.dims[a] + 1) >> 1);   // bit width of the BUCKET coordinate
+        if (L.bits[a] > 11) return M3DREG_ERR_GRID_TOO_LARGE;
+        g.cb[a] = L.bits[a];
         total_bits += L.bits[a];
         float ext = mx[a] - mn[a];
         float half = ext * 0.5f;
@@ -134,16 +145,15 @@ int make_grid(const float mn[3], const float mx[3], float leaf, int32_t n, int32
         amax = std::fmax(amax, std::fmax(std::fabs(mn[a]), std::fabs(mx[a])));
         ext_max = std::fmax(ext_max, ext);
     }
-    if (total_bits > 31) return M3DREG_ERR_GRID_TOO_LARGE;
-    g.sy = L.bits[0];
-    g.sz = L.bits[0] + L.bits[1];
+    if (total_bits + 3 > 31) return M3DREG_ERR_GRID_TOO_LARGE;
     L.lbound = half_max + 3.0f * leaf;
-    // hash table: power of two >= 2n (load <= 0.5 even if every point sits in its own voxel)
+    // hash table: worst-case allocation is a power of two >= 2n; the used size (power of two >= 2 * occupied
+    // voxels) is derived on the device after the sort and read back once at the end of cloud_create
     uint32_t hs = 16;
-    int hb = 4;
-    while (hs < 2u * uint32_t(n)) { hs <<= 1; hb++; }
-    g.hmask = hs - 1;
-    g.hshift = 32 - hb;
+    while (hs < 2u * uint32_t(n)) hs <<= 1;
+    L.hcap = hs;
+    g.hmask = 0;
+    g.hshift = 0;
     // pruning slack (not part of the results: only makes the box test conservative)
     g.prune_slack = 1.0e-6f * (amax + ext_max) + 1.0e-3f * leaf;
     return M3DREG_OK;
@@ -194,31 +204,34 @@ void free_cloud(m3dreg_cloud* c) {
 
 int sort_passes_for(const DevLevel& L, bool has_invalid) {
     if (has_invalid) return 4;  // the 0xFFFFFFFF keys of non-finite points must end up last
-    int bits = L.bits[0] + L.bits[1] + L.bits[2];
+    int bits = L.bits[0] + L.bits[1] + L.bits[2] + 3;
     return (bits + 7) / 8;
 }
 
 // bucket one level of `c` (geometry from the cloud's AABB)
-int bucket_level(m3dreg_handle* h, m3dreg_cloud* c, DevLevel& L, float leaf, bool want_normals_out, const float4* nrm_in) {
+int bucket_level(m3dreg_handle* h, m3dreg_cloud* c, DevLevel& L, float leaf) {
     int rc = make_grid(c->mn, c->mx, leaf, c->n, c->n_valid, L);
     if (rc) return fail(h, rc, "voxel grid needs more than 31 key bits (coarsen leaf or crop the cloud)");
     const size_t n = size_t(c->n);
-    if ((rc = dmalloc(h, c, &L.pts, n)) || (rc = dmalloc(h, c, &L.htab, size_t(L.grid.hmask) + 1)) || (rc = dmalloc(h, c, &L.keys, n)) ||
-        (rc = dmalloc(h, c, &L.skey, n)) || (rc = dmalloc(h, c, &L.perm, n)) || (rc = dmalloc(h, c, &L.n_cells, 1)))
+    if ((rc = dmalloc(h, c, &L.pts, n)) || (rc = dmalloc(h, c, &L.htab, size_t(L.hcap))) || (rc = dmalloc(h, c, &L.keys, n)) ||
+        (rc = dmalloc(h, c, &L.skey, n)) || (rc = dmalloc(h, c, &L.perm, n)) || (rc = dmalloc(h, c, &L.n_cells, 8)))
         return rc;
-    if (want_normals_out && (rc = dmalloc(h, c, &L.nrm, n))) return rc;
+    L.bigcap = uint32_t(n / 65536 + 1);
+    if ((rc = dmalloc(h, c, &L.bigcum, size_t(L.bigcap) * 8))) return rc;
+    HIPCHK(h, hipMemsetAsync(L.bigcum, 0, sizeof(uint32_t) * 8 * size_t(L.bigcap), h->stream));
     M3dBucketArgs a{};
     a.n = c->n; a.x = c->x; a.y = c->y; a.z = c->z; a.grid = L.grid;
     a.sort_passes = sort_passes_for(L, c->n_valid != c->n);
     a.keys = L.keys; a.ka = h->ka; a.va = h->va; a.kb = h->kb; a.vb = h->vb; a.hist = h->hist;
-    a.skey_out = L.skey; a.perm_out = L.perm; a.nrm_in = nrm_in; a.pts = L.pts; a.nrm = L.nrm; a.htab = L.htab; a.n_cells = L.n_cells;
+    a.skey_out = L.skey; a.perm_out = L.perm; a.pts = L.pts; a.htab = L.htab; a.hcap = L.hcap; a.bigcum = L.bigcum; a.bigcap = L.bigcap;
+    a.n_cells = L.n_cells;
     HIPCHK(h, m3d_launch_bucket_level(h->stream, a));
     return M3DREG_OK;
 }
 
-M3dLevelDev level_dev(const DevLevel& L) {
+M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
     M3dLevelDev d{};
-    d.pts = L.pts; d.nrm = L.nrm; d.htab = L.htab; d.g = L.grid;
+    d.pts = L.pts; d.nrm = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.g = L.grid;
     return d;
 }
 
@@ -250,6 +263,20 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
     return M3DREG_OK;
 }
 
+int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
+    const size_t stride = (size_t(max_n_src) + 63) & ~size_t(63);
+    if (n_pairs * stride > h->match_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_match) hipFree(h->d_match);
+        h->d_match = nullptr; h->match_cap = 0;
+        const size_t cap = n_pairs * stride + n_pairs * stride / 4;
+        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * cap));
+        h->match_cap = cap;
+    }
+    h->match_stride = int(stride);
+    return M3DREG_OK;
+}
+
 int validate_params(const m3dreg_params* p) {
     if (!p || p->n_levels < 1 || p->n_levels > M3DREG_MAX_LEVELS) return M3DREG_ERR_INVALID_ARG;
     for (int l = 0; l < p->n_levels; l++)
@@ -272,12 +299,12 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         int rc = check_levels(h, t);
         if (rc) return rc;
         if (P.metric == M3DREG_POINT_TO_PLANE && !t->has_normals) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "target cloud has no normals");
-        if (s->n > max_n_src) max_n_src = s->n;
+        if (s->n_valid > max_n_src) max_n_src = s->n_valid;
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
-            J.sx = s->x; J.sy = s->y; J.sz = s->z; J.n_src = s->n; J.metric = P.metric;
-            J.tgt = level_dev(t->lv[l]);
+            J.src = s->lv[s->n_levels - 1].pts; J.n_src = s->n_valid; J.metric = P.metric;
+            J.tgt = level_dev(t->lv[l], t->nrm_in);
             J.dmax2 = P.max_corr_dist[l] * P.max_corr_dist[l];
             fixed_exps(t->lv[l].lbound, P.max_corr_dist[l], J.exps);
             for (int k = 0; k < 6; k++) J.S[k] = std::ldexp(1.0f, J.exps[k]);
@@ -356,6 +383,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
+    if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return M3DREG_ERR_HIP; }
@@ -371,7 +399,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     hipStreamSynchronize(h->stream);
     free_cloud(h->target);
     for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->mom, (void*)h->aabb, (void*)h->d_jobs, (void*)h->d_states,
-                     (void*)h->d_trace })
+                     (void*)h->d_trace, (void*)h->d_match })
         if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
@@ -448,16 +476,24 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
     if (c->n_valid == 0) { free_cloud(c); return fail(h, M3DREG_ERR_EMPTY_CLOUD, "cloud has no finite point"); }
     for (int a = 0; a < 3; a++) { c->mn[a] = m3d_unord_f32(ab[a]); c->mx[a] = m3d_unord_f32(ab[3 + a]); }
     // a9: normals on the dedicated normal grid (point-to-plane only), kept in input order
-    float4* nrm_in = nullptr;
     if (P.metric == M3DREG_POINT_TO_PLANE) {
         DevLevel NG;
-        CLOUD_TRY(bucket_level(h, c, NG, P.normal_leaf, false, nullptr));
-        CLOUD_TRY(dmalloc(h, c, &nrm_in, n));
-        CLOUD_HIP(m3d_launch_normals(h->stream, level_dev(NG), NG.skey, h->mom, P.plane_ratio, P.normal_min_pts, P.normal_min_spread, nrm_in, int(n)));
+        CLOUD_TRY(bucket_level(h, c, NG, P.normal_leaf));
+        CLOUD_TRY(dmalloc(h, c, &c->nrm_in, n));
+        float4* nrm_in = c->nrm_in;
+        CLOUD_HIP(m3d_launch_normals(h->stream, level_dev(NG, nullptr), NG.n_cells, NG.skey, h->mom, P.plane_ratio, P.normal_min_pts, P.normal_min_spread, nrm_in, int(n)));
         c->has_normals = true;
     }
-    for (int l = 0; l < P.n_levels; l++) CLOUD_TRY(bucket_level(h, c, c->lv[l], P.leaf[l], c->has_normals, nrm_in));
+    for (int l = 0; l < P.n_levels; l++) CLOUD_TRY(bucket_level(h, c, c->lv[l], P.leaf[l]));
+    // read back the device-derived table geometry of every level (the kernels so far took it from device memory)
+    uint32_t dyn[M3DREG_MAX_LEVELS][8];
+    for (int l = 0; l < P.n_levels; l++) CLOUD_HIP(hipMemcpyAsync(dyn[l], c->lv[l].n_cells, sizeof(dyn[l]), hipMemcpyDeviceToHost, h->stream));
     CLOUD_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < P.n_levels; l++) {
+        c->lv[l].n_cells_host = dyn[l][0];
+        c->lv[l].grid.hmask = dyn[l][1];
+        c->lv[l].grid.hshift = int32_t(dyn[l][2]);
+    }
 #undef CLOUD_TRY
 #undef CLOUD_HIP
     *out = c;
@@ -480,6 +516,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     int max_n_src = 0;
     if ((rc = build_jobs(h, pairs, n_pairs, max_n_src))) return rc;
     const m3dreg_params& P = h->params;
+    if ((rc = ensure_match(h, n_pairs, max_n_src))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * size_t(P.n_levels), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));
     for (int l = 0; l < P.n_levels; l++) {
@@ -487,7 +524,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
         for (int it = 0; it < P.iterations[l]; it++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->profiling) { e0 = next_event(h); e1 = next_event(h); }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, e0, e1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, h->d_match, h->match_stride, e0, e1));
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
@@ -573,10 +610,7 @@ int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m
     const DevLevel& L = c->lv[level];
     memset(out, 0, sizeof(*out));
     out->n = c->n; out->n_valid = c->n_valid;
-    uint32_t nc = 0;
-    HIPCHK(h, hipMemcpyAsync(&nc, L.n_cells, sizeof(nc), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    out->n_cells = int32_t(nc);
+    out->n_cells = int32_t(L.n_cells_host);
     for (int a = 0; a < 3; a++) {
         out->dims[a] = L.grid.dims[a]; out->bits[a] = L.bits[a]; out->mn[a] = L.grid.mn[a]; out->mx[a] = L.mx[a]; out->center[a] = L.grid.center[a];
     }
@@ -598,7 +632,7 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
     if (sorted_xyz || normals) {
         HIPCHK(h, hipMalloc((void**)&dx, 12 * n));
         if (normals) { hipError_t e = hipMalloc((void**)&dn, 12 * n); if (e != hipSuccess) { hipFree(dx); return fail(h, M3DREG_ERR_HIP, "hipMalloc", e); } }
-        hipError_t e = m3d_launch_export_sorted(h->stream, L.pts, normals ? L.nrm : nullptr, int(n), dx, dn);
+        hipError_t e = m3d_launch_export_sorted(h->stream, L.pts, normals ? c->nrm_in : nullptr, int(n), dx, dn);
         if (e == hipSuccess && sorted_xyz) e = hipMemcpyAsync(sorted_xyz, dx, 12 * n, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && normals) e = hipMemcpyAsync(normals, dn, 12 * n, hipMemcpyDeviceToHost, h->stream);
         hipError_t e2 = hipStreamSynchronize(h->stream);
@@ -620,7 +654,7 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
     hipError_t e = hipMalloc((void**)&di, 4 * nq);
     if (e == hipSuccess) e = hipMalloc((void**)&dd, 4 * nq);
     if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = m3d_launch_debug_nn(h->stream, level_dev(target->lv[level]), dq, int(nq), max_corr_dist * max_corr_dist, di, dd);
+    if (e == hipSuccess) e = m3d_launch_debug_nn(h->stream, level_dev(target->lv[level], target->nrm_in), dq, int(nq), max_corr_dist * max_corr_dist, di, dd);
     if (e == hipSuccess) e = hipMemcpyAsync(out_idx, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_d2, dd, 4 * nq, hipMemcpyDeviceToHost, h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
@@ -642,10 +676,11 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     memcpy(p.init_T, T, sizeof(float) * 16);
     int max_n_src = 0;
     if ((rc = build_jobs(h, &p, 1, max_n_src))) return rc;
+    if ((rc = ensure_match(h, 1, max_n_src))) return rc;
     const M3dJob* hj = &h->h_jobs[size_t(level) * h->cap_pairs];
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, hj, sizeof(M3dJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric));
+    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, h->icp_variant, h->d_match, h->match_stride));
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const long long* raw = h->h_states[0].sums;
@@ -663,6 +698,12 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
         sums[27] = raw[15]; sums[28] = raw[16];
     }
     for (int i = 0; i < 6; i++) exps[i] = hj->exps[i];
+    return M3DREG_OK;
+}
+
+int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]) {
+    if (!h || !out || !h->h_states) return M3DREG_ERR_INVALID_ARG;
+    out[0] = h->h_states[0].ctr[0]; out[1] = h->h_states[0].ctr[1];
     return M3DREG_OK;
 }
 

@@ -107,6 +107,21 @@ static int ceil_log2_d(double x) {
     return (m == 0.5) ? ex - 1 : ex;
 }
 
+/* Spec §Grid: voxel sort key. Voxels are grouped into 2x2x2 buckets: bucket coords c = i >> 1, the
+ * buckets are ordered by a compact Morton code (bits of cx, cy, cz interleaved from the LSB up, an axis
+ * drops out once its bit width cb[a] is exhausted) and the 8 voxels of a bucket by
+ * sub = (ix&1) | (iy&1)<<1 | (iz&1)<<2:   key = morton(cx,cy,cz) << 3 | sub.
+ * The key is a bijection of the voxel coordinates, so a run of equal keys is one voxel, every bucket is
+ * one contiguous run of up to 8 voxel runs, and the sorted cloud follows a space-filling curve. */
+static uint32_t voxel_key(const int32_t cb[3], int32_t ix, int32_t iy, int32_t iz) {
+    const uint32_t c[3] = { (uint32_t)ix >> 1, (uint32_t)iy >> 1, (uint32_t)iz >> 1 };
+    uint32_t code = 0; int pos = 0;
+    for (int b = 0; b < 11; b++)
+        for (int a = 0; a < 3; a++)
+            if (b < cb[a]) { code |= ((c[a] >> b) & 1u) << pos; pos++; }
+    return (code << 3) | ((uint32_t)ix & 1u) | (((uint32_t)iy & 1u) << 1) | (((uint32_t)iz & 1u) << 2);
+}
+
 /* Spec §Grid: cell coordinate of a coordinate value along one axis (un-fused sub, mul, floor). */
 static float cell_f(float v, float mn, float inv_leaf) {
     float d = v - mn;
@@ -169,28 +184,28 @@ static int level_build(orc_level* L, const float* xyz, int32_t n, float leaf) {
         float fc = cell_f(g->mx[a], g->mn[a], g->inv_leaf);
         if (!(fc < 1073741824.0f)) return ORC_ERR_GRID_TOO_LARGE;
         g->dims[a] = (int32_t)fc + 1;
-        g->bits[a] = bits_for(g->dims[a]);
+        g->bits[a] = bits_for((g->dims[a] + 1) >> 1);   /* bit width of the BUCKET coordinate */
+        if (g->bits[a] > 11) return ORC_ERR_GRID_TOO_LARGE;
         total_bits += g->bits[a];
         float ext = g->mx[a] - g->mn[a];
         float half = ext * 0.5f;
         g->center[a] = g->mn[a] + half;
         if (half > half_max) half_max = half;
     }
-    if (total_bits > 31) return ORC_ERR_GRID_TOO_LARGE;
+    if (total_bits + 3 > 31) return ORC_ERR_GRID_TOO_LARGE;
     g->lbound = half_max + 3.0f * leaf;
 
     L->key = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
     L->skey = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
     L->perm = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
     L->sxyz = (float*)malloc(sizeof(float) * 3 * (size_t)n);
-    const int sy = g->bits[0], sz = g->bits[0] + g->bits[1];
     for (int32_t i = 0; i < n; i++) {
         const float* p = &xyz[3 * i];
         if (!finite3(p[0], p[1], p[2])) { L->key[i] = ORC_INVALID_KEY; continue; }
-        uint32_t ix = (uint32_t)(int32_t)cell_f(p[0], g->mn[0], g->inv_leaf);
-        uint32_t iy = (uint32_t)(int32_t)cell_f(p[1], g->mn[1], g->inv_leaf);
-        uint32_t iz = (uint32_t)(int32_t)cell_f(p[2], g->mn[2], g->inv_leaf);
-        L->key[i] = ix | (iy << sy) | (iz << sz);
+        int32_t ix = (int32_t)cell_f(p[0], g->mn[0], g->inv_leaf);
+        int32_t iy = (int32_t)cell_f(p[1], g->mn[1], g->inv_leaf);
+        int32_t iz = (int32_t)cell_f(p[2], g->mn[2], g->inv_leaf);
+        L->key[i] = voxel_key(g->bits, ix, iy, iz);
     }
     /* stable LSD radix sort (4 x 8 bit) of (key, index): the spec only says "stable sort by key" */
     {
@@ -242,12 +257,11 @@ static int32_t nn27(const orc_level* L, float ux, float uy, float uz, float dmax
         if (!(fc[a] >= -1.0f && fc[a] <= (float)g->dims[a])) return -1;
         ic[a] = (int32_t)fc[a];
     }
-    const int sy = g->bits[0], sz = g->bits[0] + g->bits[1];
     int32_t best = -1; float bd = 0.0f; int32_t bidx = 0;
     for (int dz = -1; dz <= 1; dz++) { int32_t cz = ic[2] + dz; if (cz < 0 || cz >= g->dims[2]) continue;
     for (int dy = -1; dy <= 1; dy++) { int32_t cy = ic[1] + dy; if (cy < 0 || cy >= g->dims[1]) continue;
     for (int dx = -1; dx <= 1; dx++) { int32_t cx = ic[0] + dx; if (cx < 0 || cx >= g->dims[0]) continue;
-        uint32_t key = (uint32_t)cx | ((uint32_t)cy << sy) | ((uint32_t)cz << sz);
+        uint32_t key = voxel_key(g->bits, cx, cy, cz);
         int32_t c = find_cell(L, key);
         if (c < 0) continue;
         for (int32_t j = L->cell_start[c]; j < L->cell_start[c + 1]; j++) {
@@ -302,21 +316,19 @@ static void grid_normals(const orc_level* L, float plane_ratio, int32_t min_pts,
      * gives the same integers. Units of the covariance below: (leaf/65536)^2. */
     const double spread_q = (double)min_spread * 65536.0;
     const double l2_min_abs = spread_q * spread_q;
-    const int sy = g->bits[0], sz = g->bits[0] + g->bits[1];
-    const uint32_t mx = (1u << g->bits[0]) - 1u, my = (1u << g->bits[1]) - 1u;
     /* every iteration writes only out[3*perm[j]..]: independent, so the OpenMP split changes nothing */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 256)
 #endif
     for (int32_t j = 0; j < nv; j++) {
-        uint32_t key = L->skey[j];
-        int32_t ic[3] = { (int32_t)(key & mx), (int32_t)((key >> sy) & my), (int32_t)(key >> sz) };
+        int32_t ic[3];
+        for (int a = 0; a < 3; a++) ic[a] = (int32_t)cell_f(L->sxyz[3 * j + a], g->mn[a], g->inv_leaf);
         int64_t s[3] = { 0, 0, 0 }, q[6] = { 0, 0, 0, 0, 0, 0 };
         int64_t k = 0;
         for (int dz = -1; dz <= 1; dz++) { int32_t cz = ic[2] + dz; if (cz < 0 || cz >= g->dims[2]) continue;
         for (int dy = -1; dy <= 1; dy++) { int32_t cy = ic[1] + dy; if (cy < 0 || cy >= g->dims[1]) continue;
         for (int dx = -1; dx <= 1; dx++) { int32_t cx = ic[0] + dx; if (cx < 0 || cx >= g->dims[0]) continue;
-            uint32_t ck = (uint32_t)cx | ((uint32_t)cy << sy) | ((uint32_t)cz << sz);
+            uint32_t ck = voxel_key(g->bits, cx, cy, cz);
             int32_t c = find_cell(L, ck);
             if (c < 0) continue;
             const int dd[3] = { dx, dy, dz };

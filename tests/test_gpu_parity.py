@@ -186,3 +186,25 @@ def test_full_size_properties_config3(reg):
     # run-to-run determinism
     T4, _ = R.align(cs, ct)
     assert np.array_equal(T4, T)
+
+
+def test_kernel_variants_are_bit_identical(reg, orc, monkeypatch):
+    """variant 0 (per-thread global walk) and variant 1 (wave-cooperative LDS-staged buckets) must agree
+    with each other and with the oracle on every bit, including chunks that overflow the LDS budget."""
+    src, tgt, Tgt = synth.hdl32_pair(900, 300, 301, dx=0.3, dy=-0.2, dyaw_deg=25.0)   # big yaw: many fallback chunks
+    p = _params(leaf=0.1, iterations=6, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    T0 = synth.perturb(Tgt, np.random.default_rng(5), 1.0, 0.1)
+    out = []
+    for variant in ("0", "1", "2"):
+        monkeypatch.setenv("M3DREG_ICP_VARIANT", variant)
+        R = reg.Registrar(p)
+        cs, ct = R.cloud(src), R.cloud(tgt)
+        s, e = R.accumulate(cs, ct, T0)
+        T, st = R.align(cs, ct, T0)
+        out.append((s, e, T, R.trace(), st))
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1])
+        assert np.array_equal(out[0][3], o[3]) and np.array_equal(out[0][2], o[2])
+    To, sto, tro = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=16)
+    assert np.array_equal(out[1][3], tro) and np.array_equal(out[1][2], To)
+    _same_stats(out[1][4], sto)

@@ -30,10 +30,21 @@ def test_voxel_keys_match_numpy_restatement(orc):
     ijk = np.floor((xyz[ok] - mn) * inv).astype(np.int64)  # float32 sub, float32 mul, floor
     dims = np.floor((mx - mn) * inv).astype(np.int64) + 1
     assert list(g.dims) == list(dims)
-    bits = [max(1, int(np.ceil(np.log2(d)))) for d in dims]
+    cdims = (dims + 1) // 2
+    bits = [max(1, int(np.ceil(np.log2(d)))) for d in cdims]     # bucket-coordinate bit widths
     assert list(g.bits) == bits
-    key = ijk[:, 0] | (ijk[:, 1] << bits[0]) | (ijk[:, 2] << (bits[0] + bits[1]))
+    # key = compact Morton code of the 2x2x2-bucket coordinates << 3 | position inside the bucket
+    c = ijk >> 1
+    code = np.zeros(len(ijk), np.int64)
+    pos = 0
+    for b in range(11):
+        for a in range(3):
+            if b < bits[a]:
+                code |= ((c[:, a] >> b) & 1) << pos
+                pos += 1
+    key = (code << 3) | (ijk[:, 0] & 1) | ((ijk[:, 1] & 1) << 1) | ((ijk[:, 2] & 1) << 2)
     assert np.array_equal(e["keys"][ok], key.astype(np.uint32))
+    assert len(np.unique(key)) == len(np.unique(ijk, axis=0))          # bijective on voxels
     assert (e["keys"][~ok] == 0xFFFFFFFF).all()
     # stable sort
     perm = np.argsort(e["keys"], kind="stable")
