@@ -84,9 +84,11 @@ def main():
     last = {}
 
     def step():
-        clouds = []
+        items = []
         for ds, ns, dt, nt in payloads:
-            clouds.append((reg.cloud_from_device(ds.data_ptr(), ns), reg.cloud_from_device(dt.data_ptr(), nt)))
+            items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
+        cl = reg.clouds_from_device(items)          # all 2B clouds bucketed by one batched pipeline
+        clouds = [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
         T, st = reg.align_batch([(s, t, None) for s, t in clouds])
         if world > 1:
             pose_buf.copy_(torch.from_numpy(np.ascontiguousarray(T.reshape(B, 16), np.float32)))

@@ -129,6 +129,14 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
 int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step,
                         size_t off_x, size_t off_y, size_t off_z, int data_is_device,
                         m3dreg_cloud** out);
+/* Buckets many clouds at once: one decode launch and one bucketing pipeline serve the whole batch
+ * (a single 100k-point cloud cannot fill 256 CUs), with two host synchronisations per BATCH. */
+typedef struct m3dreg_cloud_desc {
+    const void* data;     /* PointCloud2 payload (host, or device when data_is_device != 0) */
+    size_t n, point_step, off_x, off_y, off_z;
+    int32_t data_is_device;
+} m3dreg_cloud_desc;
+int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c);
 int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
                         const float init_T[16], float out_T[16], m3dreg_stats* stats);

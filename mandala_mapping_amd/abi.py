@@ -114,6 +114,11 @@ class GridInfo(C.Structure):
                 for k, _ in self._fields_}
 
 
+class CloudDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("point_step", C.c_size_t), ("off_x", C.c_size_t), ("off_y", C.c_size_t),
+                ("off_z", C.c_size_t), ("data_is_device", C.c_int32)]
+
+
 class Pair(C.Structure):
     _fields_ = [("source", C.c_void_p), ("target", C.c_void_p), ("init_T", C.c_float * 16)]
 

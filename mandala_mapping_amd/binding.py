@@ -26,7 +26,7 @@ EXPORTS = [
     "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
-    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters",
+    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
 ]
 
 
@@ -55,6 +55,7 @@ def lib():
     L.m3dreg_set_target_xyz.argtypes = [vp, vp, sz, sz, sz, sz, sz]
     L.m3dreg_align.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_cloud_create.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
+    L.m3dreg_cloud_create_batch.argtypes = [vp, C.POINTER(abi.CloudDesc), sz, C.POINTER(vp)]
     L.m3dreg_cloud_destroy.argtypes = [vp, vp]
     L.m3dreg_align_clouds.argtypes = [vp, vp, vp, f32p, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_align_batch.argtypes = [vp, C.POINTER(abi.Pair), sz, f32p, C.POINTER(abi.Stats)]
@@ -198,6 +199,33 @@ class Registrar:
         p = C.c_void_p()
         self._check(lib().m3dreg_cloud_create(self._h, C.c_void_p(dev_ptr), n, point_step, offsets[0], offsets[1], offsets[2], 1, C.byref(p)), "cloud_create(device)")
         return Cloud(self, p, n)
+
+    def clouds_from_device(self, items):
+        """items: list of (device address, n[, point_step, (ox, oy, oz)]) -> list of Clouds, bucketed in ONE batch."""
+        k = len(items)
+        descs = (abi.CloudDesc * k)()
+        for i, it in enumerate(items):
+            step = it[2] if len(it) > 2 else 16
+            off = it[3] if len(it) > 3 else (0, 4, 8)
+            descs[i].data, descs[i].n, descs[i].point_step = it[0], it[1], step
+            descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = off[0], off[1], off[2], 1
+        out = (C.c_void_p * k)()
+        self._check(lib().m3dreg_cloud_create_batch(self._h, descs, k, out), "cloud_create_batch")
+        return [Cloud(self, C.c_void_p(out[i]), items[i][1]) for i in range(k)]
+
+    def clouds(self, arrays):
+        """arrays: list of float32 [n,3] arrays / PointCloud2 messages -> list of Clouds, bucketed in ONE batch."""
+        msgs = [to_little_endian(encode_xyz(a) if isinstance(a, np.ndarray) else a) for a in arrays]
+        k = len(msgs)
+        bufs = [(C.c_char * len(m.data)).from_buffer_copy(m.data) for m in msgs]
+        descs = (abi.CloudDesc * k)()
+        for i, m in enumerate(msgs):
+            ox, oy, oz = m.xyz_offsets()
+            descs[i].data, descs[i].n, descs[i].point_step = C.addressof(bufs[i]), m.n, m.point_step
+            descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = ox, oy, oz, 0
+        out = (C.c_void_p * k)()
+        self._check(lib().m3dreg_cloud_create_batch(self._h, descs, k, out), "cloud_create_batch")
+        return [Cloud(self, C.c_void_p(out[i]), msgs[i].n) for i in range(k)]
 
     # ---- registration -------------------------------------------------------------------------
     def align(self, source: Cloud, target: Cloud, init_T=None):

@@ -4,8 +4,11 @@
 // /root/reference/m3d/m3d_calibration/src/m3d_calibration_twiddle.cpp:279-286. The normative
 // arithmetic is DESIGN.md §Spec; oracle/m3d_oracle.c restates it on the CPU.
 //
-// All of this is HBM-bound integer/byte work: coalesced 4-B/16-B streams, LDS histograms and
-// wave64 ballots for the stable in-block ranks; no MFMA (nothing here is a contraction).
+// Everything is BATCHED: one launch serves every cloud / every grid of a batch (blockIdx.y selects the
+// descriptor), because a single 100k-point cloud cannot fill 256 CUs and ~50 tiny launches per cloud
+// were costing more than the work itself (profiles/r01_v4_*). All of this is HBM-bound integer/byte
+// work: coalesced 4-B/16-B streams, LDS histograms and wave64 ballots for the stable in-block ranks;
+// no MFMA (nothing here is a contraction).
 #include "m3d_kernels.h"
 
 #define RS_THREADS 256
@@ -24,31 +27,31 @@ __host__ __device__ inline float unord_f32(uint32_t u) {
 }
 float m3d_unord_f32(uint32_t u) { return unord_f32(u); }
 
-// aabb[0..2] = ordered min, aabb[3..5] = ordered max, aabb[6] = n_valid
-__global__ __launch_bounds__(256) void k_decode_aabb(const uint8_t* __restrict__ raw, int n, int step, int ox, int oy, int oz,
-                                                     float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
-                                                     uint32_t* __restrict__ aabb) {
-    uint32_t mn[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, mx[3] = { 0u, 0u, 0u };
+// aabb (zero-initialised): [0..2] = max of ~ordered (i.e. the minimum), [3..5] = max of ordered, [6] = finite points
+__global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict__ descs) {
+    const M3dDecode D = descs[blockIdx.y];
+    const int n = D.n;
+    uint32_t mn[3] = { 0u, 0u, 0u }, mx[3] = { 0u, 0u, 0u };
     uint32_t cnt = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint8_t* p = raw + (size_t)i * step;
-        float px = *reinterpret_cast<const float*>(p + ox);
-        float py = *reinterpret_cast<const float*>(p + oy);
-        float pz = *reinterpret_cast<const float*>(p + oz);
-        x[i] = px; y[i] = py; z[i] = pz;
+        const uint8_t* p = D.raw + (size_t)i * D.step;
+        const float px = *reinterpret_cast<const float*>(p + D.ox);
+        const float py = *reinterpret_cast<const float*>(p + D.oy);
+        const float pz = *reinterpret_cast<const float*>(p + D.oz);
+        D.x[i] = px; D.y[i] = py; D.z[i] = pz;
         if (m3d_finite3(px, py, pz)) {
-            uint32_t a = ord_f32(px), b = ord_f32(py), c = ord_f32(pz);
-            mn[0] = min(mn[0], a); mx[0] = max(mx[0], a);
-            mn[1] = min(mn[1], b); mx[1] = max(mx[1], b);
-            mn[2] = min(mn[2], c); mx[2] = max(mx[2], c);
+            const uint32_t a = ord_f32(px), b = ord_f32(py), c = ord_f32(pz);
+            mn[0] = max(mn[0], ~a); mx[0] = max(mx[0], a);
+            mn[1] = max(mn[1], ~b); mx[1] = max(mx[1], b);
+            mn[2] = max(mn[2], ~c); mx[2] = max(mx[2], c);
             cnt++;
         }
     }
     // wave64 shuffle reduction -> LDS across the 4 waves -> one set of integer atomics per block
-    // (exact and order-independent; per-wave atomics made this kernel contention-bound: 128 us -> see profiles/)
+    // (exact and order-independent; per-wave atomics made this kernel contention-bound: 128 us vs 9 us)
     for (int o = 32; o > 0; o >>= 1) {
         for (int a = 0; a < 3; a++) {
-            mn[a] = min(mn[a], (uint32_t)__shfl_down((int)mn[a], o));
+            mn[a] = max(mn[a], (uint32_t)__shfl_down((int)mn[a], o));
             mx[a] = max(mx[a], (uint32_t)__shfl_down((int)mx[a], o));
         }
         cnt += __shfl_down((int)cnt, o);
@@ -60,47 +63,63 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const uint8_t* __restrict__
     if (threadIdx.x < 7) {
         const int a = threadIdx.x;
         uint32_t v = red[0][a];
-        for (int w = 1; w < 4; w++) v = (a < 3) ? min(v, red[w][a]) : (a < 6 ? max(v, red[w][a]) : v + red[w][a]);
-        if (a < 3) atomicMin(&aabb[a], v); else if (a < 6) atomicMax(&aabb[a], v); else if (v) atomicAdd(&aabb[6], v);
+        for (int w = 1; w < 4; w++) v = (a < 6) ? max(v, red[w][a]) : v + red[w][a];
+        if (a < 6) { if (v) atomicMax(&D.aabb[a], v); } else if (v) atomicAdd(&D.aabb[6], v);
     }
 }
 
 // ---- a3: voxel key per point ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_voxel_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                    int n, M3dGrid g, uint32_t* __restrict__ keys, uint32_t* __restrict__ skey,
-                                                    uint32_t* __restrict__ sval) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float px = x[i], py = y[i], pz = z[i];
+__global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    const float px = B.x[i], py = B.y[i], pz = B.z[i];
     uint32_t key = M3D_INVALID_KEY;
     if (m3d_finite3(px, py, pz)) {
-        const int ix = (int)m3d_cell_f(px, g.mn[0], g.inv_leaf);
-        const int iy = (int)m3d_cell_f(py, g.mn[1], g.inv_leaf);
-        const int iz = (int)m3d_cell_f(pz, g.mn[2], g.inv_leaf);
-        key = m3d_voxel_key(g.cb, ix, iy, iz);
+        const int ix = (int)m3d_cell_f(px, B.grid.mn[0], B.grid.inv_leaf);
+        const int iy = (int)m3d_cell_f(py, B.grid.mn[1], B.grid.inv_leaf);
+        const int iz = (int)m3d_cell_f(pz, B.grid.mn[2], B.grid.inv_leaf);
+        key = m3d_voxel_key(B.grid.cb, ix, iy, iz);
     }
-    keys[i] = key; skey[i] = key; sval[i] = (uint32_t)i;
+    B.keys[i] = key; B.ka[i] = key; B.va[i] = (uint32_t)i;
 }
 
 // ---- a4: stable LSD radix sort, 8-bit digits ------------------------------------------------------
-// pass = histogram per tile -> exclusive scan over [digit][tile] -> stable scatter
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
-                                                        uint32_t* __restrict__ hist, int ntiles) {
+// pass = histogram per tile -> exclusive scan over [digit][tile] -> stable scatter. A build whose keys
+// need fewer passes simply skips the later ones (its result then sits in the buffer of its own parity).
+__device__ __forceinline__ void sort_buffers(const M3dBuild& B, int pass, const uint32_t*& kin, const uint32_t*& vin, uint32_t*& kout,
+                                             uint32_t*& vout) {
+    if (pass & 1) { kin = B.kb; vin = B.vb; kout = B.ka; vout = B.va; }
+    else { kin = B.ka; vin = B.va; kout = B.kb; vout = B.vb; }
+}
+__device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return (B.sort_passes & 1) ? B.kb : B.ka; }
+__device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { return (B.sort_passes & 1) ? B.vb : B.va; }
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
+    const uint32_t *kin, *vin; uint32_t *kout, *vout;
+    sort_buffers(B, pass, kin, vin, kout, vout);
+    const int n = B.n, shift = 8 * pass;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE;
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
-        int i = base + r * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        const int i = base + r * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(kin[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    B.hist[threadIdx.x * B.ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// single-workgroup exclusive scan of `total` counters (total = 256 * ntiles, a few 10^5 at most)
-__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ hist, int total) {
+// one workgroup per build: exclusive scan of its 256 * ntiles counters
+__global__ __launch_bounds__(1024) void k_rs_scan(const M3dBuild* __restrict__ builds, int pass) {
+    const M3dBuild& B = builds[blockIdx.x];
+    if (pass >= B.sort_passes) return;
+    uint32_t* hist = B.hist;
+    const int total = 256 * B.ntiles;
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     const int per = (total + 1023) / 1024;
@@ -119,9 +138,13 @@ __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ hist, i
     for (int i = b; i < e; i++) { uint32_t v = hist[i]; hist[i] = run; run += v; }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                           uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int n, int shift,
-                                                           const uint32_t* __restrict__ scanned, int ntiles) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
+    const uint32_t *kin, *vin; uint32_t *kout, *vout;
+    sort_buffers(B, pass, kin, vin, kout, vout);
+    const int n = B.n, shift = 8 * pass, ntiles = B.ntiles;
+    const uint32_t* scanned = B.hist;
     __shared__ uint32_t cnt[RS_ROUNDS * RS_WAVES][256];   // 32 KiB: per (round, wave) digit counts
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
@@ -167,7 +190,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __res
 // ---- a4: bucket heads -> exact-sized hash table, sorted float4 points -----------------------------
 // dyn[0] = occupied voxels, dyn[1] = hmask, dyn[2] = hshift, dyn[3] = occupied buckets, dyn[4] = big buckets
 // (table geometry is derived on the device: no host round trip between the sort and the table build)
-__global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict__ skey, int n, uint32_t* __restrict__ dyn) {
+__global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    const uint32_t* skey = sorted_keys(B);
+    const int n = B.n;
     uint32_t c = 0, b = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const uint32_t k = skey[j];
@@ -183,8 +209,8 @@ __global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict_
     if (threadIdx.x == 0) {
         c = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-        if (c) atomicAdd(&dyn[0], c);
-        if (b) atomicAdd(&dyn[3], b);
+        if (c) atomicAdd(&B.dyn[0], c);
+        if (b) atomicAdd(&B.dyn[3], b);
     }
 }
 
@@ -194,17 +220,23 @@ __host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap
     hmask = hs - 1; hshift = 32 - hb;
 }
 
-__global__ void k_table_params(uint32_t* __restrict__ dyn, uint32_t hcap) {
+__global__ void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_builds) return;
+    const M3dBuild& B = builds[i];
     uint32_t hmask; int hshift;
-    m3d_table_size(dyn[3], hcap, hmask, hshift);
-    dyn[1] = hmask; dyn[2] = (uint32_t)hshift;
+    m3d_table_size(B.dyn[3], B.hcap, hmask, hshift);
+    B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
 }
 
-__global__ __launch_bounds__(256) void k_clear_table(M3dBucket* __restrict__ htab, const uint32_t* __restrict__ dyn) {
-    const uint32_t T2 = 2u * (dyn[1] + 1u);
-    uint4* t = reinterpret_cast<uint4*>(htab);
+__global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    const uint32_t T2 = 2u * (B.dyn[1] + 1u);
+    uint4* t = reinterpret_cast<uint4*>(B.htab);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T2; i += gridDim.x * blockDim.x)
         t[i] = (i & 1u) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+    const uint32_t nb = 8u * B.bigcap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) B.bigcum[i] = 0u;
 }
 
 __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const float4& p) {
@@ -213,30 +245,32 @@ __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const 
     return m3d_bucket_key(g, ix >> 1, iy >> 1, iz >> 1);
 }
 
-__global__ __launch_bounds__(256) void k_finalize_level(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sval, int n,
-                                                        const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                        M3dGrid g, float4* __restrict__ pts, M3dBucket* __restrict__ htab,
-                                                        const uint32_t* __restrict__ dyn) {
+__global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B.n;
     if (j >= n) return;
-    const uint32_t hmask = dyn[1];
-    const int hshift = (int)dyn[2];
+    const uint32_t* skey = sorted_keys(B);
+    const uint32_t* sval = sorted_vals(B);
+    const uint32_t hmask = B.dyn[1];
+    const int hshift = (int)B.dyn[2];
     const uint32_t k = skey[j];
     const uint32_t oi = sval[j];
+    B.skey_out[j] = k; B.perm_out[j] = oi;             // kept for the introspection API
     const bool valid = k != M3D_INVALID_KEY;
     const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
     const bool last = valid && (j == n - 1 || skey[j + 1] != k);
     float4 p;
-    p.x = x[oi]; p.y = y[oi]; p.z = z[oi];
+    p.x = B.x[oi]; p.y = B.y[oi]; p.z = B.z[oi];
     p.w = __uint_as_float(oi | (last ? M3D_LAST_FLAG : 0u));
-    pts[j] = p;
+    B.pts[j] = p;
     if (bhead) {
-        const uint32_t bk = bucket_key_of_point(g, p);
+        const uint32_t bk = bucket_key_of_point(B.grid, p);
         uint32_t h = m3d_hash_slot(bk, hshift);
         for (;;) {   // bucket keys are unique here, so a successful CAS owns the slot
-            uint32_t old = atomicCAS(&htab[h].key, M3D_INVALID_KEY, bk);
-            if (old == M3D_INVALID_KEY) { htab[h].start = (uint32_t)j; break; }
+            uint32_t old = atomicCAS(&B.htab[h].key, M3D_INVALID_KEY, bk);
+            if (old == M3D_INVALID_KEY) { B.htab[h].start = (uint32_t)j; break; }
             h = (h + 1) & hmask;
         }
     }
@@ -244,44 +278,47 @@ __global__ __launch_bounds__(256) void k_finalize_level(const uint32_t* __restri
 
 // second pass: the last point of every bucket writes the population (and claims a bigcum row when it
 // does not fit 16 bits)
-__global__ __launch_bounds__(256) void k_bucket_counts(const uint32_t* __restrict__ skey, int n, const float4* __restrict__ pts, M3dGrid g,
-                                                       M3dBucket* __restrict__ htab, uint32_t* __restrict__ dyn) {
+__global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B.n;
     if (j >= n) return;
+    const uint32_t* skey = B.skey_out;
     const uint32_t k = skey[j];
     if (k == M3D_INVALID_KEY) return;
     const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
     if ((kn >> 3) == (k >> 3) && kn != M3D_INVALID_KEY) return;     // not the last point of its bucket
-    const uint32_t hmask = dyn[1];
-    const uint32_t bk = bucket_key_of_point(g, pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)dyn[2]);
-    while (htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t cnt = (uint32_t)j - htab[h].start + 1u;
-    htab[h].count = cnt;
-    htab[h].big = (cnt > 65535u) ? (1u + atomicAdd(&dyn[4], 1u)) : 0u;
+    const uint32_t hmask = B.dyn[1];
+    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
+    while (B.htab[h].key != bk) h = (h + 1) & hmask;
+    const uint32_t cnt = (uint32_t)j - B.htab[h].start + 1u;
+    B.htab[h].count = cnt;
+    B.htab[h].big = (cnt > 65535u) ? (1u + atomicAdd(&B.dyn[4], 1u)) : 0u;
 }
 
 // third pass: the last point of every voxel writes the cumulative population of its voxel and of the
 // empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0)
-__global__ __launch_bounds__(256) void k_bucket_cum(const uint32_t* __restrict__ skey, int n, const float4* __restrict__ pts, M3dGrid g,
-                                                    M3dBucket* __restrict__ htab, uint32_t* __restrict__ bigcum, uint32_t bigcap,
-                                                    const uint32_t* __restrict__ dyn) {
+__global__ __launch_bounds__(256) void k_bucket_cum(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B.n;
     if (j >= n) return;
+    const uint32_t* skey = B.skey_out;
     const uint32_t k = skey[j];
     if (k == M3D_INVALID_KEY) return;
     const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
     if (kn == k) return;                                              // not the last point of its voxel
     const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
     const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
-    const uint32_t hmask = dyn[1];
-    const uint32_t bk = bucket_key_of_point(g, pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)dyn[2]);
-    while (htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t v = (uint32_t)j - htab[h].start + 1u;
-    const uint32_t big = htab[h].big;
-    if (big == 0) { for (int t = s0; t < s1; t++) htab[h].cum[t] = (uint16_t)v; }
-    else if (big - 1u < bigcap) { for (int t = s0; t < s1; t++) bigcum[8 * (size_t)(big - 1u) + t] = v; }
+    const uint32_t hmask = B.dyn[1];
+    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
+    while (B.htab[h].key != bk) h = (h + 1) & hmask;
+    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
+    const uint32_t big = B.htab[h].big;
+    if (big == 0) { for (int t = s0; t < s1; t++) B.htab[h].cum[t] = (uint16_t)v; }
+    else if (big - 1u < B.bigcap) { for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v; }
 }
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
@@ -310,9 +347,9 @@ __device__ __forceinline__ double det_rsqrt(double x) {   // spec: bit-trick see
 }
 
 // Spec §Normals (v2): positions quantised to 1/65536 voxel inside their voxel, exact int64 moments.
-// Pass 1: per-voxel moments {n, S[3], P[6]} by a segmented wave64 scan over the cell-sorted points
-// (a run of equal keys is a voxel), one set of 64-bit integer atomics per run and wave, stored at the
-// voxel's first sorted position.
+// Pass 1: per-voxel moments {n, S[3], P[6]} by a segmented wave64 scan over the sorted points (a run of
+// equal keys is a voxel), one set of 64-bit integer atomics per run and wave, stored at the voxel's
+// first sorted position.
 #define M3D_NQ 65536
 __device__ __forceinline__ int m3d_quant_frac(float v, float mn, float inv_leaf) {
     const float sv = (v - mn) * inv_leaf;
@@ -320,10 +357,19 @@ __device__ __forceinline__ int m3d_quant_frac(float v, float mn, float inv_leaf)
     return (int)rintf(fr * 65536.0f);
 }
 
-__global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint32_t* __restrict__ dyn, const uint32_t* __restrict__ skey,
-                                                      long long* __restrict__ mom) {
+__device__ __forceinline__ M3dLevelDev build_level(const M3dBuild& B) {
+    M3dLevelDev L;
+    L.pts = B.pts; L.nrm = nullptr; L.htab = B.htab; L.bigcum = B.bigcum; L.g = B.grid;
+    L.g.hmask = B.dyn[1]; L.g.hshift = (int)B.dyn[2];   // the host copy is not known yet at this point
+    return L;
+}
+
+__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.mom) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    L.g.hmask = dyn[1]; L.g.hshift = (int)dyn[2];
+    if ((int)(blockIdx.x * blockDim.x) >= B.grid.n_valid) return;
+    const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const int lane = threadIdx.x & 63;
     const bool ok = j < g.n_valid;
@@ -332,7 +378,7 @@ __global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint3
 #pragma unroll
     for (int i = 0; i < 10; i++) v[i] = 0;
     if (ok) {
-        key = skey[j];
+        key = B.skey_out[j];
         const float4 p = L.pts[j];
         const long long qx = m3d_quant_frac(p.x, g.mn[0], g.inv_leaf), qy = m3d_quant_frac(p.y, g.mn[1], g.inv_leaf),
                         qz = m3d_quant_frac(p.z, g.mn[2], g.inv_leaf);
@@ -360,22 +406,25 @@ __global__ __launch_bounds__(256) void k_cell_moments(M3dLevelDev L, const uint3
         const int hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
                                            (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
 #pragma unroll
-        for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
+        for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&B.mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
     }
 }
 
 // Pass 2: per point, add the (shifted) moments of the 27 voxels around it and take the smallest
 // eigenvector of the covariance.
-__global__ __launch_bounds__(256) void k_normals(M3dLevelDev L, const uint32_t* __restrict__ dyn, const uint32_t* __restrict__ skey,
-                                                 const long long* __restrict__ mom, float plane_ratio, int min_pts, float min_spread,
-                                                 float4* __restrict__ nrm_in) {
+__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.mom) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= L.g.n_valid) return;
-    L.g.hmask = dyn[1]; L.g.hshift = (int)dyn[2];
+    if (j >= B.n) return;
+    const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
+    const long long* mom = B.mom;
+    float4* nrm_in = B.nrm_in;
     const float4 pj = L.pts[j];
     const uint32_t oi = __float_as_uint(pj.w) & ~M3D_LAST_FLAG;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j >= g.n_valid) { nrm_in[oi] = out; return; }   // non-finite points sort last: no normal
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
               icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
@@ -465,57 +514,39 @@ __global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __
 // ---- host-side launchers ----------------------------------------------------------------------------
 #define HIP_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return _e; } while (0)
 
-hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int step, int ox, int oy, int oz, float* x, float* y,
-                                  float* z, uint32_t* aabb) {
-    HIP_TRY(hipMemsetAsync(aabb, 0xFF, 3 * sizeof(uint32_t), s));      // ordered min = +max
-    HIP_TRY(hipMemsetAsync(aabb + 3, 0, 5 * sizeof(uint32_t), s));     // ordered max = 0, count = 0
-    int blocks = (n + 1023) / 1024;   // ~4 points per thread, one atomic set per block
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_decode_aabb, dim3(blocks), dim3(256), 0, s, raw, n, step, ox, oy, oz, x, y, z, aabb);
-    return hipGetLastError();
-}
-
-hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a) {
-    const int n = a.n;
-    const int blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks), dim3(256), 0, s, a.x, a.y, a.z, n, a.grid, a.keys, a.ka, a.va);
-    HIP_TRY(hipGetLastError());
-    const int ntiles = (n + RS_TILE - 1) / RS_TILE;
-    uint32_t *kin = a.ka, *vin = a.va, *kout = a.kb, *vout = a.vb;
-    for (int pass = 0; pass < a.sort_passes; pass++) {
-        const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, a.hist, ntiles);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, a.hist, 256 * ntiles);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, a.hist, ntiles);
-        HIP_TRY(hipGetLastError());
-        uint32_t* t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
-    }
-    // keep the sorted keys / permutation for the introspection API
-    HIP_TRY(hipMemcpyAsync(a.skey_out, kin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(a.perm_out, vin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(a.n_cells, 0, 8 * sizeof(uint32_t), s));
-    int cb = blocks > 256 ? 256 : blocks;
-    hipLaunchKernelGGL(k_count_cells, dim3(cb), dim3(256), 0, s, kin, n, a.n_cells);
-    hipLaunchKernelGGL(k_table_params, dim3(1), dim3(1), 0, s, a.n_cells, a.hcap);
-    hipLaunchKernelGGL(k_clear_table, dim3(cb), dim3(256), 0, s, a.htab, a.n_cells);
-    hipLaunchKernelGGL(k_finalize_level, dim3(blocks), dim3(256), 0, s, kin, vin, n, a.x, a.y, a.z, a.grid, a.pts, a.htab, a.n_cells);
-    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks), dim3(256), 0, s, kin, n, a.pts, a.grid, a.htab, a.n_cells);
-    hipLaunchKernelGGL(k_bucket_cum, dim3(blocks), dim3(256), 0, s, kin, n, a.pts, a.grid, a.htab, a.bigcum, a.bigcap, a.n_cells);
-    return hipGetLastError();
-}
-
 int m3d_sort_tiles(int n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* dyn, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
-                              float min_spread, float4* nrm_in, int n) {
-    HIP_TRY(hipMemsetAsync(nrm_in, 0, sizeof(float4) * (size_t)n, s));
-    const int nv = L.g.n_valid;
-    HIP_TRY(hipMemsetAsync(mom, 0, sizeof(long long) * 10 * (size_t)nv, s));
-    const int blocks = (nv + 255) / 256;
-    hipLaunchKernelGGL(k_cell_moments, dim3(blocks), dim3(256), 0, s, L, dyn, skey, mom);
-    hipLaunchKernelGGL(k_normals, dim3(blocks), dim3(256), 0, s, L, dyn, skey, (const long long*)mom, plane_ratio, min_pts, min_spread, nrm_in);
+hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n_clouds, int max_n) {
+    int blocks = (max_n + 1023) / 1024;   // ~4 points per thread, one atomic set per block
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_decode_aabb, dim3(blocks, n_clouds), dim3(256), 0, s, d_descs);
+    return hipGetLastError();
+}
+
+// the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
+hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int n_builds, int max_n, int max_passes, bool any_normals,
+                                   float plane_ratio, int min_pts, float min_spread) {
+    const int blocks = (max_n + 255) / 256;
+    const int ntiles = m3d_sort_tiles(max_n);
+    const int cb = blocks > 256 ? 256 : blocks;
+    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    for (int pass = 0; pass < max_passes; pass++) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+        hipLaunchKernelGGL(k_rs_scan, dim3(n_builds), dim3(1024), 0, s, d_builds, pass);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_count_cells, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_table_params, dim3((n_builds + 63) / 64), dim3(64), 0, s, d_builds, n_builds);
+    hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_finalize_level, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_bucket_cum, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    if (any_normals) {
+        hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+        hipLaunchKernelGGL(k_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);
+    }
     return hipGetLastError();
 }
 

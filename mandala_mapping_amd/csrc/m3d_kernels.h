@@ -3,33 +3,39 @@
 #pragma once
 #include "m3d_device.h"
 
-struct M3dBucketArgs {
+struct M3dDecode {               // one cloud of a decode batch (a2)
+    const uint8_t* raw;          // PointCloud2 payload on the device
+    int n, step, ox, oy, oz;
+    float *x, *y, *z;            // [n] out: SoA coordinates, input order
+    uint32_t* aabb;              // [8] out (zeroed): ~ordered min[3] (as max), ordered max[3], finite count
+};
+
+struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4, a9)
     int n;
-    const float *x, *y, *z;      // SoA input-order coordinates
-    M3dGrid grid;
-    int sort_passes;             // 8-bit LSD passes needed to order the keys
+    int sort_passes;             // 8-bit LSD passes needed to order this grid's keys
+    int ntiles;
+    const float *x, *y, *z;      // SoA input-order coordinates of the cloud
+    M3dGrid grid;                // hmask/hshift are filled on the device (dyn)
     uint32_t* keys;              // [n] out: key per input point
     uint32_t *ka, *va, *kb, *vb; // [n] sort ping-pong workspace
-    uint32_t* hist;              // [256 * tiles]
+    uint32_t* hist;              // [256 * ntiles] workspace
     uint32_t* skey_out;          // [n] out: sorted keys
     uint32_t* perm_out;          // [n] out: permutation
     float4* pts;                 // [n] out
-    M3dBucket* htab;             // [hcap] out (hcap = worst-case allocation; the used size is derived on the device)
+    M3dBucket* htab;             // [hcap] out (worst-case allocation; the used size is derived on the device)
     uint32_t hcap;
-    uint32_t* bigcum;            // [bigcap][8] out: 32-bit cumulative populations of buckets with > 65535 points
+    uint32_t* bigcum;            // [bigcap][8] out
     uint32_t bigcap;
-    uint32_t* n_cells;           // [8] out: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
+    uint32_t* dyn;               // [8] (zeroed) out: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
+    long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
+    float4* nrm_in;              // [n] out: normals by input index, normal grids only
 };
 
 float m3d_unord_f32(uint32_t u);
 int m3d_sort_tiles(int n);
-hipError_t m3d_launch_decode_aabb(hipStream_t s, const uint8_t* raw, int n, int step, int ox, int oy, int oz, float* x, float* y,
-                                  float* z, uint32_t* aabb);
-hipError_t m3d_launch_bucket_level(hipStream_t s, const M3dBucketArgs& a);
-// mom: workspace of 10 * n_valid int64 (per-voxel moments, indexed by the voxel's first sorted position)
-// dyn: the level's device-side {occupied voxels, hmask, hshift} (the host copy is not known yet at this point)
-hipError_t m3d_launch_normals(hipStream_t s, const M3dLevelDev& L, const uint32_t* dyn, const uint32_t* skey, long long* mom, float plane_ratio, int min_pts,
-                              float min_spread, float4* nrm_in, int n);
+hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n_clouds, int max_n);
+hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int n_builds, int max_n, int max_passes, bool any_normals,
+                                   float plane_ratio, int min_pts, float min_spread);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // icp.hip

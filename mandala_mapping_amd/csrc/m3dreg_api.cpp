@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -25,14 +26,27 @@ struct DevLevel {
     float lbound = 0.f;
     float4* pts = nullptr;
     M3dBucket* htab = nullptr;
+    uint32_t hcap = 0;             // allocated entries (worst case); the used size is grid.hmask + 1
     uint32_t* bigcum = nullptr;
     uint32_t bigcap = 0;
-    uint32_t hcap = 0;             // allocated entries (worst case); the used size lives in n_cells[1..2]
-    uint32_t n_cells_host = 0;
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
     uint32_t* perm = nullptr;
-    uint32_t* n_cells = nullptr;   // device: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
+    uint32_t n_cells_host = 0;
+};
+
+struct Block { void* p = nullptr; size_t bytes = 0; };
+
+// bump allocator over one device block (256-byte aligned pieces); with base == nullptr it only sizes
+struct Carver {
+    uint8_t* base; size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<uint8_t*>(b)) {}
+    template <typename T> T* take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += sizeof(T) * (count ? count : 1);
+        return r;
+    }
 };
 
 }  // namespace
@@ -47,7 +61,7 @@ struct m3dreg_cloud {
     float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
-    std::vector<void*> allocs;
+    Block block;                   // ONE device allocation holds every array of the cloud
 };
 
 struct m3dreg_handle {
@@ -56,10 +70,12 @@ struct m3dreg_handle {
     bool own_stream = false;
     m3dreg_params params{};
     std::string err;
-    // sort workspace (grown on demand)
-    size_t ws_n = 0;
-    uint32_t *ka = nullptr, *va = nullptr, *kb = nullptr, *vb = nullptr, *hist = nullptr, *aabb = nullptr;
-    long long* mom = nullptr;          // [10 * ws_n] per-voxel moments of the normal grid
+    // pooled cloud blocks (hipMalloc/hipFree per cloud would serialise the device) and the batch workspace
+    std::vector<Block> pool;
+    size_t pool_bytes = 0;
+    Block ws;                          // device workspace of the bucketing batch
+    void* h_ws = nullptr;              // pinned host staging (descriptors, aabb / dyn read-back)
+    size_t h_ws_bytes = 0;
     // batch state
     size_t cap_pairs = 0;
     M3dJob* d_jobs = nullptr;          // [levels][cap_pairs]
@@ -169,36 +185,62 @@ void fixed_exps(float lbound, float max_corr_dist, int32_t e[6]) {
     e[5] = 30 - ceil_log2_d(D * D);
 }
 
-template <typename T>
-int dmalloc(m3dreg_handle* h, m3dreg_cloud* c, T** out, size_t count) {
+const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
+
+int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
+    int best = -1;
+    for (size_t i = 0; i < h->pool.size(); i++)
+        if (h->pool[i].bytes >= bytes && h->pool[i].bytes <= bytes + bytes / 2 && (best < 0 || h->pool[i].bytes < h->pool[size_t(best)].bytes)) best = int(i);
+    if (best >= 0) {
+        out = h->pool[size_t(best)];
+        h->pool_bytes -= out.bytes;
+        h->pool.erase(h->pool.begin() + best);
+        return M3DREG_OK;
+    }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, sizeof(T) * (count ? count : 1));
-    if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "hipMalloc", e);
-    if (c) c->allocs.push_back(p);
-    *out = static_cast<T*>(p);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {   // make room: drop the cache and retry once
+        hipStreamSynchronize(h->stream);
+        for (Block& b : h->pool) hipFree(b.p);
+        h->pool.clear(); h->pool_bytes = 0;
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "hipMalloc(cloud block)", e);
+    }
+    out.p = p; out.bytes = bytes;
     return M3DREG_OK;
 }
 
-int ensure_workspace(m3dreg_handle* h, size_t n) {
-    if (!h->aabb) { int rc = dmalloc(h, nullptr, &h->aabb, 8); if (rc) return rc; }
-    if (n <= h->ws_n) return M3DREG_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->mom }) if (p) hipFree(p);
-    h->ka = h->va = h->kb = h->vb = h->hist = nullptr; h->mom = nullptr;
-    h->ws_n = 0;
-    size_t cap = n + n / 4 + 1024;
-    int rc;
-    if ((rc = dmalloc(h, nullptr, &h->ka, cap)) || (rc = dmalloc(h, nullptr, &h->va, cap)) || (rc = dmalloc(h, nullptr, &h->kb, cap)) ||
-        (rc = dmalloc(h, nullptr, &h->vb, cap)) || (rc = dmalloc(h, nullptr, &h->hist, 256 * size_t(m3d_sort_tiles(int(cap)) + 1))) ||
-        (rc = dmalloc(h, nullptr, &h->mom, 10 * cap)))
-        return rc;
-    h->ws_n = cap;
+// Blocks go back to the cache without a device sync: every use of a block is ordered on the handle's stream.
+void pool_put(m3dreg_handle* h, Block b) {
+    if (!b.p) return;
+    if (h->pool_bytes + b.bytes > POOL_CAP_BYTES) { hipStreamSynchronize(h->stream); hipFree(b.p); return; }
+    h->pool.push_back(b);
+    h->pool_bytes += b.bytes;
+}
+
+int ensure_ws(m3dreg_handle* h, size_t dev_bytes, size_t host_bytes) {
+    if (dev_bytes > h->ws.bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->ws.p) hipFree(h->ws.p);
+        h->ws = Block();
+        const size_t cap = dev_bytes + dev_bytes / 4;
+        HIPCHK(h, hipMalloc(&h->ws.p, cap));
+        h->ws.bytes = cap;
+    }
+    if (host_bytes > h->h_ws_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->h_ws) hipHostFree(h->h_ws);
+        h->h_ws = nullptr; h->h_ws_bytes = 0;
+        const size_t cap = host_bytes + host_bytes / 4;
+        HIPCHK(h, hipHostMalloc(&h->h_ws, cap, hipHostMallocDefault));
+        h->h_ws_bytes = cap;
+    }
     return M3DREG_OK;
 }
 
-void free_cloud(m3dreg_cloud* c) {
+void free_cloud(m3dreg_handle* h, m3dreg_cloud* c) {
     if (!c) return;
-    for (void* p : c->allocs) hipFree(p);
+    pool_put(h, c->block);
     delete c;
 }
 
@@ -208,24 +250,175 @@ int sort_passes_for(const DevLevel& L, bool has_invalid) {
     return (bits + 7) / 8;
 }
 
-// bucket one level of `c` (geometry from the cloud's AABB)
-int bucket_level(m3dreg_handle* h, m3dreg_cloud* c, DevLevel& L, float leaf) {
-    int rc = make_grid(c->mn, c->mx, leaf, c->n, c->n_valid, L);
-    if (rc) return fail(h, rc, "voxel grid needs more than 31 key bits (coarsen leaf or crop the cloud)");
+uint32_t table_cap(size_t n) { uint32_t hs = 16; while (hs < 2u * uint32_t(n)) hs <<= 1; return hs; }
+
+// lay a cloud's arrays out in its block (base == nullptr: size only)
+size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
+    Carver k(base);
     const size_t n = size_t(c->n);
-    if ((rc = dmalloc(h, c, &L.pts, n)) || (rc = dmalloc(h, c, &L.htab, size_t(L.hcap))) || (rc = dmalloc(h, c, &L.keys, n)) ||
-        (rc = dmalloc(h, c, &L.skey, n)) || (rc = dmalloc(h, c, &L.perm, n)) || (rc = dmalloc(h, c, &L.n_cells, 8)))
-        return rc;
-    L.bigcap = uint32_t(n / 65536 + 1);
-    if ((rc = dmalloc(h, c, &L.bigcum, size_t(L.bigcap) * 8))) return rc;
-    HIPCHK(h, hipMemsetAsync(L.bigcum, 0, sizeof(uint32_t) * 8 * size_t(L.bigcap), h->stream));
-    M3dBucketArgs a{};
-    a.n = c->n; a.x = c->x; a.y = c->y; a.z = c->z; a.grid = L.grid;
-    a.sort_passes = sort_passes_for(L, c->n_valid != c->n);
-    a.keys = L.keys; a.ka = h->ka; a.va = h->va; a.kb = h->kb; a.vb = h->vb; a.hist = h->hist;
-    a.skey_out = L.skey; a.perm_out = L.perm; a.pts = L.pts; a.htab = L.htab; a.hcap = L.hcap; a.bigcum = L.bigcum; a.bigcap = L.bigcap;
-    a.n_cells = L.n_cells;
-    HIPCHK(h, m3d_launch_bucket_level(h->stream, a));
+    c->x = k.take<float>(n); c->y = k.take<float>(n); c->z = k.take<float>(n);
+    c->nrm_in = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
+    for (int l = 0; l < P.n_levels; l++) {
+        DevLevel& L = c->lv[l];
+        L.hcap = table_cap(n);
+        L.bigcap = uint32_t(n / 65536 + 1);
+        L.pts = k.take<float4>(n);
+        L.htab = k.take<M3dBucket>(L.hcap);
+        L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
+        L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
+    }
+    return (k.off + 255) & ~size_t(255);
+}
+
+struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned; };
+
+// Bucket a batch of clouds: one decode launch, ONE host sync (grid geometry is host-derived from the exact
+// AABBs), one bucketing pipeline for every grid of every cloud, one final sync (table geometry read-back).
+int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud** out) {
+    const m3dreg_params& P = h->params;
+    const bool want_normals = P.metric == M3DREG_POINT_TO_PLANE;
+    const int grids_per_cloud = P.n_levels + (want_normals ? 1 : 0);
+    const size_t n_builds = k * size_t(grids_per_cloud);
+    std::vector<m3dreg_cloud*> cl(k, nullptr);
+    auto cleanup = [&]() { hipStreamSynchronize(h->stream); for (m3dreg_cloud* c : cl) free_cloud(h, c); };
+    size_t max_n = 0;
+    for (size_t i = 0; i < k; i++) {
+        m3dreg_cloud* c = new m3dreg_cloud();
+        cl[i] = c;
+        c->n = int32_t(in[i].n);
+        c->n_levels = P.n_levels;
+        for (int l = 0; l < P.n_levels; l++) c->leaf[l] = P.leaf[l];
+        const size_t bytes = carve_cloud(c, nullptr, P);
+        int rc = pool_get(h, bytes, c->block);
+        if (rc) { cleanup(); return rc; }
+        carve_cloud(c, c->block.p, P);
+        if (in[i].n > max_n) max_n = in[i].n;
+    }
+    // ---- workspace layout (device) + pinned host staging -------------------------------------------------
+    std::vector<uint8_t*> staged(k, nullptr);
+    std::vector<uint32_t*> aabb(k, nullptr);
+    struct BuildWs { uint32_t *ka, *va, *kb, *vb, *hist, *dyn; DevLevel ng; long long* mom; };
+    std::vector<BuildWs> bw(n_builds);
+    M3dDecode* d_dec = nullptr; M3dBuild* d_builds = nullptr; uint8_t* zero_lo = nullptr; uint8_t* zero_hi = nullptr;
+    auto layout = [&](void* base) -> size_t {
+        Carver w(base);
+        d_dec = w.take<M3dDecode>(k);
+        d_builds = w.take<M3dBuild>(n_builds);
+        // --- region zeroed with one memset: aabb, dyn, moments ---
+        w.take<uint8_t>(0); zero_lo = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
+        uint32_t* aabb_all = w.take<uint32_t>(8 * k);              // contiguous: read back with one copy
+        for (size_t i = 0; i < k; i++) aabb[i] = base ? aabb_all + 8 * i : nullptr;
+        uint32_t* dyn_all = w.take<uint32_t>(8 * n_builds);        // contiguous: read back with one copy
+        for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + 8 * b : nullptr;
+        for (size_t i = 0; i < k; i++) {
+            BuildWs& B = bw[i * size_t(grids_per_cloud)];
+            B.mom = want_normals ? w.take<long long>(10 * in[i].n) : nullptr;
+        }
+        w.take<uint8_t>(0); zero_hi = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
+        // --- the rest ---
+        for (size_t i = 0; i < k; i++) {
+            const size_t n = in[i].n;
+            staged[i] = (!in[i].is_device) ? w.take<uint8_t>(in[i].aligned ? n * in[i].step : 12 * n) : nullptr;
+            for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
+                BuildWs& B = bw[i * size_t(grids_per_cloud) + size_t(gidx)];
+                B.ka = w.take<uint32_t>(n); B.va = w.take<uint32_t>(n); B.kb = w.take<uint32_t>(n); B.vb = w.take<uint32_t>(n);
+                B.hist = w.take<uint32_t>(256 * size_t(m3d_sort_tiles(int(n)) + 1));
+                if (want_normals && gidx == 0) {   // the normal grid lives in the workspace only
+                    DevLevel& G = B.ng;
+                    G.hcap = table_cap(n); G.bigcap = uint32_t(n / 65536 + 1);
+                    G.pts = w.take<float4>(n); G.htab = w.take<M3dBucket>(G.hcap); G.bigcum = w.take<uint32_t>(size_t(G.bigcap) * 8);
+                    G.keys = w.take<uint32_t>(n); G.skey = w.take<uint32_t>(n); G.perm = w.take<uint32_t>(n);
+                }
+            }
+        }
+        return (w.off + 255) & ~size_t(255);
+    };
+    const size_t ws_bytes = layout(nullptr);
+    const size_t host_bytes = sizeof(M3dDecode) * k + sizeof(M3dBuild) * n_builds + 32 * (k + n_builds) + 1024;
+    int rc = ensure_ws(h, ws_bytes, host_bytes);
+    if (rc) { cleanup(); return rc; }
+    layout(h->ws.p);
+    Carver hw(h->h_ws);
+    M3dDecode* h_dec = hw.take<M3dDecode>(k);
+    M3dBuild* h_builds = hw.take<M3dBuild>(n_builds);
+    uint32_t* h_aabb = hw.take<uint32_t>(8 * k);
+    uint32_t* h_dyn = hw.take<uint32_t>(8 * n_builds);
+#define B_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
+    B_HIP(hipMemsetAsync(zero_lo, 0, size_t(zero_hi - zero_lo), h->stream));
+    // ---- a2: stage + decode ----------------------------------------------------------------------------------
+    std::vector<std::vector<float>> repack(k);
+    for (size_t i = 0; i < k; i++) {
+        M3dDecode& D = h_dec[i];
+        size_t step = in[i].step, ox = in[i].ox, oy = in[i].oy, oz = in[i].oz;
+        const uint8_t* raw = static_cast<const uint8_t*>(in[i].data);
+        if (!in[i].is_device) {
+            const void* src = in[i].data;
+            size_t bytes = in[i].n * in[i].step;
+            if (!in[i].aligned) {   // never produced by m3d_aggregator (16/0/4/8); repacked on the host
+                repack[i].resize(3 * in[i].n);
+                const uint8_t* b = static_cast<const uint8_t*>(in[i].data);
+                for (size_t j = 0; j < in[i].n; j++) {
+                    memcpy(&repack[i][3 * j], b + j * step + ox, 4);
+                    memcpy(&repack[i][3 * j + 1], b + j * step + oy, 4);
+                    memcpy(&repack[i][3 * j + 2], b + j * step + oz, 4);
+                }
+                src = repack[i].data(); bytes = 12 * in[i].n; step = 12; ox = 0; oy = 4; oz = 8;
+            }
+            B_HIP(hipMemcpyAsync(staged[i], src, bytes, hipMemcpyHostToDevice, h->stream));
+            raw = staged[i];
+        }
+        D.raw = raw; D.n = int(in[i].n); D.step = int(step); D.ox = int(ox); D.oy = int(oy); D.oz = int(oz);
+        D.x = cl[i]->x; D.y = cl[i]->y; D.z = cl[i]->z; D.aabb = aabb[i];
+    }
+    B_HIP(hipMemcpyAsync(d_dec, h_dec, sizeof(M3dDecode) * k, hipMemcpyHostToDevice, h->stream));
+    B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
+    B_HIP(hipMemcpyAsync(h_aabb, aabb[0], sizeof(uint32_t) * 8 * k, hipMemcpyDeviceToHost, h->stream));
+    B_HIP(hipStreamSynchronize(h->stream));   // sync 1 of 2: the grid geometry is derived on the host from the exact AABB
+    // ---- a3/a4/a9: one build descriptor per grid ---------------------------------------------------------------
+    int max_passes = 0;
+    for (size_t i = 0; i < k; i++) {
+        m3dreg_cloud* c = cl[i];
+        const uint32_t* ab = h_aabb + 8 * i;
+        c->n_valid = int32_t(ab[6]);
+        if (c->n_valid == 0) { cleanup(); return fail(h, M3DREG_ERR_EMPTY_CLOUD, "cloud has no finite point"); }
+        for (int a = 0; a < 3; a++) { c->mn[a] = m3d_unord_f32(~ab[a]); c->mx[a] = m3d_unord_f32(ab[3 + a]); }
+        c->has_normals = want_normals;
+        for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
+            const size_t bi = i * size_t(grids_per_cloud) + size_t(gidx);
+            BuildWs& W = bw[bi];
+            const bool is_ng = want_normals && gidx == 0;
+            DevLevel& L = is_ng ? W.ng : c->lv[gidx - (want_normals ? 1 : 0)];
+            const float leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
+            rc = make_grid(c->mn, c->mx, leaf, c->n, c->n_valid, L);
+            if (rc) { cleanup(); return fail(h, rc, "voxel grid needs more than 31 key bits (coarsen leaf or crop the cloud)"); }
+            M3dBuild& B = h_builds[bi];
+            memset(&B, 0, sizeof(B));
+            B.n = c->n; B.sort_passes = sort_passes_for(L, c->n_valid != c->n); B.ntiles = m3d_sort_tiles(c->n);
+            if (B.sort_passes > max_passes) max_passes = B.sort_passes;
+            B.x = c->x; B.y = c->y; B.z = c->z; B.grid = L.grid;
+            B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
+            B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
+            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = W.dyn;
+            B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
+            B.nrm_in = is_ng ? c->nrm_in : nullptr;
+        }
+    }
+    B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
+    B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(n_builds), int(max_n), max_passes, want_normals, P.plane_ratio, P.normal_min_pts,
+                                  P.normal_min_spread));
+    B_HIP(hipMemcpyAsync(h_dyn, bw[0].dyn, sizeof(uint32_t) * 8 * n_builds, hipMemcpyDeviceToHost, h->stream));
+    B_HIP(hipStreamSynchronize(h->stream));   // sync 2 of 2: device-derived table geometry of every level
+#undef B_HIP
+    for (size_t i = 0; i < k; i++) {
+        for (int l = 0; l < P.n_levels; l++) {
+            const uint32_t* dyn = h_dyn + 8 * (i * size_t(grids_per_cloud) + size_t(l + (want_normals ? 1 : 0)));
+            DevLevel& L = cl[i]->lv[l];
+            L.n_cells_host = dyn[0];
+            L.grid.hmask = dyn[1];
+            L.grid.hshift = int32_t(dyn[2]);
+        }
+        out[i] = cl[i];
+    }
     return M3DREG_OK;
 }
 
@@ -397,10 +590,11 @@ int m3dreg_destroy(m3dreg_handle* h) {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    free_cloud(h->target);
-    for (void* p : { (void*)h->ka, (void*)h->va, (void*)h->kb, (void*)h->vb, (void*)h->hist, (void*)h->mom, (void*)h->aabb, (void*)h->d_jobs, (void*)h->d_states,
-                     (void*)h->d_trace, (void*)h->d_match })
-        if (p) hipFree(p);
+    free_cloud(h, h->target);
+    for (Block& b : h->pool) hipFree(b.p);
+    if (h->ws.p) hipFree(h->ws.p);
+    if (h->h_ws) hipHostFree(h->h_ws);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -416,95 +610,38 @@ int m3dreg_synchronize(m3dreg_handle* h) {
     return M3DREG_OK;
 }
 
+static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput& ci) {
+    if (!d.data || d.n == 0 || d.n >= 0x7FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
+    if (d.off_x + 4 > d.point_step || d.off_y + 4 > d.point_step || d.off_z + 4 > d.point_step || d.point_step > 0x7FFFFFFFull)
+        return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: field offsets outside point_step");
+    ci.data = d.data; ci.n = d.n; ci.step = d.point_step; ci.ox = d.off_x; ci.oy = d.off_y; ci.oz = d.off_z;
+    ci.is_device = d.data_is_device != 0;
+    // device code reads 4-byte aligned floats; anything else is repacked on the host first
+    ci.aligned = (d.point_step % 4 == 0) && (d.off_x % 4 == 0) && (d.off_y % 4 == 0) && (d.off_z % 4 == 0) &&
+                 (reinterpret_cast<uintptr_t>(d.data) % 4 == 0);
+    if (ci.is_device && !ci.aligned) return fail(h, M3DREG_ERR_INVALID_ARG, "device payloads must be 4-byte aligned");
+    return M3DREG_OK;
+}
+
+int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
+    if (!h || !descs || !out || n_clouds == 0 || n_clouds > 4096) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_batch: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<CloudInput> in(n_clouds);
+    for (size_t i = 0; i < n_clouds; i++) { out[i] = nullptr; int rc = check_input(h, descs[i], in[i]); if (rc) return rc; }
+    return create_clouds(h, in.data(), n_clouds, out);
+}
+
 int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                         int data_is_device, m3dreg_cloud** out) {
-    if (!h || !data || !out || n == 0 || n >= 0x7FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
-    if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step || point_step > 0x7FFFFFFFull)
-        return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: field offsets outside point_step");
-    *out = nullptr;
-    HIPCHK(h, hipSetDevice(h->device));
-    const m3dreg_params& P = h->params;
-    m3dreg_cloud* c = new m3dreg_cloud();
-    c->n = int32_t(n);
-    c->n_levels = P.n_levels;
-    for (int l = 0; l < P.n_levels; l++) c->leaf[l] = P.leaf[l];
-    int rc;
-#define CLOUD_TRY(expr) do { rc = (expr); if (rc) { hipStreamSynchronize(h->stream); free_cloud(c); return rc; } } while (0)
-#define CLOUD_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { hipStreamSynchronize(h->stream); free_cloud(c); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
-    CLOUD_TRY(ensure_workspace(h, n));
-    // stage the payload on the device (a2). Device code reads 4-byte aligned floats; anything else is
-    // repacked on the host first (never seen from m3d_aggregator, whose layout is 16/0/4/8).
-    const uint8_t* raw_d = nullptr;
-    uint8_t* staged = nullptr;
-    std::vector<float> repack;
-    const bool aligned = (point_step % 4 == 0) && (off_x % 4 == 0) && (off_y % 4 == 0) && (off_z % 4 == 0) && (reinterpret_cast<uintptr_t>(data) % 4 == 0);
-    if (data_is_device) {
-        if (!aligned) { free_cloud(c); return fail(h, M3DREG_ERR_INVALID_ARG, "device payloads must be 4-byte aligned"); }
-        raw_d = static_cast<const uint8_t*>(data);
-    } else {
-        const void* src = data;
-        size_t bytes = n * point_step;
-        if (!aligned) {
-            repack.resize(3 * n);
-            const uint8_t* b = static_cast<const uint8_t*>(data);
-            for (size_t i = 0; i < n; i++) {
-                memcpy(&repack[3 * i], b + i * point_step + off_x, 4);
-                memcpy(&repack[3 * i + 1], b + i * point_step + off_y, 4);
-                memcpy(&repack[3 * i + 2], b + i * point_step + off_z, 4);
-            }
-            src = repack.data(); bytes = 12 * n; point_step = 12; off_x = 0; off_y = 4; off_z = 8;
-        }
-        CLOUD_HIP(hipMalloc((void**)&staged, bytes));
-        hipError_t e = hipMemcpyAsync(staged, src, bytes, hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) { hipFree(staged); CLOUD_HIP(e); }
-        raw_d = staged;
-    }
-    auto drop_staged = [&]() { if (staged) { hipStreamSynchronize(h->stream); hipFree(staged); staged = nullptr; } };
-#undef CLOUD_TRY
-#undef CLOUD_HIP
-#define CLOUD_TRY(expr) do { rc = (expr); if (rc) { drop_staged(); hipStreamSynchronize(h->stream); free_cloud(c); return rc; } } while (0)
-#define CLOUD_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { drop_staged(); hipStreamSynchronize(h->stream); free_cloud(c); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
-    CLOUD_TRY(dmalloc(h, c, &c->x, n));
-    CLOUD_TRY(dmalloc(h, c, &c->y, n));
-    CLOUD_TRY(dmalloc(h, c, &c->z, n));
-    CLOUD_HIP(m3d_launch_decode_aabb(h->stream, raw_d, int(n), int(point_step), int(off_x), int(off_y), int(off_z), c->x, c->y, c->z, h->aabb));
-    uint32_t ab[8];
-    CLOUD_HIP(hipMemcpyAsync(ab, h->aabb, sizeof(ab), hipMemcpyDeviceToHost, h->stream));
-    CLOUD_HIP(hipStreamSynchronize(h->stream));   // the only host sync of the bucketing: grid geometry is host-derived
-    drop_staged();
-    c->n_valid = int32_t(ab[6]);
-    if (c->n_valid == 0) { free_cloud(c); return fail(h, M3DREG_ERR_EMPTY_CLOUD, "cloud has no finite point"); }
-    for (int a = 0; a < 3; a++) { c->mn[a] = m3d_unord_f32(ab[a]); c->mx[a] = m3d_unord_f32(ab[3 + a]); }
-    // a9: normals on the dedicated normal grid (point-to-plane only), kept in input order
-    if (P.metric == M3DREG_POINT_TO_PLANE) {
-        DevLevel NG;
-        CLOUD_TRY(bucket_level(h, c, NG, P.normal_leaf));
-        CLOUD_TRY(dmalloc(h, c, &c->nrm_in, n));
-        float4* nrm_in = c->nrm_in;
-        CLOUD_HIP(m3d_launch_normals(h->stream, level_dev(NG, nullptr), NG.n_cells, NG.skey, h->mom, P.plane_ratio, P.normal_min_pts, P.normal_min_spread, nrm_in, int(n)));
-        c->has_normals = true;
-    }
-    for (int l = 0; l < P.n_levels; l++) CLOUD_TRY(bucket_level(h, c, c->lv[l], P.leaf[l]));
-    // read back the device-derived table geometry of every level (the kernels so far took it from device memory)
-    uint32_t dyn[M3DREG_MAX_LEVELS][8];
-    for (int l = 0; l < P.n_levels; l++) CLOUD_HIP(hipMemcpyAsync(dyn[l], c->lv[l].n_cells, sizeof(dyn[l]), hipMemcpyDeviceToHost, h->stream));
-    CLOUD_HIP(hipStreamSynchronize(h->stream));
-    for (int l = 0; l < P.n_levels; l++) {
-        c->lv[l].n_cells_host = dyn[l][0];
-        c->lv[l].grid.hmask = dyn[l][1];
-        c->lv[l].grid.hshift = int32_t(dyn[l][2]);
-    }
-#undef CLOUD_TRY
-#undef CLOUD_HIP
-    *out = c;
-    return M3DREG_OK;
+    if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
+    m3dreg_cloud_desc d;
+    d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z; d.data_is_device = data_is_device;
+    return m3dreg_cloud_create_batch(h, &d, 1, out);
 }
 
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
     if (!h || !c) return M3DREG_ERR_INVALID_ARG;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    free_cloud(c);
+    free_cloud(h, c);   // the block returns to the handle's cache; later users are ordered on the same stream
     return M3DREG_OK;
 }
 
@@ -568,7 +705,7 @@ int m3dreg_set_target_xyz(m3dreg_handle* h, const void* data, size_t n, size_t p
     m3dreg_cloud* c = nullptr;
     int rc = m3dreg_cloud_create(h, data, n, point_step, off_x, off_y, off_z, 0, &c);
     if (rc) return rc;
-    if (h->target) m3dreg_cloud_destroy(h, h->target);
+    if (h->target) free_cloud(h, h->target);
     h->target = c;
     return M3DREG_OK;
 }

@@ -208,3 +208,21 @@ def test_kernel_variants_are_bit_identical(reg, orc, monkeypatch):
     To, sto, tro = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=16)
     assert np.array_equal(out[1][3], tro) and np.array_equal(out[1][2], To)
     _same_stats(out[1][4], sto)
+
+
+def test_batched_bucketing_equals_single(reg, orc):
+    """m3dreg_cloud_create_batch (one pipeline for many clouds of different sizes, some with non-finite
+    points) produces exactly the clouds the one-at-a-time path and the oracle produce."""
+    p = _params(leaf=(0.5, 0.25), iterations=(3, 3), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    arrays = []
+    for k in range(5):
+        a = synth.planes_cloud(1500 + 700 * k, 20 + k).copy()
+        if k % 2:
+            a[::53] = np.nan
+        arrays.append(a)
+    batch = R.clouds(arrays)
+    for a, c in zip(arrays, batch):
+        o = orc.Cloud(p, a)
+        _check_bucketing(c, o, 2)
+        _check_bucketing(R.cloud(a), o, 2)
