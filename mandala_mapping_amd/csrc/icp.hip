@@ -418,14 +418,34 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 
 // Search state kept deliberately small (high occupancy). `g` is a by-value copy of the grid (SGPRs),
 // tab/pts/bigcum are global-address-space pointers (global_load, not flat_load).
+// m_prev: the match of this query in the previous iteration of the same level (or -1). When that point is
+// still closer than one voxel edge it necessarily lies inside the 27-voxel neighbourhood, so it is a
+// legitimate candidate: seeding the search with it changes nothing in the result (the argmin rule is
+// order-independent) but lets the box pruning discard most voxels — and whole buckets — before any probe.
 __device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                            float dmax2) {
+                                            float dmax2, int m_prev) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
-    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
     int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
     float bound = dmax2 * 1.0001f;
+    if (m_prev >= 0) {
+        const float4 c4 = m3d_ld(pts, (size_t)m_prev);
+        const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
+        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+        const float reach = 0.99f * g.leaf;
+        if (dd < reach * reach) {
+            best = m_prev; bd = dd; boi = __float_as_uint(c4.w) & ~M3D_LAST_FLAG;
+            bound = fminf(bound, bd * 1.0001f);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
+                if (Q.gl[a] * Q.gl[a] > bound) Q.lo[a] = max(Q.lo[a], Q.ic[a]);
+                if (Q.gh[a] * Q.gh[a] > bound) Q.hi[a] = min(Q.hi[a], Q.ic[a]);
+            }
+        }
+    }
+    if (Q.lo[0] > Q.hi[0] || Q.lo[1] > Q.hi[1] || Q.lo[2] > Q.hi[2]) return (best >= 0 && bd <= dmax2) ? best : -1;
+    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
     // all (up to eight) bucket entries, both halves, are requested before the first one is used: 16 loads in flight
     uint4 lo[8], hi[8]; uint32_t key[8]; bool act[8];
 #pragma unroll
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(256) void k_nn_search(const M3dJob* __restrict__ jo
         const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
         int m = -1;
-        if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_pos(g, tab, pts, bigcum, ux, uy, uz, dmax2);
+        if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_pos(g, tab, pts, bigcum, ux, uy, uz, dmax2, first_of_level ? -1 : out[i]);
         out[i] = m;
     }
 }
