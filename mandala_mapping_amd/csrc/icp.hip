@@ -418,22 +418,39 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 
 // Search state kept deliberately small (high occupancy). `g` is a by-value copy of the grid (SGPRs),
 // tab/pts/bigcum are global-address-space pointers (global_load, not flat_load).
-// m_prev: the match of this query in the previous iteration of the same level (or -1). When that point is
-// still closer than one voxel edge it necessarily lies inside the 27-voxel neighbourhood, so it is a
-// legitimate candidate: seeding the search with it changes nothing in the result (the argmin rule is
+// Per-query state kept between the iterations of a level:
+//   match[i] (int32)  >= 0: sorted position of the match; -1: no match; -2: no match AND the 27 voxels
+//                     around the query's voxel held no point at all — cache[i] then holds that voxel
+//   cache[i] (int64)  the voxel (ic.x | ic.y << 16 | ic.z << 32, each + 1) the "-2" verdict was made for.
+// While a query stays in the same voxel its neighbourhood is the same set of (static) target voxels, so
+// "-2" is answered again without a single probe. Exact: a changed voxel simply re-runs the full search.
+#define M3D_NN_NONE_CACHED (-2)
+#define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
+__device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
+    return (long long)(Q.ic[0] + 1) | ((long long)(Q.ic[1] + 1) << 16) | ((long long)(Q.ic[2] + 1) << 32);
+}
+
+// LIGHT path. m_prev: this query's result in the previous iteration of the same level. When the previous
+// match is still closer than one voxel edge it necessarily lies inside the 27-voxel neighbourhood, so it
+// is a legitimate candidate: seeding the search with it changes nothing in the result (the argmin rule is
 // order-independent) but lets the box pruning discard most voxels — and whole buckets — before any probe.
-__device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                            float dmax2, int m_prev) {
+// Queries that cannot be seeded return M3D_NN_HEAVY and are searched later, compacted into dense waves.
+__device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
+                                              float dmax2, int m_prev, long long cache_prev, float seed_reach) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
+    if (m_prev == M3D_NN_NONE_CACHED) return (m3d_voxel_code(Q) == cache_prev) ? M3D_NN_NONE_CACHED : M3D_NN_HEAVY;
+    if (m_prev < 0) return M3D_NN_HEAVY;
     int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
     float bound = dmax2 * 1.0001f;
-    if (m_prev >= 0) {
+    bool seeded = false;
+    {
         const float4 c4 = m3d_ld(pts, (size_t)m_prev);
         const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
         const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        const float reach = 0.99f * g.leaf;
+        const float reach = seed_reach * g.leaf;   // <= 0.99: closer than one voxel edge => inside the neighbourhood
         if (dd < reach * reach) {
+            seeded = true;
             best = m_prev; bd = dd; boi = __float_as_uint(c4.w) & ~M3D_LAST_FLAG;
             bound = fminf(bound, bd * 1.0001f);
 #pragma unroll
@@ -443,9 +460,96 @@ __device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_g
             }
         }
     }
+    if (!seeded) return M3D_NN_HEAVY;
     if (Q.lo[0] > Q.hi[0] || Q.lo[1] > Q.hi[1] || Q.lo[2] > Q.hi[2]) return (best >= 0 && bd <= dmax2) ? best : -1;
     const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
     const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+    // Compact per-lane bucket list: the loop runs max-over-lanes(#buckets) times, not 8 — after seeding most
+    // lanes need 1-2 buckets, and a fully unrolled 2x2x2 walk would make every wave pay for all 8.
+    const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
+    const int shy = nbx, shz = nbx + nby;                 // bit positions of the y / z choice inside the bucket counter
+    uint4 lo_n = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi_n = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t key_n = m3d_bucket_key(g, b0x, b0y, b0z);
+    {   // prefetch bucket 0
+        const uint32_t slot = m3d_hash_slot(key_n, g.hshift);
+        lo_n = m3d_ld(tab, 2 * (size_t)slot); hi_n = m3d_ld(tab, 2 * (size_t)slot + 1);
+    }
+    for (int bi = 0; bi < nb; bi++) {
+        uint4 lo = lo_n, hi = hi_n; const uint32_t key = key_n;
+        const int ox = bi & nbx, oy = (bi >> shy) & nby, oz = (bi >> shz) & nbz;
+        if (bi + 1 < nb) {   // software pipelining: the next bucket's entry is in flight while this one is walked
+            const int b2 = bi + 1;
+            key_n = m3d_bucket_key(g, b0x + (b2 & nbx), b0y + ((b2 >> shy) & nby), b0z + ((b2 >> shz) & nbz));
+            const uint32_t slot = m3d_hash_slot(key_n, g.hshift);
+            lo_n = m3d_ld(tab, 2 * (size_t)slot); hi_n = m3d_ld(tab, 2 * (size_t)slot + 1);
+        }
+        if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+            uint32_t slot = m3d_hash_slot(key, g.hshift);
+            do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
+            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
+        }
+        if (lo.x != key) continue;
+        // voxels of this bucket inside the neighbourhood: a sub-box, per axis [s0, s1] with s in {0,1}
+        const int vx0 = 2 * (b0x + ox), vy0 = 2 * (b0y + oy), vz0 = 2 * (b0z + oz);
+        const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
+        const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
+        const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
+        const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
+        const float gx2 = gx * gx;
+        const uint32_t base = lo.y;
+        const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
+        // the (y,z) rows of the sub-box; the x-adjacent voxels of a row are adjacent runs: one merged range
+        for (int sz = sz0; sz <= sz1; sz++) {
+            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
+            for (int sy = sy0; sy <= sy1; sy++) {
+                const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
+                if (gx2 + gy * gy + gz * gz > bound) continue;
+                const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
+                uint32_t c0, c1;
+                if (lo.w == 0) {
+                    c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
+                    const int sm = s_first - 1;
+                    c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
+                } else {
+                    const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
+                    c1 = bc[s_last];
+                    c0 = s_first ? bc[s_first - 1] : 0u;
+                }
+                const uint32_t t1 = base + c1;
+                for (uint32_t t = base + c0; t < t1; t += 4) {
+                    // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
+                    float4 c4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
+                        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                        const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
+                        if (best < 0 || dd < bd || (dd == bd && oi < boi)) { best = (int)min(t + k, t1 - 1); bd = dd; boi = oi; }
+                    }
+                }
+                bound = fminf(bound, bd * 1.0001f);
+            }
+        }
+    }
+    if (best < 0 || !(bd <= dmax2)) return -1;
+    return best;
+}
+
+// FULL search (no seed): all (up to eight) bucket entries are requested before the first one is used.
+// Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
+// always with every lane of the wave doing the same amount of work.
+__device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
+                                             float dmax2, long long& cache_out) {
+    M3dQuery Q;
+    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
+    cache_out = m3d_voxel_code(Q);
+    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+    bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
+    int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
+    float bound = dmax2 * 1.0001f;
     // all (up to eight) bucket entries, both halves, are requested before the first one is used: 16 loads in flight
     uint4 lo[8], hi[8]; uint32_t key[8]; bool act[8];
 #pragma unroll
@@ -481,9 +585,6 @@ __device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_g
         for (int r = 0; r < 4; r++) {
             const int sy = r & 1, sz = r >> 1;
             if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
-            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
-            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
-            if (gx2 + gy * gy + gz * gz > bound) continue;
             uint32_t c0, c1;
             if (!big) {
                 const uint32_t w = (r == 0) ? hi[b].x : (r == 1 ? hi[b].y : (r == 2 ? hi[b].z : hi[b].w));
@@ -495,6 +596,10 @@ __device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_g
                 c1 = bc[2 * r + sx1];
                 c0 = (2 * r + sx0) ? bc[2 * r + sx0 - 1] : 0u;
             }
+            any_point = any_point || (c1 > c0);
+            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
+            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
+            if (gx2 + gy * gy + gz * gz > bound) continue;
             const uint32_t t1 = base + c1;
             for (uint32_t t = base + c0; t < t1; t += 4) {
                 // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
@@ -512,46 +617,95 @@ __device__ __forceinline__ int m3d_nn27_pos(const M3dGrid& g, m3d_gu4 tab, m3d_g
             bound = fminf(bound, bd * 1.0001f);
         }
     }
-    if (best < 0 || !(bd <= dmax2)) return -1;
+    if (best < 0 || !(bd <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
     return best;
 }
 
-__global__ __launch_bounds__(256) void k_nn_search(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
-                                                   int* __restrict__ match, int match_stride) {
-    int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk);
-    const M3dJob& J = jobs[pair];
-    const M3dPairState* st = J.st;
-    if (st->done || (!first_of_level && st->level_done)) return;
-    float R[9], tt[3];
-    m3d_load_pose(st, R, tt);
-    // hoist everything wave-uniform out of the loop (scalar registers), re-type the pointers as global
-    const M3dGrid g = J.tgt.g;
-    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
-    const m3d_gf4 pts = m3d_as_global(J.tgt.pts);
-    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
-    const m3d_gf4 src = m3d_as_global(J.src);
-    const float dmax2 = J.dmax2;
-    const int n = J.n_src;
-    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(match + (size_t)pair * match_stride);
-    for (int i = blk * 256 + threadIdx.x; i < n; i += bpp * 256) {
+// Two kernels per iteration. k_nn_light: one query per thread, seeded light path; lanes that need the
+// full walk append their query index to the pair's worklist (one wave-aggregated atomic per wave, the
+// lanes of a wave stay adjacent in the list). k_nn_heavy: the worklist, densely packed into waves whose
+// lanes all do the same (full) amount of work. On the first iteration of a level there is nothing to
+// seed from: k_nn_heavy runs over all queries in their own (Morton) order and k_nn_light is skipped.
+struct M3dNnArgs {
+    int* match; int match_stride;      // per pair: result of every query (see the encoding above)
+    int* heavy; int heavy_stride;      // per pair: worklist of query indices
+    unsigned int* heavy_cnt;           // per pair: worklist length (reset by k_accumulate_matches)
+    long long* cache;                  // per pair: voxel code of the "-2" verdicts (same stride as match)
+    float seed_reach;                  // seeds farther than this many voxel edges go to the heavy list (<= 0.99)
+};
+
+#define NN_SETUP()                                                                                          \
+    int pair, blk;                                                                                          \
+    m3d_map_block(n_pairs, bpp, pair, blk);                                                                 \
+    const M3dJob& J = jobs[pair];                                                                           \
+    const M3dPairState* st = J.st;                                                                          \
+    if (st->done || (!first_of_level && st->level_done)) return;                                            \
+    float R[9], tt[3];                                                                                      \
+    m3d_load_pose(st, R, tt);                                                                               \
+    const M3dGrid g = J.tgt.g;                                                                              \
+    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));                          \
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts);                                                           \
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);                                                    \
+    const m3d_gf4 src = m3d_as_global(J.src);                                                               \
+    const float dmax2 = J.dmax2;                                                                            \
+    const int n = J.n_src;                                                                                  \
+    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);     \
+    M3D_GLOBAL int* list = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.heavy + (size_t)pair * A.heavy_stride);         \
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+
+__global__ __launch_bounds__(256) void k_nn_light(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    NN_SETUP();
+    const int i = blk * 256 + (int)threadIdx.x;
+    int m = -1;
+    if (i < n) {
         const float4 p = m3d_ld(src, i);
         const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        int m = -1;
-        if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_pos(g, tab, pts, bigcum, ux, uy, uz, dmax2, first_of_level ? -1 : out[i]);
-        out[i] = m;
+        if (m3d_finite3(ux, uy, uz)) {
+            const int mp = out[i];
+            const long long cp = (mp == M3D_NN_NONE_CACHED) ? cache[i] : 0ll;
+            m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, mp, cp, A.seed_reach);
+        }
     }
+    const bool heavy = m == M3D_NN_HEAVY;
+    const unsigned long long hb = __ballot(heavy);
+    if (hb) {   // wave-aggregated append
+        const int lane = threadIdx.x & 63;
+        unsigned int base = 0;
+        if (lane == (int)__builtin_ctzll(hb)) base = atomicAdd(&A.heavy_cnt[pair], (unsigned int)__popcll(hb));
+        base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(hb));
+        if (heavy) list[base + (unsigned int)__popcll(hb & ((1ull << lane) - 1ull))] = i;
+    }
+    if (i < n && !heavy) out[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_nn_heavy(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    NN_SETUP();
+    const int j = blk * 256 + (int)threadIdx.x;
+    const int count = first_of_level ? n : (int)A.heavy_cnt[pair];
+    if (j >= count) return;
+    const int i = first_of_level ? j : list[j];
+    const float4 p = m3d_ld(src, i);
+    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+    int m = -1;
+    long long code = 0;
+    if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_full(g, tab, pts, bigcum, ux, uy, uz, dmax2, code);
+    out[i] = m;
+    if (m == M3D_NN_NONE_CACHED) cache[i] = code;
 }
 
 template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
-                                                                    const int* __restrict__ match, int match_stride) {
+                                                                    const int* __restrict__ match, int match_stride,
+                                                                    unsigned int* __restrict__ heavy_cnt) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk);
     const M3dJob& J = jobs[pair];
     M3dPairState* st = J.st;
+    if (blk == 0 && threadIdx.x == 0) heavy_cnt[pair] = 0u;   // the search kernels of this iteration are done with it
     if (st->done || (!first_of_level && st->level_done)) return;
     float R[9], tt[3];
     m3d_load_pose(st, R, tt);
@@ -734,14 +888,16 @@ static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
 }
 
 static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
-                              int* match, int match_stride) {
+                              const M3dNnWork& w) {
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        hipLaunchKernelGGL(k_nn_search, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, match, match_stride);
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.cache = w.cache; A.seed_reach = w.seed_reach;
+        if (!first_of_level) hipLaunchKernelGGL(k_nn_light, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        hipLaunchKernelGGL(k_nn_heavy, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         int bpp_a = (max_n_src + 256 * 8 - 1) / (256 * 8); if (bpp_a < 1) bpp_a = 1;
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, match, match_stride);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, match, match_stride);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);
         if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
@@ -754,16 +910,16 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     }
 }
 
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant, int* match,
-                                      int match_stride) {
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, 1, variant, match, match_stride);
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
+                                      const M3dNnWork& w) {
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, 1, variant, w);
     return hipGetLastError();
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, int* match, int match_stride, hipEvent_t e0, hipEvent_t e1) {
+                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1) {
     if (e0) (void)hipEventRecord(e0, s);
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, match, match_stride);
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w);
     if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_solve_update, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, first_of_level);
     return hipGetLastError();

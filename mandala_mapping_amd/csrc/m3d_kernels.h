@@ -40,12 +40,19 @@ hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const floa
 
 // icp.hip
 // variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
-//          2 = split: k_nn_search (one int32 match per query into `match`) + k_accumulate_matches (default)
-// match: workspace of n_pairs * match_stride int32 (variant 2)
+//          2 = split (default): k_nn_light + k_nn_heavy (one int32 result per query) + k_accumulate_matches
+struct M3dNnWork {               // variant-2 workspace, all per pair with the same stride
+    int* match;                  // [n_pairs * stride] result of every query, kept between iterations (seeds the next search)
+    int* heavy;                  // [n_pairs * stride] worklist of queries that need the full walk
+    unsigned int* heavy_cnt;     // [n_pairs] worklist lengths (zeroed at batch start, reset by k_accumulate_matches)
+    long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
+    int stride;
+    float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
+};
 // e0/e1 (optional): events recorded immediately before / after the launch(es) of the linearisation
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, int* match, int match_stride, hipEvent_t e0, hipEvent_t e1);
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant, int* match,
-                                      int match_stride);
+                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1);
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
+                                      const M3dNnWork& w);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

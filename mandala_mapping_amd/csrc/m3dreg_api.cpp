@@ -88,10 +88,14 @@ struct m3dreg_handle {
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
+    float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
-    int* d_match = nullptr;            // [match_pairs * match_stride] NN result per query (variant 2)
+    int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
+    unsigned int* d_heavy_cnt = nullptr;
     size_t match_cap = 0;
+    size_t match_pairs_cap = 0;
     int match_stride = 0;
+    size_t match_pairs = 0;
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -463,11 +467,28 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         if (h->d_match) hipFree(h->d_match);
         h->d_match = nullptr; h->match_cap = 0;
         const size_t cap = n_pairs * stride + n_pairs * stride / 4;
-        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * cap));
+        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // match | heavy list | cache (int64)
         h->match_cap = cap;
     }
+    if (n_pairs > h->match_pairs_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_heavy_cnt) hipFree(h->d_heavy_cnt);
+        h->d_heavy_cnt = nullptr;
+        HIPCHK(h, hipMalloc((void**)&h->d_heavy_cnt, sizeof(unsigned int) * (n_pairs + 8)));
+        h->match_pairs_cap = n_pairs + 8;
+    }
     h->match_stride = int(stride);
+    h->match_pairs = n_pairs;
+    HIPCHK(h, hipMemsetAsync(h->d_heavy_cnt, 0, sizeof(unsigned int) * n_pairs, h->stream));
     return M3DREG_OK;
+}
+
+M3dNnWork nn_work(const m3dreg_handle* h) {
+    M3dNnWork w;
+    w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride;
+    w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
+    w.seed_reach = h->seed_reach;
+    return w;
 }
 
 int validate_params(const m3dreg_params* p) {
@@ -576,6 +597,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
+    if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
     else {
@@ -594,7 +616,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match }) if (p) hipFree(p);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_heavy_cnt }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -661,7 +683,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
         for (int it = 0; it < P.iterations[l]; it++) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->profiling) { e0 = next_event(h); e1 = next_event(h); }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, h->d_match, h->match_stride, e0, e1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), e0, e1));
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
@@ -817,7 +839,7 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     const M3dJob* hj = &h->h_jobs[size_t(level) * h->cap_pairs];
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, hj, sizeof(M3dJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, h->icp_variant, h->d_match, h->match_stride));
+    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, h->icp_variant, nn_work(h)));
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const long long* raw = h->h_states[0].sums;
