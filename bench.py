@@ -8,11 +8,12 @@ decode + exact AABB + voxel bucketing + normals of BOTH clouds, then --iters poi
 iterations (0.1 m voxel NN), then the pose read-back; with N > 1 the poses of all ranks are gathered
 over RCCL (one all_gather per step — the only collective; pairs never exchange data).
 
-Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_icp_accumulate: transform +
-27-voxel NN + residual + 29-term reduction for every pair of the batch in one launch) by its
-algorithmic bytes over its average launch duration, taken from hipEvents the library
-records on its stream around every launch inside the timed region. `cpu_baseline` is the CPU oracle
-(OpenMP build) timed on a bounded sample of the same workload on this host's cores.
+Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_light: source transform +
+exact 27-voxel nearest-neighbour search of every query of every pair of the batch in one launch, seeded
+by the previous iteration) by its algorithmic bytes (NN part: 12 N + 12 M + 8 C_occ per
+pair) over its average launch duration, taken from hipEvents the library records on its stream around
+every launch of that kernel inside the timed region. `cpu_baseline` is the CPU oracle (OpenMP build)
+timed on a bounded sample of the same workload on this host's cores.
 """
 import argparse
 import ctypes as C
@@ -98,10 +99,12 @@ def main():
 
     # algorithmic bytes of one launch of the dominant kernel, from the real clouds
     clouds0 = step()
-    alg_bytes = 0
+    alg_bytes = 0       # NN kernel: source xyz + target xyz + occupied-voxel table, each touched once
+    alg_bytes_iter = 0  # whole linearisation: + target normals (point-to-plane)
     for (s, t) in clouds0:
         g = t.grid_info()
-        alg_bytes += 12 * s.n + 12 * t.n + 8 * g.n_cells + 12 * t.n
+        alg_bytes += 12 * s.n + 12 * t.n + 8 * g.n_cells
+        alg_bytes_iter += 12 * s.n + 12 * t.n + 8 * g.n_cells + 12 * t.n
     n_pts = int(np.mean([s.n for s, _ in clouds0]))
     del clouds0
     last.clear()
@@ -115,14 +118,16 @@ def main():
         torch.cuda.synchronize()
 
     reg.profile_enable(True)
-    reg.profile_read(reset=True)
+    reg.profile_read(0, reset=True)
+    reg.profile_read(1, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     barrier()
     t1 = time.perf_counter()
-    launches, kern_ms = reg.profile_read(reset=True)
+    launches, kern_ms = reg.profile_read(1, reset=True)       # k_nn_light alone
+    iters_timed, iter_ms = reg.profile_read(0, reset=True)    # search + reduction of one linearisation
     reg.profile_enable(False)
     elapsed = t1 - t0
     if world > 1:
@@ -143,7 +148,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_icp_accumulate", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("k_nn_light", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -156,10 +161,11 @@ def main():
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step"},
-            "ms_per_icp_iter_batch": 1e3 * avg_launch_s,
-            "ms_per_icp_iter_per_pair": 1e3 * avg_launch_s / B,
-            "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr, "lds_chunks_vs_fallback_pair0": list(reg.counters()),
-            "roofline": {"bound": "hbm", "kernel": "k_icp_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
+            "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
+            "iteration_algorithmic_GBps": alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9,
+            "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
+            "roofline": {"bound": "hbm", "kernel": "k_nn_light", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
         }

@@ -152,13 +152,16 @@ int m3dreg_synchronize(m3dreg_handle* h);
 void* m3dreg_get_stream(m3dreg_handle* h);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* When enabled, every launch of the dominant kernel (the fused NN + residual + reduction kernel,
- * `k_icp_accumulate`) is bracketed by two hipEvents recorded on the handle's stream, so bench.py can
- * report that kernel's average launch duration from inside its timed region. */
+/* When enabled, hipEvents are recorded on the handle's stream (a) around all launches of every
+ * linearisation (NN search + residual reduction of the whole batch) and (b) around every launch of the
+ * dominant kernel alone (`k_nn_light`, the seeded NN search; the first iteration of a level runs only
+ * `k_nn_heavy`), so bench.py can report that kernel's average launch duration from inside its timed region. */
 int m3dreg_profile_enable(m3dreg_handle* h, int on);
-/* Synchronises the stream, returns the number of bracketed launches and the sum of their durations
- * since the last reset; `reset` != 0 clears the counters. */
-int m3dreg_profile_read(m3dreg_handle* h, uint64_t* n_launches, double* total_ms, int reset);
+#define M3DREG_PROFILE_ITERATION 0
+#define M3DREG_PROFILE_DOMINANT_KERNEL 1
+/* Synchronises the stream, returns the number of bracketed launches of kind `what` and the sum of their
+ * durations since the last reset; `reset` != 0 clears that kind's counters. */
+int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset);
 
 /* ---- introspection used by the parity tests (stage-by-stage comparison with oracle/) -------- */
 typedef struct m3dreg_grid_info {

@@ -72,7 +72,7 @@ def lib():
     L.m3dreg_debug_trace.argtypes = [vp, f64p, sz, C.POINTER(sz)]
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
-    L.m3dreg_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), f64p, C.c_int]
+    L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
     if L.m3dreg_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libm3dreg.so ABI version mismatch")
     _lib = L
@@ -175,10 +175,11 @@ class Registrar:
     def profile_enable(self, on=True):
         self._check(lib().m3dreg_profile_enable(self._h, 1 if on else 0), "profile_enable")
 
-    def profile_read(self, reset=True):
-        """(launches, total ms) of the dominant kernel since the last reset, from hipEvents on the stream."""
+    def profile_read(self, what=1, reset=True):
+        """(launches, total ms) since the last reset, from hipEvents on the stream.
+        what = 0: whole linearisations (search + reduction); what = 1: the dominant kernel (k_nn_light) alone."""
         n, ms = C.c_uint64(0), C.c_double(0.0)
-        self._check(lib().m3dreg_profile_read(self._h, C.byref(n), C.byref(ms), 1 if reset else 0), "profile_read")
+        self._check(lib().m3dreg_profile_read(self._h, what, C.byref(n), C.byref(ms), 1 if reset else 0), "profile_read")
         return n.value, ms.value
 
     # ---- clouds -------------------------------------------------------------------------------

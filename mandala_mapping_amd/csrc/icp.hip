@@ -888,12 +888,16 @@ static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
 }
 
 static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
-                              const M3dNnWork& w) {
+                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr) {
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
         M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.cache = w.cache; A.seed_reach = w.seed_reach;
-        if (!first_of_level) hipLaunchKernelGGL(k_nn_light, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        if (!first_of_level) {
+            if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
+            hipLaunchKernelGGL(k_nn_light, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            if (k1) (void)hipEventRecord(k1, s);
+        }
         hipLaunchKernelGGL(k_nn_heavy, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         int bpp_a = (max_n_src + 256 * 8 - 1) / (256 * 8); if (bpp_a < 1) bpp_a = 1;
         if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
@@ -917,9 +921,9 @@ hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1) {
+                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
     if (e0) (void)hipEventRecord(e0, s);
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w);
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1);
     if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_solve_update, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, first_of_level);
     return hipGetLastError();

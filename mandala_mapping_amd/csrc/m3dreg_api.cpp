@@ -99,9 +99,10 @@ struct m3dreg_handle {
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_kind;          // per recorded pair: 0 = whole linearisation, 1 = dominant kernel (k_nn_light)
     size_t ev_used = 0;
-    uint64_t prof_launches = 0;
-    double prof_ms = 0.0;
+    uint64_t prof_launches[2] = { 0, 0 };
+    double prof_ms[2] = { 0.0, 0.0 };
 };
 
 namespace {
@@ -551,9 +552,11 @@ hipEvent_t next_event(m3dreg_handle* h) {
 void drain_events(m3dreg_handle* h) {
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { h->prof_ms += double(ms); h->prof_launches++; }
+        const int kind = h->ev_kind[i / 2];
+        if (hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { h->prof_ms[kind] += double(ms); h->prof_launches[kind]++; }
     }
     h->ev_used = 0;
+    h->ev_kind.clear();
 }
 
 void stats_from_state(const M3dPairState& S, m3dreg_stats* st) {
@@ -681,9 +684,12 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     for (int l = 0; l < P.n_levels; l++) {
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
         for (int it = 0; it < P.iterations[l]; it++) {
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (h->profiling) { e0 = next_event(h); e1 = next_event(h); }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), e0, e1));
+            hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
+            if (h->profiling) {
+                e0 = next_event(h); e1 = next_event(h); h->ev_kind.push_back(0);
+                if (it > 0 && h->icp_variant == 2) { k0 = next_event(h); k1 = next_event(h); h->ev_kind.push_back(1); }
+            }
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), e0, e1, k0, k1));
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
@@ -751,13 +757,13 @@ int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     return M3DREG_OK;
 }
 
-int m3dreg_profile_read(m3dreg_handle* h, uint64_t* n_launches, double* total_ms, int reset) {
-    if (!h) return M3DREG_ERR_INVALID_ARG;
+int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset) {
+    if (!h || what < 0 || what > 1) return M3DREG_ERR_INVALID_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drain_events(h);
-    if (n_launches) *n_launches = h->prof_launches;
-    if (total_ms) *total_ms = h->prof_ms;
-    if (reset) { h->prof_launches = 0; h->prof_ms = 0.0; }
+    if (n_launches) *n_launches = h->prof_launches[what];
+    if (total_ms) *total_ms = h->prof_ms[what];
+    if (reset) { h->prof_launches[what] = 0; h->prof_ms[what] = 0.0; }
     return M3DREG_OK;
 }
 
