@@ -46,7 +46,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from mandala_mapping_amd import abi, binding, synth
+    from mandala_mapping_amd import abi, binding, sharding, synth
     from mandala_mapping_amd.pointcloud2 import encode_xyz
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,8 +79,6 @@ def main():
         if rank == 0 and i < 8:
             host_pairs.append((src, tgt))
     torch.cuda.synchronize()
-    pose_buf = torch.zeros((B, 16), dtype=torch.float32, device=dev)
-    gathered = [torch.zeros_like(pose_buf) for _ in range(world)] if world > 1 else None
 
     last = {}
 
@@ -91,9 +89,9 @@ def main():
         cl = reg.clouds_from_device(items)          # all 2B clouds bucketed by one batched pipeline
         clouds = [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
         T, st = reg.align_batch([(s, t, None) for s, t in clouds])
-        if world > 1:
-            pose_buf.copy_(torch.from_numpy(np.ascontiguousarray(T.reshape(B, 16), np.float32)))
-            dist.all_gather(gathered, pose_buf)
+        if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI)
+            allT, allst = sharding.gather_results([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, dev)
+            last["all"] = (allT, allst)
         last["T"], last["st"], last["clouds"] = T, st, clouds
         return clouds
 

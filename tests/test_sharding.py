@@ -1,0 +1,93 @@
+"""The N > 1 host path on CPU: LPT sharding + the single pose all_gather, world_size 2 over gloo.
+The per-rank registration function is the CPU oracle here (tests may use it); on the GPU box bench.py runs
+the same sharding code with Registrar.align_batch per rank over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from mandala_mapping_amd import sharding
+
+
+def test_lpt_assignment_properties():
+    costs = [100, 90, 80, 10, 10, 10, 5, 5]
+    sh = sharding.lpt_assign(costs, 3)
+    assert sorted(i for s in sh for i in s) == list(range(8))
+    loads = [sum(costs[i] for i in s) for s in sh]
+    assert max(loads) - min(loads) <= 20
+    # pairs sharing a target stay together
+    sh = sharding.lpt_assign([10] * 6, 2, groups=[0, 0, 1, 1, 2, 2])
+    for s in sh:
+        for gpair in ((0, 1), (2, 3), (4, 5)):
+            assert (gpair[0] in s) == (gpair[1] in s)
+    assert sharding.lpt_assign([], 4) == [[], [], [], []]
+    assert sharding.lpt_assign([1.0], 1) == [[0]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mandala_mapping_amd import abi, synth
+    from oracle import orc
+    p = abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    pairs, costs = [], []
+    for k in range(5):
+        tgt = synth.planes_cloud(1500 + 400 * k, 50 + k)
+        Tg = synth.random_T(np.random.default_rng(k), 2.0, 0.1)
+        src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(1200 + 300 * k, 80 + k)).astype(np.float32)
+        pairs.append((src, tgt))
+        costs.append(len(src) + len(tgt))
+
+    def local(idx):
+        Ts, sts = [], []
+        for i in idx:
+            T, st, _ = orc.align(p, orc.Cloud(p, pairs[i][0]), orc.Cloud(p, pairs[i][1]))
+            Ts.append(T)
+            sts.append(st.status)
+        return np.stack(Ts), sts
+
+    T, st = sharding.register_sharded(pairs, costs, local, dist)
+    mine = sharding.lpt_assign(costs, world)[rank]
+    q.put((rank, T, st, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    (_, T0, st0, m0), (_, T1, st1, m1) = res
+    assert np.array_equal(T0, T1) and np.array_equal(st0, st1)          # every rank holds the full result
+    assert sorted(m0 + m1) == list(range(5)) and m0 and m1               # work was really split
+    assert (st0 >= 0).all()
+    # and it equals the single-process result
+    from mandala_mapping_amd import abi, synth
+    from oracle import orc
+    p = abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    k = 3
+    tgt = synth.planes_cloud(1500 + 400 * k, 50 + k)
+    Tg = synth.random_T(np.random.default_rng(k), 2.0, 0.1)
+    src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(1200 + 300 * k, 80 + k)).astype(np.float32)
+    T, _, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    assert np.array_equal(T0[k], T)
