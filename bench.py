@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--iters", type=int, default=20, help="fixed Gauss-Newton iterations per registration")
     ap.add_argument("--azimuth", type=int, default=3125, help="azimuth steps per sweep (x32 beams = points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="hand over HOST PointCloud2 buffers every step (PCIe-inclusive rate; reported in DESIGN.md, never the headline)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
 
@@ -68,13 +71,14 @@ def main():
     reg = binding.Registrar(params, device=local_rank, stream=C.c_void_p(stream.cuda_stream))
 
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
-    payloads, gts, host_pairs = [], [], []
+    payloads, gts, host_pairs, host_msgs = [], [], [], []
     for i in range(B):
         src, tgt, Tgt = synth.config4_pair(rank * B + i, args.azimuth)
         ms, mt = encode_xyz(src), encode_xyz(tgt)
         ds = torch.frombuffer(bytearray(ms.data), dtype=torch.uint8).to(dev)
         dt = torch.frombuffer(bytearray(mt.data), dtype=torch.uint8).to(dev)
         payloads.append((ds, ms.n, dt, mt.n))
+        host_msgs += [ms, mt]
         gts.append(Tgt)
         if rank == 0 and i < 8:
             host_pairs.append((src, tgt))
@@ -83,10 +87,13 @@ def main():
     last = {}
 
     def step():
-        items = []
-        for ds, ns, dt, nt in payloads:
-            items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
-        cl = reg.clouds_from_device(items)          # all 2B clouds bucketed by one batched pipeline
+        if args.from_host:
+            cl = reg.clouds(host_msgs)              # host buffers cross PCIe inside the timed region
+        else:
+            items = []
+            for ds, ns, dt, nt in payloads:
+                items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
+            cl = reg.clouds_from_device(items)      # all 2B clouds bucketed by one batched pipeline
         clouds = [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
         T, st = reg.align_batch([(s, t, None) for s, t in clouds])
         if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI)
@@ -168,19 +175,21 @@ def main():
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, host_pairs, args.iters)
+            out["cpu_baseline"] = cpu_baseline(params, host_pairs, args.iters, args.cpu_threads)
+        if args.from_host:
+            out["data"] = "synthetic (host PointCloud2 buffers: PCIe-inclusive, not the headline configuration)"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(params, host_pairs, iters):
+def cpu_baseline(params, host_pairs, iters, threads=0):
     """The CPU oracle (OpenMP build: normals and the per-point NN/accumulate loop are parallel, the sort
     and the 6x6 solve are serial) on a bounded sample of the same pairs."""
     from oracle import orc
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = threads or min(os.cpu_count() or 1, 64)   # beyond ~64 threads the per-iteration fork/join outweighs the work
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     orc.build()
     done, t0 = 0, time.perf_counter()
     for src, tgt in host_pairs:

@@ -1,0 +1,129 @@
+// gpu_6dslam_node.cpp — SOURCE-ONLY ROS1 shim (catkin package `gpu_6dslam`, executable `gpu_6dslam_node`).
+//
+// This is the node the reference launches at
+//   /root/reference/m3d/m3d_husky_launch/launch/m3d_husky_bringup.launch:13
+//     <node pkg="gpu_6dslam" type="gpu_6dslam_node" name="gpu_6dslam_node" />
+// and whose own source is absent from the reference (gpu_6dslam/ is an empty, un-vendored submodule).
+// It cannot be compiled or run in this repository's environments (no ROS, no PCL, no Eigen anywhere:
+// SURVEY.md §0 F7); it is kept short on purpose — everything of substance happens behind the C ABI of
+// include/m3dreg.h — and is reviewed, not executed. Build it inside a catkin workspace with
+//   find_package(catkin REQUIRED COMPONENTS roscpp sensor_msgs geometry_msgs tf)
+//   target_link_libraries(gpu_6dslam_node ${catkin_LIBRARIES} m3dreg)
+//
+// Topic contract (what the producer publishes, all under the aggregator's private namespace):
+//   ~cloud    sensor_msgs/PointCloud2, queue 1   m3d/m3d_aggregator/src/m3d_aggregator.cpp:174,209
+//   ~done     std_msgs/Bool, published right BEFORE each cloud          :206-208
+//   ~progress std_msgs/Float32                                          :190-192
+// resolved as /m3d_test/aggregator/{cloud,done,progress} (universal.launch:15,45; the joystick remap
+// in m3d_husky_bringup.launch:10 confirms the /m3d_test/aggregator prefix). The message is
+// pcl::toPCLPointCloud2 of pcl::PointXYZ (:196-201): point_step 16, FLOAT32 x@0 y@4 z@8, unorganised,
+// frame_id = pointCloudFrame (default m3d_test/m3d_link, :152,:203).
+#include <cstring>
+#include <string>
+
+#include <geometry_msgs/PoseStamped.h>
+#include <ros/ros.h>
+#include <sensor_msgs/PointCloud2.h>
+#include <tf/transform_broadcaster.h>
+
+#include "m3dreg.h"
+
+class Gpu6dSlamNode {
+public:
+    Gpu6dSlamNode() : nh_("~"), have_target_(false) {
+        std::string cloud_topic;
+        nh_.param<std::string>("cloud", cloud_topic, "/m3d_test/aggregator/cloud");
+        nh_.param<std::string>("odom_frame", odom_frame_, "m3d_test/odom");
+        m3dreg_params p;
+        m3dreg_default_params(&p);
+        double leaf = p.leaf[0], dmax = p.max_corr_dist[0], normal_leaf = p.normal_leaf;
+        int iters = p.iterations[0], device = 0;
+        nh_.param("leaf", leaf, leaf);
+        nh_.param("max_corr_dist", dmax, dmax);
+        nh_.param("normal_leaf", normal_leaf, normal_leaf);
+        nh_.param("iterations", iters, iters);
+        nh_.param("device", device, device);
+        p.leaf[0] = float(leaf); p.max_corr_dist[0] = float(dmax); p.normal_leaf = float(normal_leaf); p.iterations[0] = iters;
+        int rc = m3dreg_create(&p, device, nullptr, &h_);
+        if (rc != M3DREG_OK) {   // same policy as the reference's drivers: fatal + exit (encoder_node_li.cpp:60-80)
+            ROS_FATAL("m3dreg_create failed (%d): no usable MI355X; there is no CPU fallback", rc);
+            ros::shutdown();
+            return;
+        }
+        for (int i = 0; i < 16; i++) { pose_[i] = (i % 5 == 0) ? 1.f : 0.f; delta_[i] = pose_[i]; }
+        pose_pub_ = nh_.advertise<geometry_msgs::PoseStamped>("pose", 1);
+        sub_ = nh_.subscribe(cloud_topic, 1, &Gpu6dSlamNode::onCloud, this);   // queue depth 1, like the producer
+    }
+    ~Gpu6dSlamNode() { if (h_) m3dreg_destroy(h_); }
+
+private:
+    // byte offsets of the FLOAT32 x/y/z fields (the aggregator always sends 0/4/8 in a 16-byte point)
+    static bool xyzOffsets(const sensor_msgs::PointCloud2& m, size_t off[3]) {
+        int found = 0;
+        for (const auto& f : m.fields) {
+            int a = f.name == "x" ? 0 : f.name == "y" ? 1 : f.name == "z" ? 2 : -1;
+            if (a < 0) continue;
+            if (f.datatype != sensor_msgs::PointField::FLOAT32 || f.count != 1) return false;
+            off[a] = f.offset; found |= 1 << a;
+        }
+        return found == 7 && !m.is_bigendian;
+    }
+
+    void onCloud(const sensor_msgs::PointCloud2ConstPtr& msg) {
+        size_t off[3];
+        const size_t n = size_t(msg->width) * msg->height;
+        if (n == 0 || !xyzOffsets(*msg, off)) { ROS_WARN("unsupported PointCloud2 layout"); return; }
+        if (have_target_) {
+            float T[16]; m3dreg_stats st;
+            // the raw message buffer crosses the C ABI as is: no PCL conversion, no copy on the host
+            int rc = m3dreg_align(h_, msg->data.data(), n, msg->point_step, off[0], off[1], off[2], delta_, T, &st);
+            if (rc != M3DREG_OK) { ROS_WARN("m3dreg_align: %s", m3dreg_last_error(h_)); }   // logged and swallowed, m3d_aggregator.cpp:239-241
+            else if (st.status == M3DREG_CONVERGED || st.status == M3DREG_MAX_ITERATIONS) {
+                std::memcpy(delta_, T, sizeof(T));   // constant-velocity prior for the next sweep
+                float P[16];                          // pose <- pose * T  (column-major 4x4, Eigen::Matrix4f layout)
+                for (int c = 0; c < 4; c++)
+                    for (int r = 0; r < 4; r++) {
+                        float s = 0.f;
+                        for (int k = 0; k < 4; k++) s += pose_[k * 4 + r] * T[c * 4 + k];
+                        P[c * 4 + r] = s;
+                    }
+                std::memcpy(pose_, P, sizeof(P));
+                publish(msg->header);
+            } else {
+                ROS_WARN("registration rejected: status %d after %d iterations", st.status, st.iterations);
+            }
+        }
+        // the new sweep becomes the target of the next registration (scan-to-scan odometry)
+        int rc = m3dreg_set_target_xyz(h_, msg->data.data(), n, msg->point_step, off[0], off[1], off[2]);
+        have_target_ = (rc == M3DREG_OK);
+        if (!have_target_) ROS_WARN("m3dreg_set_target_xyz: %s", m3dreg_last_error(h_));
+    }
+
+    void publish(const std_msgs::Header& hdr) {
+        tf::Matrix3x3 R(pose_[0], pose_[4], pose_[8], pose_[1], pose_[5], pose_[9], pose_[2], pose_[6], pose_[10]);
+        tf::Transform t(R, tf::Vector3(pose_[12], pose_[13], pose_[14]));
+        br_.sendTransform(tf::StampedTransform(t, hdr.stamp, odom_frame_, hdr.frame_id));
+        geometry_msgs::PoseStamped ps;
+        ps.header.stamp = hdr.stamp; ps.header.frame_id = odom_frame_;
+        tf::Quaternion q; R.getRotation(q);
+        ps.pose.position.x = pose_[12]; ps.pose.position.y = pose_[13]; ps.pose.position.z = pose_[14];
+        ps.pose.orientation.x = q.x(); ps.pose.orientation.y = q.y(); ps.pose.orientation.z = q.z(); ps.pose.orientation.w = q.w();
+        pose_pub_.publish(ps);
+    }
+
+    ros::NodeHandle nh_;
+    ros::Subscriber sub_;
+    ros::Publisher pose_pub_;
+    tf::TransformBroadcaster br_;
+    std::string odom_frame_;
+    m3dreg_handle* h_ = nullptr;
+    bool have_target_;
+    float pose_[16], delta_[16];
+};
+
+int main(int argc, char** argv) {
+    ros::init(argc, argv, "gpu_6dslam_node");
+    Gpu6dSlamNode node;
+    ros::spin();   // single-threaded, callbacks serialised — same threading model as the producer (m3d_aggregator.cpp:185)
+    return 0;
+}
