@@ -186,9 +186,10 @@ def config4_pair(k, n_azimuth=3125):
 
 
 def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
-    """(live scan, map, T_gt): map = n_scans sweeps along a 10 m straight trajectory merged in the frame
-    of the first sweep and de-duplicated on a `dedup` grid (~2 M points at the defaults); live scan = one
-    more sweep 0.3 m / 2 deg off the trajectory's midpoint."""
+    """(live scan, map, T_gt, T_init): map = n_scans sweeps along a 10 m straight trajectory merged in the
+    frame of the first sweep and de-duplicated on a `dedup` grid (~2 M points at the defaults); live scan =
+    one more sweep 0.3 m / 0.2 m / 2 deg off the trajectory's midpoint; T_init = the midpoint pose itself (the
+    odometry prior a map-based localiser starts from)."""
     P0 = sensor_pose(-5.0, 0.0, 0.0)
     parts = []
     for i in range(n_scans):
@@ -203,7 +204,7 @@ def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
         m = m[np.sort(first)]
     Pl = sensor_pose(0.3, 0.2, 2.0)
     live = hdl32_scan(Pl, n_azimuth, 777)
-    return live, m.astype(np.float32), inv_T(P0) @ Pl
+    return live, m.astype(np.float32), inv_T(P0) @ Pl, inv_T(P0) @ sensor_pose(0.0, 0.0, 0.0)
 
 
 def perturb(T, rng, deg, trans):

@@ -226,3 +226,70 @@ def test_batched_bucketing_equals_single(reg, orc):
         o = orc.Cloud(p, a)
         _check_bucketing(c, o, 2)
         _check_bucketing(R.cloud(a), o, 2)
+
+
+def test_config2_hdl32_point_to_point(reg, orc):
+    """BASELINE config 2: single HDL-32 scan pair (70 016 rays), point-to-point, 1 x MI355X — bit-exact vs the oracle."""
+    src, tgt, Tgt = synth.config2()
+    p = _params(leaf=0.2, iterations=30, max_corr_dist=1.0, metric=abi.POINT_TO_POINT)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([src, tgt])
+    T1, st1 = R.align(cs, ct)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True), orc.Cloud(p, tgt, omp=True), trace_cap=64)
+    assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+    # point-to-point slides along the walls (textbook behaviour): it must at least reduce the error monotonically enough
+    e0, e1 = synth.pose_error(np.eye(4), Tgt), synth.pose_error(T1, Tgt)
+    assert e1[0] < e0[0] and e1[1] < e0[1]
+
+
+def test_config5_dense_map_multiresolution(reg, orc):
+    """BASELINE config 5 (reduced to 5 sweeps = ~0.5 M map points so the oracle finishes in seconds):
+    live scan against a merged map, leaf 0.4 -> 0.2 -> 0.1, bit-exact vs the oracle."""
+    live, mp, Tgt, T0 = synth.config5(n_scans=5)
+    p = _params(leaf=(0.4, 0.2, 0.1), iterations=(10, 10, 10), max_corr_dist=(1.0, 0.5, 0.3), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([live, mp])
+    _check_bucketing(ct, orc.Cloud(p, mp, omp=True), 3)
+    T1, st1 = R.align(cs, ct, T0)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, live, omp=True), orc.Cloud(p, mp, omp=True), T0, trace_cap=64)
+    assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+    rot, tra = synth.pose_error(T1, Tgt)
+    assert rot < 0.05 and tra < 0.01, (rot, tra)
+
+
+def test_config5_full_size_properties(reg):
+    """BASELINE config 5 at full size: ~2 M-point map vs 100 k live scan, multi-resolution voxel NN."""
+    live, mp, Tgt, T0 = synth.config5()
+    assert len(mp) > 1_500_000
+    p = _params(leaf=(0.4, 0.2, 0.1), iterations=(10, 10, 10), max_corr_dist=(1.0, 0.5, 0.3), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([live, mp])
+    e = ct.export(2)
+    assert (np.diff(e["sorted_keys"].astype(np.int64)) >= 0).all()
+    assert np.array_equal(np.sort(e["perm"]), np.arange(len(mp)))
+    T, st = R.align(cs, ct, T0)
+    rot, tra = synth.pose_error(T, Tgt)
+    assert st.status in (abi.CONVERGED, abi.MAX_ITERATIONS) and rot < 0.05 and tra < 0.01, (rot, tra, st.as_dict())
+    T2, _ = R.align(cs, ct, T0)
+    assert np.array_equal(T, T2)
+
+
+def test_degenerate_clouds(reg, orc):
+    """All points identical (one voxel, one huge bucket), a single point, and two far-apart points."""
+    p = _params(leaf=0.1, iterations=3, metric=abi.POINT_TO_POINT)
+    R = reg.Registrar(p)
+    same = np.tile(np.float32([1.0, 2.0, 3.0]), (70000, 1))     # > 65535 points in one bucket: the bigcum path
+    c, o = R.cloud(same), orc.Cloud(p, same)
+    _check_bucketing(c, o, 1)
+    q = np.float32([[1.0, 2.0, 3.05], [1.2, 2.0, 3.0]])
+    i1, d1 = c.nn(q, 0.5)
+    i2, d2 = o.nn(q, 0.5)
+    assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32)) and i1[0] == 0
+    one = np.float32([[0.5, 0.5, 0.5]])
+    _check_bucketing(R.cloud(one), orc.Cloud(p, one), 1)
+    two = np.float32([[0, 0, 0], [50, 40, 3]])
+    _check_bucketing(R.cloud(two), orc.Cloud(p, two), 1)
+    T, st = R.align(R.cloud(two), R.cloud(two))
+    assert st.status == abi.TOO_FEW_CORR
