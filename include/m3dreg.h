@@ -199,8 +199,9 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
 /* Per-iteration pose trace of the most recent m3dreg_align/align_clouds on this handle:
  * column-major double[16] after each executed iteration; returns count via *n_out (<= cap). */
 int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out);
-/* Diagnostics of the first pair of the most recent batch: out[0] = 64-query chunks whose voxel box was
- * served from LDS, out[1] = chunks that fell back to the global-memory walk (summed over iterations). */
+/* Diagnostics of the first pair of the most recent batch (default kernel variant): out[0] = queries that
+ * went through the compacted full search after the first iteration of a level (summed over iterations),
+ * out[1] = iterations executed. */
 int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]);
 
 #ifdef __cplusplus

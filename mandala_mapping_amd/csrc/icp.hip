@@ -57,6 +57,17 @@ __device__ __forceinline__ float m3d_voxel_lb2(const M3dQuery& Q, int vx, int vy
 
 struct M3dBest { int found; float d2; uint32_t oi; float4 q; };
 
+// Branch-free argmin step: (d2, input index) packed into one 64-bit key — d2 >= 0, so its float bits order
+// like the value, and the low word breaks ties towards the lowest input index exactly as the spec says.
+// One v_cmp_lt_u64 + three v_cndmask per candidate instead of a saveexec/branch ladder.
+__device__ __forceinline__ void m3d_argmin_step(unsigned long long& bestkey, int& best, float dd, uint32_t oi, int t) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | oi;
+    const bool better = key < bestkey;
+    bestkey = better ? key : bestkey;
+    best = better ? t : best;
+}
+__device__ __forceinline__ float m3d_key_d2(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
+
 __device__ __forceinline__ void m3d_consider(M3dBest& B, const float4& c4, float ux, float uy, float uz) {
     const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
@@ -441,7 +452,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     if (m_prev == M3D_NN_NONE_CACHED) return (m3d_voxel_code(Q) == cache_prev) ? M3D_NN_NONE_CACHED : M3D_NN_HEAVY;
     if (m_prev < 0) return M3D_NN_HEAVY;
-    int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
+    int best = -1; unsigned long long bkey = ~0ull;
     float bound = dmax2 * 1.0001f;
     bool seeded = false;
     {
@@ -451,8 +462,8 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
         const float reach = seed_reach * g.leaf;   // <= 0.99: closer than one voxel edge => inside the neighbourhood
         if (dd < reach * reach) {
             seeded = true;
-            best = m_prev; bd = dd; boi = __float_as_uint(c4.w) & ~M3D_LAST_FLAG;
-            bound = fminf(bound, bd * 1.0001f);
+            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & ~M3D_LAST_FLAG, m_prev);
+            bound = fminf(bound, dd * 1.0001f);
 #pragma unroll
             for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
                 if (Q.gl[a] * Q.gl[a] > bound) Q.lo[a] = max(Q.lo[a], Q.ic[a]);
@@ -461,7 +472,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
         }
     }
     if (!seeded) return M3D_NN_HEAVY;
-    if (Q.lo[0] > Q.hi[0] || Q.lo[1] > Q.hi[1] || Q.lo[2] > Q.hi[2]) return (best >= 0 && bd <= dmax2) ? best : -1;
+    if (Q.lo[0] > Q.hi[0] || Q.lo[1] > Q.hi[1] || Q.lo[2] > Q.hi[2]) return (best >= 0 && m3d_key_d2(bkey) <= dmax2) ? best : -1;
     const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
     const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
     // Compact per-lane bucket list: the loop runs max-over-lanes(#buckets) times, not 8 — after seeding most
@@ -526,14 +537,14 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
                         const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                         const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                         const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
-                        if (best < 0 || dd < bd || (dd == bd && oi < boi)) { best = (int)min(t + k, t1 - 1); bd = dd; boi = oi; }
+                        m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
                     }
                 }
-                bound = fminf(bound, bd * 1.0001f);
+                bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
             }
         }
     }
-    if (best < 0 || !(bd <= dmax2)) return -1;
+    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return -1;
     return best;
 }
 
@@ -548,7 +559,7 @@ __device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_
     const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
     const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
     bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
-    int best = -1; float bd = 3.0e38f; uint32_t boi = 0;
+    int best = -1; unsigned long long bkey = ~0ull;
     float bound = dmax2 * 1.0001f;
     // all (up to eight) bucket entries, both halves, are requested before the first one is used: 16 loads in flight
     uint4 lo[8], hi[8]; uint32_t key[8]; bool act[8];
@@ -611,13 +622,13 @@ __device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_
                     const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
-                    if (best < 0 || dd < bd || (dd == bd && oi < boi)) { best = (int)min(t + k, t1 - 1); bd = dd; boi = oi; }
+                    m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
                 }
             }
-            bound = fminf(bound, bd * 1.0001f);
+            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
         }
     }
-    if (best < 0 || !(bd <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
+    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
     return best;
 }
 
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     m3d_map_block(n_pairs, bpp, pair, blk);
     const M3dJob& J = jobs[pair];
     M3dPairState* st = J.st;
-    if (blk == 0 && threadIdx.x == 0) heavy_cnt[pair] = 0u;   // the search kernels of this iteration are done with it
+    if (blk == 0 && threadIdx.x == 0) { st->ctr[0] += heavy_cnt[pair]; st->ctr[1] += 1u; heavy_cnt[pair] = 0u; }   // diagnostics, then reset for the next iteration
     if (st->done || (!first_of_level && st->level_done)) return;
     float R[9], tt[3];
     m3d_load_pose(st, R, tt);
