@@ -827,11 +827,12 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
     return -1;
 }
 
-// One thread per pair: consume the sums of the iteration that just ran, update the pose, decide.
-__global__ __launch_bounds__(64) void k_solve_update(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const M3dJob& J = jobs[p];
+// One workgroup for the whole batch, one thread per pair (looping): consume the sums of the iteration that
+// just ran, update the pose, decide. Finally publish {iteration sequence number, pairs that still have work
+// at this level} as ONE 8-byte store into host-mapped memory: the host polls it between launches and stops
+// enqueuing a level's remaining iterations once nothing is active — early termination without any
+// host-device synchronisation (a stale read only costs a few empty launches, never correctness).
+__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level) {
     M3dPairState* st = J.st;
     if (st->done || (!first_of_level && st->level_done)) return;
     long long sums[M3D_NSUMS];
@@ -865,6 +866,25 @@ __global__ __launch_bounds__(64) void k_solve_update(const M3dJob* __restrict__ 
     if (J.trace && it < M3D_MAX_TRACE) for (int i = 0; i < 16; i++) J.trace[16 * it + i] = T[i];
     st->done = done;
     st->level_done = level_done;
+}
+
+__global__ __launch_bounds__(256) void k_solve_update(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, unsigned int seq,
+                                                      unsigned long long* __restrict__ progress) {
+    __shared__ int s_active;
+    if (threadIdx.x == 0) s_active = 0;
+    __syncthreads();
+    int active = 0;
+    for (int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
+        m3d_solve_pair(jobs[p], first_of_level);
+        const M3dPairState* st = jobs[p].st;
+        if (!st->done && !st->level_done) active++;
+    }
+    if (active) atomicAdd(&s_active, active);
+    __syncthreads();
+    if (threadIdx.x == 0 && progress) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long*>(progress) = ((unsigned long long)seq << 32) | (unsigned int)s_active;
+    }
 }
 
 // ---- introspection: NN of arbitrary queries --------------------------------------------------------
@@ -932,11 +952,12 @@ hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
+                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
+                                    hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
     if (e0) (void)hipEventRecord(e0, s);
     launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1);
     if (e1) (void)hipEventRecord(e1, s);
-    hipLaunchKernelGGL(k_solve_update, dim3((n_pairs + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, first_of_level);
+    hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress);
     return hipGetLastError();
 }
 

@@ -51,8 +51,11 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
 };
 // e0/e1 (optional): events recorded immediately before / after the launches of one linearisation (search + reduction);
 // k0/k1 (optional): events around the dominant kernel alone (k_nn_light; not launched on the first iteration of a level)
+// seq / progress: k_solve_update stores {seq, pairs still active at this level} to *progress (device view of
+// host-mapped memory, may be null) so that the host can stop enqueuing iterations without synchronising
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, hipEvent_t e0, hipEvent_t e1, hipEvent_t k0, hipEvent_t k1);
+                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
+                                    hipEvent_t e1, hipEvent_t k0, hipEvent_t k1);
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
                                       const M3dNnWork& w);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,

@@ -88,6 +88,11 @@ struct m3dreg_handle {
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
+    // sync-free early termination: k_solve_update publishes {sequence, active pairs} into host-mapped memory
+    volatile unsigned long long* h_progress = nullptr;   // pinned + mapped
+    unsigned long long* d_progress = nullptr;            // device view of the same word
+    unsigned int seq = 0;
+    uint64_t launched_iters = 0, skipped_iters = 0;
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
     int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
@@ -457,6 +462,17 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
         HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE));
         HIPCHK(h, hipHostMalloc((void**)&h->h_trace, sizeof(double) * 16 * M3D_MAX_TRACE, hipHostMallocDefault));
     }
+    if (!h->h_progress) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                h->h_progress = static_cast<volatile unsigned long long*>(hp);
+                h->d_progress = static_cast<unsigned long long*>(dp);
+                *h->h_progress = 0ull;
+            } else hipHostFree(hp);
+        }   // without mapped memory the library simply enqueues every iteration (still correct)
+    }
     h->cap_pairs = cap;
     return M3DREG_OK;
 }
@@ -620,7 +636,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
     for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_heavy_cnt }) if (p) hipFree(p);
-    for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace }) if (p) hipHostFree(p);
+    for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -681,15 +697,26 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     if ((rc = ensure_match(h, n_pairs, max_n_src))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * size_t(P.n_levels), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));
+    const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
     for (int l = 0; l < P.n_levels; l++) {
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
+        const unsigned int level_first_seq = h->seq + 1;
         for (int it = 0; it < P.iterations[l]; it++) {
+            if (can_stop_early && it > 0) {   // nothing left to do at this level? (a stale value only delays the exit)
+                const unsigned long long v = *h->h_progress;
+                if ((unsigned int)(v >> 32) >= level_first_seq && (unsigned int)(v >> 32) <= h->seq && (unsigned int)v == 0u) {
+                    h->skipped_iters += uint64_t(P.iterations[l] - it);
+                    break;
+                }
+            }
+            h->seq++;
+            h->launched_iters++;
             hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
             if (h->profiling) {
                 e0 = next_event(h); e1 = next_event(h); h->ev_kind.push_back(0);
                 if (it > 0 && h->icp_variant == 2) { k0 = next_event(h); k1 = next_event(h); h->ev_kind.push_back(1); }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), e0, e1, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), h->seq, h->d_progress, e0, e1, k0, k1));
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
