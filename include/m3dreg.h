@@ -151,6 +151,30 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats);
 int m3dreg_synchronize(m3dreg_handle* h);
 void* m3dreg_get_stream(m3dreg_handle* h);
 
+/* ---- aggregation on the device ---------------------------------------------
+ * The step m3d_aggregator performs before publishing a cloud (m3d/m3d_aggregator/src/m3d_aggregator.cpp):
+ * every incoming PointCloud2 / LaserScan message is rigidly transformed by the tf lookup of its callback
+ * (:236-248, :261-268), points INSIDE the self-filter box are dropped (:65-73), the rest is appended, and the
+ * rotation travelled by the head is accumulated (:75-87) until it exceeds 1.1*pi (:30, :95-103).
+ * `tf7` = {tx, ty, tz, qx, qy, qz, qw} of geometry_msgs/Transform. The aggregate lives in HBM in
+ * pcl::PointXYZ layout, so m3dagg_take_cloud buckets it in place — the sweep never crosses PCIe as a cloud. */
+typedef struct m3dagg m3dagg;
+/* bbox = {x_up, x_down, y_up, y_down, z_up, z_down} (setBBox :42-52; node defaults +-1 m, :164-171) */
+int m3dagg_create(m3dreg_handle* h, const double bbox[6], size_t capacity, m3dagg** out);
+int m3dagg_destroy(m3dagg* a);
+/* rotLaserPointCloudCallback (:231-254): `data` is the message's host buffer */
+int m3dagg_add_cloud(m3dagg* a, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                     const double tf7[7]);
+/* rotLaserScanCallback (:256-288): ranges[i] at angle_min + i * angle_increment, z = 0 */
+int m3dagg_add_scan(m3dagg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf7[7]);
+/* getProgress (:119-124) in percent, isPointcloudReady (:95-103), currentAngularDistance, points kept so far */
+int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t* n_points);
+/* publishPointcloud (:194-212) without the publish: buckets the aggregate as an m3dreg_cloud, then clears and
+ * restarts the aggregator (clearPointCloud :108-114; the node is re-armed by requestCallback :224-229). */
+int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out);
+int m3dagg_restart(m3dagg* a);                       /* requestCallback (:224-229) */
+int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled, hipEvents are recorded on the handle's stream (a) around all launches of every
  * linearisation (NN search + residual reduction of the whole batch) and (b) around every launch of the

@@ -27,6 +27,8 @@ EXPORTS = [
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
+    "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
+    "m3dagg_download",
 ]
 
 
@@ -70,6 +72,14 @@ def lib():
     L.m3dreg_debug_nn.argtypes = [vp, vp, C.c_int, f32p, sz, C.c_float, i32p, f32p]
     L.m3dreg_debug_accumulate.argtypes = [vp, vp, vp, C.c_int, f32p, i64p, i32p]
     L.m3dreg_debug_trace.argtypes = [vp, f64p, sz, C.POINTER(sz)]
+    L.m3dagg_create.argtypes = [vp, f64p, sz, C.POINTER(vp)]
+    L.m3dagg_destroy.argtypes = [vp]
+    L.m3dagg_add_cloud.argtypes = [vp, vp, sz, sz, sz, sz, sz, f64p]
+    L.m3dagg_add_scan.argtypes = [vp, f32p, sz, C.c_float, C.c_float, f64p]
+    L.m3dagg_status.argtypes = [vp, f64p, C.POINTER(C.c_int), f64p, C.POINTER(sz)]
+    L.m3dagg_take_cloud.argtypes = [vp, C.POINTER(vp)]
+    L.m3dagg_restart.argtypes = [vp]
+    L.m3dagg_download.argtypes = [vp, f32p, sz, C.POINTER(sz)]
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
@@ -298,6 +308,62 @@ class Registrar:
         self._check(lib().m3dreg_debug_trace(self._h, _ptr(buf, C.c_double), cap, C.byref(n)), "debug_trace")
         k = min(n.value, cap)
         return np.stack([colmajor16_to_T(buf[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))
+
+
+class Aggregator:
+    """Device-side mirror of m3d_aggregator's pointCloudAggregator (m3d_aggregator.cpp:22-143): messages in,
+    one bucketed cloud per 1.1*pi of head rotation out, the sweep itself never leaves HBM."""
+
+    def __init__(self, reg: Registrar, bbox=(1.0, -1.0, 1.0, -1.0, 1.0, -1.0), capacity=1 << 20):
+        self._reg = reg
+        self._a = C.c_void_p()
+        bb = np.asarray(bbox, np.float64)
+        reg._check(lib().m3dagg_create(reg._h, _ptr(bb, C.c_double), capacity, C.byref(self._a)), "m3dagg_create")
+
+    def close(self):
+        if self._a:
+            lib().m3dagg_destroy(self._a)
+            self._a = None
+
+    def __del__(self):
+        try:
+            if self._reg._h:
+                self.close()
+        except Exception:
+            pass
+
+    def add_cloud(self, msg: PointCloud2, tf7):
+        msg = to_little_endian(msg)
+        ox, oy, oz = msg.xyz_offsets()
+        buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+        t = np.asarray(tf7, np.float64)
+        self._reg._check(lib().m3dagg_add_cloud(self._a, buf, msg.n, msg.point_step, ox, oy, oz, _ptr(t, C.c_double)), "m3dagg_add_cloud")
+
+    def add_scan(self, ranges, angle_min, angle_increment, tf7):
+        r = np.ascontiguousarray(ranges, np.float32)
+        t = np.asarray(tf7, np.float64)
+        self._reg._check(lib().m3dagg_add_scan(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double)), "m3dagg_add_scan")
+
+    def status(self):
+        pr, rd, an, n = C.c_double(), C.c_int(), C.c_double(), C.c_size_t()
+        self._reg._check(lib().m3dagg_status(self._a, C.byref(pr), C.byref(rd), C.byref(an), C.byref(n)), "m3dagg_status")
+        return {"progress": pr.value, "ready": bool(rd.value), "angle": an.value, "n": n.value}
+
+    def points(self):
+        n = self.status()["n"]
+        out = np.zeros((max(n, 1), 4), np.float32)
+        k = C.c_size_t()
+        self._reg._check(lib().m3dagg_download(self._a, _ptr(out, C.c_float), n, C.byref(k)), "m3dagg_download")
+        return out[:n]
+
+    def take_cloud(self):
+        n = self.status()["n"]
+        p = C.c_void_p()
+        self._reg._check(lib().m3dagg_take_cloud(self._a, C.byref(p)), "m3dagg_take_cloud")
+        return Cloud(self._reg, p, n)
+
+    def restart(self):
+        self._reg._check(lib().m3dagg_restart(self._a), "m3dagg_restart")
 
 
 class Gpu6dSlamNode:

@@ -38,6 +38,21 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
                                    float plane_ratio, int min_pts, float min_spread);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
+// aggregate.hip
+struct M3dAggArgs {
+    int mode;                    // 0 = PointCloud2 payload, 1 = LaserScan ranges
+    int n;
+    const uint8_t* raw; int step, ox, oy, oz;
+    const float* ranges; float angle_min, angle_inc;
+    double m[9], o[3];           // tf::Transform: row-major basis + origin
+    double bb[6];                // x_up, x_down, y_up, y_down, z_up, z_down
+    float4* out;                 // aggregate buffer, pcl::PointXYZ layout
+    uint32_t* count;             // [2] device: points aggregated so far, overflow flag
+    uint32_t capacity;
+    uint32_t* block_counts;      // [blocks] workspace
+};
+hipError_t m3d_launch_aggregate(hipStream_t s, const M3dAggArgs& A);
+
 // icp.hip
 // variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
 //          2 = split (default): k_nn_light + k_nn_heavy (one int32 result per query) + k_accumulate_matches

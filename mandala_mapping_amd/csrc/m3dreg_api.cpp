@@ -777,6 +777,198 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
     return rc;
 }
 
+// ---- aggregation on the device --------------------------------------------------------
+}  // extern "C"
+
+struct m3dagg {
+    m3dreg_handle* h = nullptr;
+    double bb[6]{};
+    double current_angle = 0.0;
+    double angular_distance = 1.1 * 3.14159265358979323846;   // 1.1 * M_PI, m3d_aggregator.cpp:30
+    bool creating = true, first_scan = true;
+    double actual[4]{};
+    float4* d_pts = nullptr;       // pcl::PointXYZ layout
+    uint32_t* d_count = nullptr;   // {points, overflow}
+    uint32_t* d_blocks = nullptr;
+    uint8_t* d_stage = nullptr;    // staged message payload
+    size_t capacity = 0, stage_bytes = 0, blocks_cap = 0;
+};
+
+namespace {
+// tf LinearMath (un-vendored dependency of m3d_aggregator): Matrix3x3::setRotation / getRotation and
+// Quaternion::angleShortestPath restated in double with the published operation order
+void tf_set_rotation(const double q[4], double m[9]) {
+    const double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double s = 2.0 / d;
+    const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+    const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+    const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+    const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+    m[0] = 1.0 - (yy + zz); m[1] = xy - wz; m[2] = xz + wy;
+    m[3] = xy + wz; m[4] = 1.0 - (xx + zz); m[5] = yz - wx;
+    m[6] = xz - wy; m[7] = yz + wx; m[8] = 1.0 - (xx + yy);
+}
+void tf_get_rotation(const double m[9], double q[4]) {
+    const double trace = m[0] + m[4] + m[8];
+    double temp[4];
+    if (trace > 0.0) {
+        double s = std::sqrt(trace + 1.0);
+        temp[3] = s * 0.5;
+        s = 0.5 / s;
+        temp[0] = (m[7] - m[5]) * s; temp[1] = (m[2] - m[6]) * s; temp[2] = (m[3] - m[1]) * s;
+    } else {
+        const int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        double s = std::sqrt(m[3 * i + i] - m[3 * j + j] - m[3 * k + k] + 1.0);
+        temp[i] = s * 0.5;
+        s = 0.5 / s;
+        temp[3] = (m[3 * k + j] - m[3 * j + k]) * s;
+        temp[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+        temp[k] = (m[3 * k + i] + m[3 * i + k]) * s;
+    }
+    memcpy(q, temp, sizeof(temp));
+}
+double tf_angle_shortest_path(const double a[4], const double b[4]) {
+    const double la = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    const double lb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    const double s = std::sqrt(la * lb);
+    const double dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    if (dot < 0.0) return std::acos(-dot / s) * 2.0;
+    return std::acos(dot / s) * 2.0;
+}
+
+int agg_add(m3dagg* a, M3dAggArgs& A, const void* host_payload, size_t payload_bytes, const double tf7[7]) {
+    m3dreg_handle* h = a->h;
+    if (!a->creating) return M3DREG_OK;   // addPoints :55
+    HIPCHK(h, hipSetDevice(h->device));
+    const double qin[4] = { tf7[3], tf7[4], tf7[5], tf7[6] };
+    tf_set_rotation(qin, A.m);
+    A.o[0] = tf7[0]; A.o[1] = tf7[1]; A.o[2] = tf7[2];
+    double q[4];
+    tf_get_rotation(A.m, q);
+    memcpy(A.bb, a->bb, sizeof(A.bb));
+    if (payload_bytes > a->stage_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (a->d_stage) hipFree(a->d_stage);
+        a->d_stage = nullptr; a->stage_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&a->d_stage, payload_bytes + payload_bytes / 2));
+        a->stage_bytes = payload_bytes + payload_bytes / 2;
+    }
+    const size_t nblocks = (size_t(A.n) + 255) / 256;
+    if (nblocks > a->blocks_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (a->d_blocks) hipFree(a->d_blocks);
+        a->d_blocks = nullptr; a->blocks_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&a->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 2 + 16)));
+        a->blocks_cap = nblocks + nblocks / 2 + 16;
+    }
+    HIPCHK(h, hipMemcpyAsync(a->d_stage, host_payload, payload_bytes, hipMemcpyHostToDevice, h->stream));
+    if (A.mode == 0) A.raw = a->d_stage; else A.ranges = reinterpret_cast<const float*>(a->d_stage);
+    A.out = a->d_pts; A.count = a->d_count; A.capacity = uint32_t(a->capacity); A.block_counts = a->d_blocks;
+    HIPCHK(h, m3d_launch_aggregate(h->stream, A));
+    // :75-87 — one quaternion per message, but the reference evaluates it once PER POINT: the first point of a
+    // message sees the rotation since the previous message, every further point adds angleShortestPath(q, q)
+    // (2*acos(1 +- rounding): tiny or NaN, skipped when NaN). Reproduced add by add to keep the same double.
+    for (int i = 0; i < A.n; i++) {
+        if (a->first_scan) { a->first_scan = false; memcpy(a->actual, q, sizeof(q)); }
+        else {
+            const double dd = tf_angle_shortest_path(q, a->actual);
+            if (!std::isnan(dd)) a->current_angle = a->current_angle + dd;
+            memcpy(a->actual, q, sizeof(q));
+        }
+    }
+    return M3DREG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int m3dagg_create(m3dreg_handle* h, const double bbox[6], size_t capacity, m3dagg** out) {
+    if (!h || !bbox || !out || capacity == 0 || capacity >= 0x7FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dagg_create: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    m3dagg* a = new m3dagg();
+    a->h = h; a->capacity = capacity;
+    memcpy(a->bb, bbox, sizeof(a->bb));
+    hipError_t e = hipMalloc((void**)&a->d_pts, sizeof(float4) * capacity);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_count, sizeof(uint32_t) * 2);
+    if (e == hipSuccess) e = hipMemsetAsync(a->d_count, 0, sizeof(uint32_t) * 2, h->stream);
+    if (e != hipSuccess) { if (a->d_pts) hipFree(a->d_pts); if (a->d_count) hipFree(a->d_count); delete a; return fail(h, M3DREG_ERR_HIP, "m3dagg_create", e); }
+    *out = a;
+    return M3DREG_OK;
+}
+
+int m3dagg_destroy(m3dagg* a) {
+    if (!a) return M3DREG_ERR_INVALID_ARG;
+    hipSetDevice(a->h->device);
+    hipStreamSynchronize(a->h->stream);
+    for (void* p : { (void*)a->d_pts, (void*)a->d_count, (void*)a->d_blocks, (void*)a->d_stage }) if (p) hipFree(p);
+    delete a;
+    return M3DREG_OK;
+}
+
+int m3dagg_add_cloud(m3dagg* a, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z, const double tf7[7]) {
+    if (!a || !data || !tf7 || n == 0 || n >= 0x7FFFFFFFull) return M3DREG_ERR_INVALID_ARG;
+    if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step || (point_step % 4) || (off_x % 4) || (off_y % 4) || (off_z % 4))
+        return fail(a->h, M3DREG_ERR_INVALID_ARG, "m3dagg_add_cloud: FLOAT32 fields must be 4-byte aligned inside point_step");
+    M3dAggArgs A{};
+    A.mode = 0; A.n = int(n); A.step = int(point_step); A.ox = int(off_x); A.oy = int(off_y); A.oz = int(off_z);
+    return agg_add(a, A, data, n * point_step, tf7);
+}
+
+int m3dagg_add_scan(m3dagg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf7[7]) {
+    if (!a || !ranges || !tf7 || n == 0 || n >= 0x7FFFFFFFull) return M3DREG_ERR_INVALID_ARG;
+    M3dAggArgs A{};
+    A.mode = 1; A.n = int(n); A.angle_min = angle_min; A.angle_inc = angle_increment;
+    return agg_add(a, A, ranges, n * sizeof(float), tf7);
+}
+
+int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t* n_points) {
+    if (!a) return M3DREG_ERR_INVALID_ARG;
+    if (progress) *progress = a->creating ? 0.1 * std::floor(a->current_angle * 1000.0 / a->angular_distance) : -1.0;   // :119-124
+    if (ready) *ready = a->current_angle > a->angular_distance ? 1 : 0;                                                  // :95-103
+    if (angle) *angle = a->current_angle;
+    if (n_points) {
+        uint32_t c[2];
+        HIPCHK(a->h, hipMemcpyAsync(c, a->d_count, sizeof(c), hipMemcpyDeviceToHost, a->h->stream));
+        HIPCHK(a->h, hipStreamSynchronize(a->h->stream));
+        if (c[1]) return fail(a->h, M3DREG_ERR_INVALID_ARG, "m3dagg: aggregate capacity exceeded");
+        *n_points = c[0];
+    }
+    return M3DREG_OK;
+}
+
+int m3dagg_restart(m3dagg* a) {
+    if (!a) return M3DREG_ERR_INVALID_ARG;
+    HIPCHK(a->h, hipMemsetAsync(a->d_count, 0, sizeof(uint32_t) * 2, a->h->stream));
+    a->current_angle = 0.0; a->first_scan = true; a->creating = true;
+    return M3DREG_OK;
+}
+
+int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out) {
+    if (!a || !out) return M3DREG_ERR_INVALID_ARG;
+    size_t n = 0;
+    int rc = m3dagg_status(a, nullptr, nullptr, nullptr, &n);
+    if (rc) return rc;
+    if (n == 0) return fail(a->h, M3DREG_ERR_EMPTY_CLOUD, "m3dagg_take_cloud: nothing aggregated");
+    rc = m3dreg_cloud_create(a->h, a->d_pts, n, 16, 0, 4, 8, 1, out);   // bucketed in place: no PCIe transfer of the sweep
+    if (rc) return rc;
+    return m3dagg_restart(a);
+}
+
+int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out) {
+    if (!a || !n_out) return M3DREG_ERR_INVALID_ARG;
+    size_t n = 0;
+    int rc = m3dagg_status(a, nullptr, nullptr, nullptr, &n);
+    if (rc) return rc;
+    *n_out = n;
+    const size_t k = n < cap_points ? n : cap_points;
+    if (xyzw && k) {
+        HIPCHK(a->h, hipMemcpyAsync(xyzw, a->d_pts, 16 * k, hipMemcpyDeviceToHost, a->h->stream));
+        HIPCHK(a->h, hipStreamSynchronize(a->h->stream));
+    }
+    return M3DREG_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------
 int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     if (!h) return M3DREG_ERR_INVALID_ARG;

@@ -39,6 +39,24 @@ def _lib(omp=False):
         L.orc_debug_nn.argtypes = [vp, C.c_int, f32p, C.c_size_t, C.c_float, i32p, f32p]
         L.orc_debug_accumulate.argtypes = [C.POINTER(abi.Params), vp, vp, C.c_int, f32p, i64p, i32p, i32p, f32p]
         L.orc_align_clouds.argtypes = [C.POINTER(abi.Params), vp, vp, f32p, f32p, C.POINTER(abi.Stats), f64p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_agg_create.argtypes = [f64p]
+        L.orc_agg_create.restype = vp
+        L.orc_agg_destroy.argtypes = [vp]
+        L.orc_agg_destroy.restype = None
+        L.orc_agg_restart.argtypes = [vp]
+        L.orc_agg_restart.restype = None
+        L.orc_agg_add_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, f64p]
+        L.orc_agg_add_cloud.restype = None
+        L.orc_agg_add_scan.argtypes = [vp, f32p, C.c_size_t, C.c_float, C.c_float, f64p]
+        L.orc_agg_add_scan.restype = None
+        L.orc_agg_count.argtypes = [vp]
+        L.orc_agg_count.restype = C.c_size_t
+        L.orc_agg_points.argtypes = [vp, f32p]
+        L.orc_agg_points.restype = None
+        for fn in ("orc_agg_angle", "orc_agg_progress"):
+            getattr(L, fn).argtypes = [vp]
+            getattr(L, fn).restype = C.c_double
+        L.orc_agg_ready.argtypes = [vp]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -137,3 +155,41 @@ def align(params, src, tgt, init_T=None, trace_cap=0):
                                    _ptr(trace, C.c_double) if trace_cap else None, trace_cap, C.byref(tn)), "align_clouds")
     k = min(tn.value, trace_cap)
     return _from16(out), st, np.stack([_from16(trace[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))
+
+
+class Aggregator:
+    """oracle/m3d_agg_oracle.c: the reference's pointCloudAggregator restated (m3d_aggregator.cpp:22-143)."""
+
+    def __init__(self, bbox=(1.0, -1.0, 1.0, -1.0, 1.0, -1.0)):
+        self._L = _lib()
+        bb = np.asarray(bbox, np.float64)
+        self._a = C.c_void_p(self._L.orc_agg_create(_ptr(bb, C.c_double)))
+
+    def __del__(self):
+        if getattr(self, "_a", None):
+            self._L.orc_agg_destroy(self._a)
+            self._a = None
+
+    def add_cloud(self, msg, tf7):
+        ox, oy, oz = msg.xyz_offsets()
+        buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+        t = np.asarray(tf7, np.float64)
+        self._L.orc_agg_add_cloud(self._a, buf, msg.n, msg.point_step, ox, oy, oz, _ptr(t, C.c_double))
+
+    def add_scan(self, ranges, angle_min, angle_increment, tf7):
+        r = np.ascontiguousarray(ranges, np.float32)
+        t = np.asarray(tf7, np.float64)
+        self._L.orc_agg_add_scan(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double))
+
+    def status(self):
+        return {"progress": self._L.orc_agg_progress(self._a), "ready": bool(self._L.orc_agg_ready(self._a)),
+                "angle": self._L.orc_agg_angle(self._a), "n": self._L.orc_agg_count(self._a)}
+
+    def points(self):
+        n = self._L.orc_agg_count(self._a)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        self._L.orc_agg_points(self._a, _ptr(out, C.c_float))
+        return out[:n]
+
+    def restart(self):
+        self._L.orc_agg_restart(self._a)
