@@ -260,10 +260,9 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const bool valid = k != M3D_INVALID_KEY;
     const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
-    const bool last = valid && (j == n - 1 || skey[j + 1] != k);
     float4 p;
     p.x = B.x[oi]; p.y = B.y[oi]; p.z = B.z[oi];
-    p.w = __uint_as_float(oi | (last ? M3D_LAST_FLAG : 0u));
+    p.w = __uint_as_float(oi | ((k & 7u) << M3D_SUB_SHIFT));   // the voxel's position inside its bucket rides along
     B.pts[j] = p;
     if (bhead) {
         const uint32_t bk = bucket_key_of_point(B.grid, p);
@@ -422,7 +421,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const long long* mom = B.mom;
     float4* nrm_in = B.nrm_in;
     const float4 pj = L.pts[j];
-    const uint32_t oi = __float_as_uint(pj.w) & ~M3D_LAST_FLAG;
+    const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j >= g.n_valid) { nrm_in[oi] = out; return; }   // non-finite points sort last: no normal
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
@@ -506,7 +505,7 @@ __global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __
     const float4 p = pts[j];
     xyz[3 * j] = p.x; xyz[3 * j + 1] = p.y; xyz[3 * j + 2] = p.z;
     if (nrm && nxyz) {   // normals are stored by input index: gather into sorted order for the export
-        const float4 q = nrm[__float_as_uint(p.w) & ~M3D_LAST_FLAG];
+        const float4 q = nrm[__float_as_uint(p.w) & M3D_IDX_MASK];
         nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z;
     }
 }

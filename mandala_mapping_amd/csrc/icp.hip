@@ -71,7 +71,7 @@ __device__ __forceinline__ float m3d_key_d2(unsigned long long key) { return __u
 __device__ __forceinline__ void m3d_consider(M3dBest& B, const float4& c4, float ux, float uy, float uz) {
     const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-    const uint32_t oi = __float_as_uint(c4.w) & ~M3D_LAST_FLAG;
+    const uint32_t oi = __float_as_uint(c4.w) & M3D_IDX_MASK;
     if (B.found < 0 || dd < B.d2 || (dd == B.d2 && oi < B.oi)) { B.found = 1; B.d2 = dd; B.oi = oi; B.q = c4; }
 }
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_accumulate(const M3dJob* __
         const int j = m3d_nn27(L, ux, uy, uz, dmax2, d2, q);
         if (j < 0) continue;
         float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & ~M3D_LAST_FLAG];
+        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & M3D_IDX_MASK];
         m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
     }
     block_reduce_to_global<NACC>(acc, st->sums);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_lds(const M3dJob* __restric
         if (lane == 0) atomicAdd(&st->ctr[fast ? 0 : 1], 1u);
         if (B.found >= 0) {
             float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (METRIC == 1) nq = L.nrm[__float_as_uint(B.q.w) & ~M3D_LAST_FLAG];
+            if (METRIC == 1) nq = L.nrm[__float_as_uint(B.q.w) & M3D_IDX_MASK];
             m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, B.q, B.d2, nq, cx, cy, cz, S);
         }
     }
@@ -441,7 +441,53 @@ __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
     return (long long)(Q.ic[0] + 1) | ((long long)(Q.ic[1] + 1) << 16) | ((long long)(Q.ic[2] + 1) << 32);
 }
 
-// LIGHT path. m_prev: this query's result in the previous iteration of the same level. When the previous
+// 8-bit mask of the voxels of the bucket whose first voxel is (vx0,vy0,vz0) that lie inside the query's
+// neighbourhood, plus the conservative squared distance from the query to that part of the bucket
+__device__ __forceinline__ uint32_t m3d_bucket_mask(const M3dQuery& Q, int vx0, int vy0, int vz0, float& lb2) {
+    const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
+    const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
+    const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
+    const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
+    const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy0, vy0 + sy1, Q.gl[1], Q.gh[1]);
+    const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz0, vz0 + sz1, Q.gl[2], Q.gh[2]);
+    lb2 = gx * gx + gy * gy + gz * gz;
+    if (sx0 > sx1 || sy0 > sy1 || sz0 > sz1) return 0u;
+    const uint32_t mx = (sx0 == sx1) ? (sx0 ? 0xAAu : 0x55u) : 0xFFu;   // bit s <-> voxel (s&1, (s>>1)&1, s>>2)
+    const uint32_t my = (sy0 == sy1) ? (sy0 ? 0xCCu : 0x33u) : 0xFFu;
+    const uint32_t mz = (sz0 == sz1) ? (sz0 ? 0xF0u : 0x0Fu) : 0xFFu;
+    return mx & my & mz;
+}
+
+// Scan ONE bucket as one contiguous run: every point carries its voxel position (3 bits of .w), so the
+// neighbourhood test is a mask lookup — no per-voxel loops, no cumulative tables on the hot path.
+// Four independent 16-B gathers per wait; indices are clamped into the run (a repeated point cannot change
+// the argmin). Returns true when at least one point of the neighbourhood was seen.
+__device__ __forceinline__ bool m3d_scan_bucket(m3d_gf4 pts, uint32_t base, uint32_t count, uint32_t mask, float ux, float uy, float uz,
+                                                unsigned long long& bkey, int& best) {
+    bool seen = false;
+    const uint32_t t1 = base + count;
+    for (uint32_t t = base; t < t1; t += 4) {
+        float4 c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = __float_as_uint(c4[k].w);
+            const bool in = (mask >> (w >> M3D_SUB_SHIFT)) & 1u;
+            const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
+            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            const unsigned long long key = in ? (((unsigned long long)__float_as_uint(dd) << 32) | (w & M3D_IDX_MASK)) : ~0ull;
+            const bool better = key < bkey;
+            bkey = better ? key : bkey;
+            best = better ? (int)min(t + k, t1 - 1) : best;
+            seen = seen || in;
+        }
+    }
+    return seen;
+}
+
+// LIGHT path (voxel-row walk: fewest gathers; the whole-bucket scan used by the full search costs 2.7x more
+// gathers here because a seeded neighbourhood covers ~6 of the ~16 voxels of its buckets). m_prev: this query's result in the previous iteration of the same level. When the previous
 // match is still closer than one voxel edge it necessarily lies inside the 27-voxel neighbourhood, so it
 // is a legitimate candidate: seeding the search with it changes nothing in the result (the argmin rule is
 // order-independent) but lets the box pruning discard most voxels — and whole buckets — before any probe.
@@ -462,7 +508,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
         const float reach = seed_reach * g.leaf;   // <= 0.99: closer than one voxel edge => inside the neighbourhood
         if (dd < reach * reach) {
             seeded = true;
-            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & ~M3D_LAST_FLAG, m_prev);
+            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, m_prev);
             bound = fminf(bound, dd * 1.0001f);
 #pragma unroll
             for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
@@ -536,7 +582,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
                     for (int k = 0; k < 4; k++) {
                         const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                         const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                        const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
+                        const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
                         m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
                     }
                 }
@@ -551,7 +597,48 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
 // FULL search (no seed): all (up to eight) bucket entries are requested before the first one is used.
 // Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
 // always with every lane of the wave doing the same amount of work.
-__device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
+__device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, float ux, float uy, float uz, float dmax2,
+                                             long long& cache_out) {
+    M3dQuery Q;
+    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
+    cache_out = m3d_voxel_code(Q);
+    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+    bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
+    int best = -1; unsigned long long bkey = ~0ull;
+    float bound = dmax2 * 1.0001f;
+    uint4 lo[8]; uint32_t key[8]; bool act[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+        act[b] = (ox <= nbx) && (oy <= nby) && (oz <= nbz);
+        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+        if (act[b]) lo[b] = m3d_ld(tab, 2 * (size_t)m3d_hash_slot(key[b], g.hshift));
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        if (!act[b]) continue;
+        if (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+            uint32_t slot = m3d_hash_slot(key[b], g.hshift);
+            do { slot = (slot + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot); } while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY);
+        }
+        if (lo[b].x != key[b]) continue;
+        float lb2;
+        const uint32_t mask = m3d_bucket_mask(Q, 2 * (b0x + (b & 1)), 2 * (b0y + ((b >> 1) & 1)), 2 * (b0z + (b >> 2)), lb2);
+        if (mask == 0u) continue;
+        if (lb2 > bound) { any_point = true; continue; }   // conservatively "some point may be there": never cache a pruned bucket as empty
+        any_point = m3d_scan_bucket(pts, lo[b].y, lo[b].z, mask, ux, uy, uz, bkey, best) || any_point;
+        bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+    }
+    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
+    return best;
+}
+
+// FULL search, voxel-row variant (A/B: M3DREG_FULL_ROWS=1): all (up to eight) bucket entries are requested before the first one is used.
+// Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
+// always with every lane of the wave doing the same amount of work.
+__device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
                                              float dmax2, long long& cache_out) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
@@ -621,7 +708,7 @@ __device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_
                 for (int k = 0; k < 4; k++) {
                     const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                    const uint32_t oi = __float_as_uint(c4[k].w) & ~M3D_LAST_FLAG;
+                    const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
                     m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
                 }
             }
@@ -643,6 +730,7 @@ struct M3dNnArgs {
     unsigned int* heavy_cnt;           // per pair: worklist length (reset by k_accumulate_matches)
     long long* cache;                  // per pair: voxel code of the "-2" verdicts (same stride as match)
     float seed_reach;                  // seeds farther than this many voxel edges go to the heavy list (<= 0.99)
+    int full_rows;                     // A/B: 1 = voxel-row full search, 0 = whole-bucket scan
 };
 
 #define NN_SETUP()                                                                                          \
@@ -656,7 +744,7 @@ struct M3dNnArgs {
     const M3dGrid g = J.tgt.g;                                                                              \
     const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));                          \
     const m3d_gf4 pts = m3d_as_global(J.tgt.pts);                                                           \
-    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);                                                    \
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum); (void)bigcum;                                      \
     const m3d_gf4 src = m3d_as_global(J.src);                                                               \
     const float dmax2 = J.dmax2;                                                                            \
     const int n = J.n_src;                                                                                  \
@@ -703,7 +791,7 @@ __global__ __launch_bounds__(256) void k_nn_heavy(const M3dJob* __restrict__ job
     const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
     int m = -1;
     long long code = 0;
-    if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_full(g, tab, pts, bigcum, ux, uy, uz, dmax2, code);
+    if (m3d_finite3(ux, uy, uz)) m = A.full_rows ? m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code) : m3d_nn27_full(g, tab, pts, ux, uy, uz, dmax2, code);
     out[i] = m;
     if (m == M3D_NN_NONE_CACHED) cache[i] = code;
 }
@@ -740,7 +828,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
         const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
         const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
         float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & ~M3D_LAST_FLAG];
+        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & M3D_IDX_MASK];
         m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
     }
     block_reduce_to_global<NACC>(acc, st->sums);
@@ -897,7 +985,7 @@ __global__ __launch_bounds__(256) void k_debug_nn(M3dLevelDev L, const float* __
     if (m3d_finite3(ux, uy, uz)) {
         float4 qq; float dd;
         const int j = m3d_nn27(L, ux, uy, uz, dmax2, dd, qq);
-        if (j >= 0) { idx = (int32_t)(__float_as_uint(qq.w) & ~M3D_LAST_FLAG); d2 = dd; }
+        if (j >= 0) { idx = (int32_t)(__float_as_uint(qq.w) & M3D_IDX_MASK); d2 = dd; }
     }
     out_idx[i] = idx; out_d2[i] = d2;
 }
@@ -923,7 +1011,7 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.cache = w.cache; A.seed_reach = w.seed_reach;
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.cache = w.cache; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows;
         if (!first_of_level) {
             if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
             hipLaunchKernelGGL(k_nn_light, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);

@@ -63,6 +63,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
+    int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)
 };
 // e0/e1 (optional): events recorded immediately before / after the launches of one linearisation (search + reduction);
 // k0/k1 (optional): events around the dominant kernel alone (k_nn_light; not launched on the first iteration of a level)

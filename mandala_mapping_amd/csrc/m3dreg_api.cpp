@@ -93,6 +93,7 @@ struct m3dreg_handle {
     unsigned long long* d_progress = nullptr;            // device view of the same word
     unsigned int seq = 0;
     uint64_t launched_iters = 0, skipped_iters = 0;
+    int full_rows = 1;                 // full search walks voxel rows (default); 0 = whole-bucket scan (M3DREG_FULL_ROWS, A/B: rows win by 10 %)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
     int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
@@ -505,6 +506,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.seed_reach = h->seed_reach;
+    w.full_rows = h->full_rows;
     return w;
 }
 
@@ -616,6 +618,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
+    if (const char* v = getenv("M3DREG_FULL_ROWS")) h->full_rows = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
@@ -652,7 +655,7 @@ int m3dreg_synchronize(m3dreg_handle* h) {
 }
 
 static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput& ci) {
-    if (!d.data || d.n == 0 || d.n >= 0x7FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
+    if (!d.data || d.n == 0 || d.n > 0x0FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument (at most 2^28 - 1 points per cloud)");
     if (d.off_x + 4 > d.point_step || d.off_y + 4 > d.point_step || d.off_z + 4 > d.point_step || d.point_step > 0x7FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: field offsets outside point_step");
     ci.data = d.data; ci.n = d.n; ci.step = d.point_step; ci.ox = d.off_x; ci.oy = d.off_y; ci.oz = d.off_z;
