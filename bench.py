@@ -8,9 +8,9 @@ decode + exact AABB + voxel bucketing + normals of BOTH clouds, then --iters poi
 iterations (0.1 m voxel NN), then the pose read-back; with N > 1 the poses of all ranks are gathered
 over RCCL (one all_gather per step — the only collective; pairs never exchange data).
 
-Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_light: source transform +
-exact 27-voxel nearest-neighbour search of every query of every pair of the batch in one launch, seeded
-by the previous iteration) by its algorithmic bytes (NN part: 12 N + 12 M + 8 C_occ per
+Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_coop: source transform +
+exact 27-voxel nearest-neighbour search, 8 lanes per query, of every query of every pair of the batch that
+the previous iteration's NN certificate could not answer) by its algorithmic bytes (NN part: 12 N + 12 M + 8 C_occ per
 pair) over its average launch duration, taken from hipEvents the library records on its stream around
 every launch of that kernel inside the timed region. `cpu_baseline` is the CPU oracle (OpenMP build)
 timed on a bounded sample of the same workload on this host's cores.
@@ -133,7 +133,7 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
-    launches, kern_ms = reg.profile_read(1, reset=True)       # k_nn_light alone
+    launches, kern_ms = reg.profile_read(1, reset=True)       # k_nn_coop alone
     iters_timed, iter_ms = reg.profile_read(0, reset=True)    # search + reduction of one linearisation
     reg.profile_enable(False)
     elapsed = t1 - t0
@@ -155,7 +155,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_nn_light", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("k_nn_coop", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -173,7 +173,7 @@ def main():
             "iteration_algorithmic_GBps": alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_light", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_coop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
         }
@@ -192,8 +192,8 @@ def cpu_baseline(params, host_pairs, iters, threads=0):
     and the 6x6 solve are serial) on a bounded sample of the same pairs."""
     from oracle import orc
     threads = threads or min(os.cpu_count() or 1, 64)   # beyond ~64 threads the per-iteration fork/join outweighs the work
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     orc.build()
+    threads = orc.set_threads(threads)   # torch has already initialised libgomp: the env var alone would be ignored
     done, t0 = 0, time.perf_counter()
     for src, tgt in host_pairs:
         cs, ct = orc.Cloud(params, src, omp=True), orc.Cloud(params, tgt, omp=True)

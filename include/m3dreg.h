@@ -178,8 +178,9 @@ int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out);  
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled, hipEvents are recorded on the handle's stream (a) around all launches of every
  * linearisation (NN search + residual reduction of the whole batch) and (b) around every launch of the
- * dominant kernel alone (`k_nn_light`, the seeded NN search; the first iteration of a level runs only
- * `k_nn_heavy`), so bench.py can report that kernel's average launch duration from inside its timed region. */
+ * dominant kernel alone (`k_nn_coop`, the exact 27-voxel NN search of every query that no certificate could
+ * answer; the first iteration of a level runs `k_nn_heavy` over all queries instead), so bench.py can report
+ * that kernel's average launch duration from inside its timed region. */
 int m3dreg_profile_enable(m3dreg_handle* h, int on);
 #define M3DREG_PROFILE_ITERATION 0
 #define M3DREG_PROFILE_DOMINANT_KERNEL 1
@@ -223,9 +224,9 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
 /* Per-iteration pose trace of the most recent m3dreg_align/align_clouds on this handle:
  * column-major double[16] after each executed iteration; returns count via *n_out (<= cap). */
 int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out);
-/* Diagnostics of the first pair of the most recent batch (default kernel variant): out[0] = queries that
- * went through the compacted full search after the first iteration of a level (summed over iterations),
- * out[1] = iterations executed. */
+/* Diagnostics of the first pair of the most recent batch (default kernel variant), summed over the
+ * iterations after the first of each level: out[0] = queries that needed the full 27-voxel search,
+ * out[1] = queries that needed the seeded search; all others were answered by an NN certificate. */
 int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]);
 
 #ifdef __cplusplus

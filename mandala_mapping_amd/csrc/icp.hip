@@ -67,6 +67,19 @@ __device__ __forceinline__ void m3d_argmin_step(unsigned long long& bestkey, int
     best = better ? t : best;
 }
 __device__ __forceinline__ float m3d_key_d2(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
+// Same, additionally maintaining `sec`: a lower bound of d2 over every candidate that is NOT the current best
+// (needed for the NN certificates). A candidate equal to the best key is the best point itself (clamped
+// re-reads, or the seed met again during the walk) and does not count. The empty key decodes to NaN, which
+// fminf ignores.
+__device__ __forceinline__ void m3d_argmin_step2(unsigned long long& bestkey, int& best, float& sec, float dd, uint32_t oi, int t) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | oi;
+    const bool better = key < bestkey;
+    const float loser = m3d_key_d2(better ? bestkey : key);
+    sec = (key != bestkey) ? fminf(sec, loser) : sec;
+    bestkey = better ? key : bestkey;
+    best = better ? t : best;
+}
+
 
 __device__ __forceinline__ void m3d_consider(M3dBest& B, const float4& c4, float ux, float uy, float uz) {
     const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
@@ -493,13 +506,14 @@ __device__ __forceinline__ bool m3d_scan_bucket(m3d_gf4 pts, uint32_t base, uint
 // order-independent) but lets the box pruning discard most voxels — and whole buckets — before any probe.
 // Queries that cannot be seeded return M3D_NN_HEAVY and are searched later, compacted into dense waves.
 __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                              float dmax2, int m_prev, long long cache_prev, float seed_reach) {
+                                              float dmax2, int m_prev, long long cache_prev, float seed_reach, float& sec) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     if (m_prev == M3D_NN_NONE_CACHED) return (m3d_voxel_code(Q) == cache_prev) ? M3D_NN_NONE_CACHED : M3D_NN_HEAVY;
     if (m_prev < 0) return M3D_NN_HEAVY;
     int best = -1; unsigned long long bkey = ~0ull;
     float bound = dmax2 * 1.0001f;
+    sec = 3.0e38f;
     bool seeded = false;
     {
         const float4 c4 = m3d_ld(pts, (size_t)m_prev);
@@ -512,8 +526,8 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
             bound = fminf(bound, dd * 1.0001f);
 #pragma unroll
             for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
-                if (Q.gl[a] * Q.gl[a] > bound) Q.lo[a] = max(Q.lo[a], Q.ic[a]);
-                if (Q.gh[a] * Q.gh[a] > bound) Q.hi[a] = min(Q.hi[a], Q.ic[a]);
+                if (Q.gl[a] * Q.gl[a] > bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); sec = fminf(sec, Q.gl[a] * Q.gl[a]); }
+                if (Q.gh[a] * Q.gh[a] > bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); sec = fminf(sec, Q.gh[a] * Q.gh[a]); }
             }
         }
     }
@@ -560,7 +574,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
             const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
             for (int sy = sy0; sy <= sy1; sy++) {
                 const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
-                if (gx2 + gy * gy + gz * gz > bound) continue;
+                { const float lb2 = gx2 + gy * gy + gz * gz; if (lb2 > bound) { sec = fminf(sec, lb2); continue; } }
                 const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
                 uint32_t c0, c1;
                 if (lo.w == 0) {
@@ -583,7 +597,7 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
                         const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                         const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                         const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
-                        m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
+                        m3d_argmin_step2(bkey, best, sec, dd, oi, (int)min(t + k, t1 - 1));
                     }
                 }
                 bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
@@ -598,7 +612,8 @@ __device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d
 // Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
 // always with every lane of the wave doing the same amount of work.
 __device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, float ux, float uy, float uz, float dmax2,
-                                             long long& cache_out) {
+                                             long long& cache_out, float& sec) {
+    sec = 0.0f;   // this variant keeps no second-best bound: its results are never certified
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     cache_out = m3d_voxel_code(Q);
@@ -639,10 +654,11 @@ __device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_
 // Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
 // always with every lane of the wave doing the same amount of work.
 __device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                             float dmax2, long long& cache_out) {
+                                             float dmax2, long long& cache_out, float& sec) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     cache_out = m3d_voxel_code(Q);
+    sec = 3.0e38f;
     const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
     const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
     bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
@@ -697,7 +713,7 @@ __device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab,
             any_point = any_point || (c1 > c0);
             const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
             const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
-            if (gx2 + gy * gy + gz * gz > bound) continue;
+            { const float lb2 = gx2 + gy * gy + gz * gz; if (lb2 > bound) { sec = fminf(sec, lb2); continue; } }
             const uint32_t t1 = base + c1;
             for (uint32_t t = base + c0; t < t1; t += 4) {
                 // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
@@ -709,7 +725,7 @@ __device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab,
                     const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
                     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
-                    m3d_argmin_step(bkey, best, dd, oi, (int)min(t + k, t1 - 1));
+                    m3d_argmin_step2(bkey, best, sec, dd, oi, (int)min(t + k, t1 - 1));
                 }
             }
             bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
@@ -719,16 +735,20 @@ __device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab,
     return best;
 }
 
-// Two kernels per iteration. k_nn_light: one query per thread, seeded light path; lanes that need the
-// full walk append their query index to the pair's worklist (one wave-aggregated atomic per wave, the
-// lanes of a wave stay adjacent in the list). k_nn_heavy: the worklist, densely packed into waves whose
-// lanes all do the same (full) amount of work. On the first iteration of a level there is nothing to
-// seed from: k_nn_heavy runs over all queries in their own (Morton) order and k_nn_light is skipped.
+// Three kernels per iteration. k_nn_light: one query per thread, no search — certify or classify; k_nn_seeded
+// and k_nn_heavy: the two block-local worklists, packed so that every active lane of a wave does the same
+// kind of work. On the first iteration of a level there is nothing to certify or seed from: k_nn_heavy runs
+// over all queries in their own (Morton) order and the other two are skipped.
 struct M3dNnArgs {
     int* match; int match_stride;      // per pair: result of every query (see the encoding above)
     int* heavy; int heavy_stride;      // per pair: worklist of query indices
-    unsigned int* heavy_cnt;           // per pair: worklist length (reset by k_accumulate_matches)
+    unsigned int* heavy_cnt;           // [(pair * bpp + blk) * 2 + {0: seeded, 1: full}]: block-local worklist lengths
+    unsigned int* pref;                // [pair][2][bpp + 1]: exclusive prefixes of those lengths (k_nn_scan)
     long long* cache;                  // per pair: voxel code of the "-2" verdicts (same stride as match)
+    float4* state;                     // per pair: {u0.xyz, sec}: where the query was at its last real search and the squared
+                                       //           lower bound of every non-best candidate seen there (NN certificate)
+    int certify;                       // 1 = use the NN certificates (default); 0 = always search (A/B, M3DREG_CERTIFY)
+    int coop_div;                      // a worklist shorter than n / coop_div is searched cooperatively (8 lanes per query)
     float seed_reach;                  // seeds farther than this many voxel edges go to the heavy list (<= 0.99)
     int full_rows;                     // A/B: 1 = voxel-row full search, 0 = whole-bucket scan
 };
@@ -750,50 +770,294 @@ struct M3dNnArgs {
     const int n = J.n_src;                                                                                  \
     M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);     \
     M3D_GLOBAL int* list = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.heavy + (size_t)pair * A.heavy_stride);         \
-    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);      \
+    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
 
+// k_nn_light: one query per thread, NO search: certify, or classify into the two worklists.
+//   certified            -> nothing to do (result and state stay)
+//   cached "none", same voxel -> nothing to do
+//   seedable (previous match closer than one voxel edge) -> list S (front of the worklist buffer, ascending)
+//   everything else      -> list H (back of the buffer, descending)
+template <bool NT>
 __global__ __launch_bounds__(256) void k_nn_light(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
     const int i = blk * 256 + (int)threadIdx.x;
-    int m = -1;
+    int cls = 0;   // 0 = done, 1 = seeded search, 2 = full search
     if (i < n) {
-        const float4 p = m3d_ld(src, i);
+        const float4 p = NT ? m3d_ld_stream(src, i) : m3d_ld(src, i);
         const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        if (m3d_finite3(ux, uy, uz)) {
-            const int mp = out[i];
-            const long long cp = (mp == M3D_NN_NONE_CACHED) ? cache[i] : 0ll;
-            m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, mp, cp, A.seed_reach);
+        const int mp = NT ? __builtin_nontemporal_load(&out[i]) : out[i];
+        if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; }
+        else {
+            const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
+            const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
+                                  (f1z >= -1.0f && f1z <= (float)g.dims[2]);
+            if (!in_range) { if (mp != -1) out[i] = -1; }
+            else if (mp == M3D_NN_NONE_CACHED) {
+                const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
+                cls = (code == cache[i]) ? 0 : 2;
+            } else if (mp < 0) cls = 2;
+            else {
+                // NN certificate: at its last real search (position u0) every candidate other than the match was at
+                // least sqrt(sec) away [inside the 27 voxels] / dout away [outside them]. The query has moved by
+                // delta since, so those are still farther than (bound - delta); if the match's CURRENT distance is
+                // below that, with margins far above float rounding, it is provably still the exact argmin.
+                const m3d_f32x4 s0 = state[i];
+                const float4 q1 = m3d_ld(pts, (size_t)mp);
+                const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+                const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                const float mx = ux - s0.x, my = uy - s0.y, mz = uz - s0.z;
+                const float delta = sqrtf(mx * mx + my * my + mz * mz);
+                const float f0x = m3d_cell_f(s0.x, g.mn[0], g.inv_leaf), f0y = m3d_cell_f(s0.y, g.mn[1], g.inv_leaf), f0z = m3d_cell_f(s0.z, g.mn[2], g.inv_leaf);
+                const bool same_voxel = (f0x == f1x) && (f0y == f1y) && (f0z == f1z);
+                const float r0x = (s0.x - g.mn[0]) - f0x * g.leaf, r0y = (s0.y - g.mn[1]) - f0y * g.leaf, r0z = (s0.z - g.mn[2]) - f0z * g.leaf;
+                const float gm = fmaxf(fminf(fminf(fminf(r0x, g.leaf - r0x), fminf(r0y, g.leaf - r0y)), fminf(r0z, g.leaf - r0z)) - g.prune_slack, 0.f);
+                const float dout = 0.999f * g.leaf + gm;
+                const float reach = A.seed_reach * g.leaf;
+                const bool seedable = dd1 < reach * reach;   // closer than one voxel edge => inside the (new) neighbourhood
+                const float others = same_voxel ? sqrtf(s0.w) : fminf(sqrtf(s0.w), dout);   // same voxel => same 27 voxels => only `sec` matters
+                const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
+                                       (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
+                cls = certified ? 0 : (seedable ? 1 : 2);
+            }
         }
     }
-    const bool heavy = m == M3D_NN_HEAVY;
-    const unsigned long long hb = __ballot(heavy);
-    if (hb) {   // wave-aggregated append
-        const int lane = threadIdx.x & 63;
-        unsigned int base = 0;
-        if (lane == (int)__builtin_ctzll(hb)) base = atomicAdd(&A.heavy_cnt[pair], (unsigned int)__popcll(hb));
-        base = (unsigned int)__shfl((int)base, (int)__builtin_ctzll(hb));
-        if (heavy) list[base + (unsigned int)__popcll(hb & ((1ull << lane) - 1ull))] = i;
-    }
-    if (i < n && !heavy) out[i] = m;
+    // block-local compaction, no atomics (one contended atomic per wave cost more than the classification itself):
+    // this block owns slots [blk*256, blk*256+256) of the pair's worklist buffer; seeded queries are packed at the
+    // front, full-search queries at the back, in query order; the two counts go to cnt[(pair*bpp + blk)*2 + {0,1}].
+    __shared__ int s_cnt[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bS = __ballot(cls == 1), bH = __ballot(cls == 2);
+    if (lane == 0) { s_cnt[0][wave] = (int)__popcll(bS); s_cnt[1][wave] = (int)__popcll(bH); }
+    __syncthreads();
+    int offS = 0, offH = 0, totS = 0, totH = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) { offS += s_cnt[0][w]; offH += s_cnt[1][w]; } totS += s_cnt[0][w]; totH += s_cnt[1][w]; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    M3D_GLOBAL int* seg = list + blk * 256;
+    if (cls == 1) seg[offS + (int)__popcll(bS & lt)] = i;
+    if (cls == 2) seg[255 - (offH + (int)__popcll(bH & lt))] = i;
+    if (threadIdx.x == 0) { A.heavy_cnt[2 * (pair * bpp + blk)] = (unsigned int)totS; A.heavy_cnt[2 * (pair * bpp + blk) + 1] = (unsigned int)totH; }
 }
 
+// Block-local worklists -> dense global order without contended atomics: one workgroup per pair scans the
+// per-block counts; consumers map a dense index j to (producer block, slot) by binary search in the prefix.
+// cnt layout per pair: [2*bpp] counts {S,H per block}; pref layout per pair: [2*(bpp+1)] exclusive prefixes (S then H).
+__global__ __launch_bounds__(512) void k_nn_scan(const M3dJob* __restrict__ jobs, int bpp, int first_of_level, const unsigned int* __restrict__ cnt,
+                                                 unsigned int* __restrict__ pref) {
+    const int pair = blockIdx.x;
+    const M3dPairState* st = jobs[pair].st;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    __shared__ unsigned int sh[2][512];
+    const unsigned int* c = cnt + (size_t)pair * 2 * bpp;
+    unsigned int* pS = pref + (size_t)pair * 2 * (bpp + 1);
+    unsigned int* pH = pS + (bpp + 1);
+    unsigned int carryS = 0, carryH = 0;
+    const int t = threadIdx.x;
+    for (int base = 0; base < bpp; base += 512) {
+        const int b = base + t;
+        const unsigned int vS = b < bpp ? c[2 * b] : 0u, vH = b < bpp ? c[2 * b + 1] : 0u;
+        sh[0][t] = vS; sh[1][t] = vH;
+        __syncthreads();
+        for (int o = 1; o < 512; o <<= 1) {
+            const unsigned int aS = t >= o ? sh[0][t - o] : 0u, aH = t >= o ? sh[1][t - o] : 0u;
+            __syncthreads();
+            sh[0][t] += aS; sh[1][t] += aH;
+            __syncthreads();
+        }
+        if (b < bpp) { pS[b] = carryS + sh[0][t] - vS; pH[b] = carryH + sh[1][t] - vH; }
+        carryS += sh[0][511]; carryH += sh[1][511];
+        __syncthreads();
+    }
+    if (t == 0) { pS[bpp] = carryS; pH[bpp] = carryH; }
+}
+
+// dense index j -> producer block (largest b with pref[b] <= j); pref[bpp] = total
+__device__ __forceinline__ int m3d_find_block(const unsigned int* __restrict__ pref, int bpp, unsigned int j) {
+    int lo = 0, hi = bpp;   // invariant: pref[lo] <= j < pref[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= j) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ---- cooperative search for SHORT worklists: 8 lanes per query, one bucket of the 2x2x2 per lane ------------
+// The one-query-per-lane kernels are throughput-shaped: a wave walks up to 8 buckets x 4 rows x n batches one
+// after the other (~50 dependent waits), so even a nearly empty worklist costs 50-100 us. Here the 8 buckets
+// of a query are walked by 8 lanes at once (chain: 1 probe + <= 4 rows) and merged with three xor-shuffles.
+// Twice the instructions per query, a fifth of the latency — used when a list holds < 1/8 of the queries.
+__device__ __forceinline__ void m3d_walk_bucket(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, int vx0, int vy0,
+                                                int vz0, float ux, float uy, float uz, float& bound, unsigned long long& bkey, int& best, float& sec,
+                                                bool& any_point) {
+    const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
+    const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
+    const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
+    const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
+    const float gx2 = gx * gx;
+    const uint32_t base = lo.y;
+    const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
+    for (int sz = sz0; sz <= sz1; sz++) {
+        const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
+        for (int sy = sy0; sy <= sy1; sy++) {
+            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
+            const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
+            uint32_t c0, c1;
+            if (lo.w == 0) {
+                c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
+                const int sm = s_first - 1;
+                c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
+            } else {
+                const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
+                c1 = bc[s_last];
+                c0 = s_first ? bc[s_first - 1] : 0u;
+            }
+            any_point = any_point || (c1 > c0);
+            const float lb2 = gx2 + gy * gy + gz * gz;
+            if (lb2 > bound) { sec = fminf(sec, lb2); continue; }
+            const uint32_t t1 = base + c1;
+            for (uint32_t t = base + c0; t < t1; t += 4) {
+                float4 c4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
+                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    m3d_argmin_step2(bkey, best, sec, dd, __float_as_uint(c4[k].w) & M3D_IDX_MASK, (int)min(t + k, t1 - 1));
+                }
+            }
+            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+        }
+    }
+}
+
+// one launch serves both worklists: the first half of a pair's blocks takes the seeded list, the second half the full-search list
+__global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A, int bpp_list) {
+    NN_SETUP();
+    const bool SEEDED = blk < (bpp >> 1);
+    blk = SEEDED ? blk : blk - (bpp >> 1);
+    const unsigned int* pref = A.pref + (size_t)pair * 2 * (bpp_list + 1) + (SEEDED ? 0 : (bpp_list + 1));
+    const unsigned int total = pref[bpp_list];
+    if (total * (unsigned int)A.coop_div >= (unsigned int)n) return;   // long list: the one-query-per-lane kernel handles it
+    const unsigned int j = (unsigned int)(blk * 32 + ((int)threadIdx.x >> 3));   // 32 queries per block
+    if (j >= total) return;                                          // uniform over the 8 lanes of a query
+    const int sub = threadIdx.x & 7;
+    const int pb = m3d_find_block(pref, bpp_list, j);
+    const int i = SEEDED ? list[pb * 256 + (int)(j - pref[pb])] : list[pb * 256 + 255 - (int)(j - pref[pb])];
+    const float4 p = m3d_ld(src, i);
+    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+    M3dQuery Q;
+    int best = -1; unsigned long long bkey = ~0ull;
+    float bound = dmax2 * 1.0001f, sec = 3.0e38f;
+    bool any_point = false;
+    long long code = 0;
+    const bool ok = m3d_finite3(ux, uy, uz) && m3d_query_setup(g, ux, uy, uz, Q);
+    if (ok) {
+        code = m3d_voxel_code(Q);
+        if (SEEDED) {   // every lane of the group starts from the seed (classification guaranteed it is inside the neighbourhood)
+            const int mp = out[i];
+            const float4 c4 = m3d_ld(pts, (size_t)mp);
+            const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
+            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, mp);
+            bound = fminf(bound, dd * 1.0001f);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if (Q.gl[a] * Q.gl[a] > bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); sec = fminf(sec, Q.gl[a] * Q.gl[a]); }
+                if (Q.gh[a] * Q.gh[a] > bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); sec = fminf(sec, Q.gh[a] * Q.gh[a]); }
+            }
+        }
+        if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
+            const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+            const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
+            const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
+            if (sub < nb) {   // this lane's bucket
+                const int shy = nbx, shz = nbx + nby;
+                const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
+                const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+                uint32_t slot = m3d_hash_slot(key, g.hshift);
+                uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
+                while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
+                if (lo.x == key) {
+                    const uint4 hi = m3d_ld(tab, 2 * (size_t)slot + 1);
+                    m3d_walk_bucket(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, bound, bkey, best, sec, any_point);
+                }
+            }
+        }
+    }
+    // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned long long ok2 = __shfl_xor(bkey, o);
+        const int ob = __shfl_xor(best, o);
+        const float os = __shfl_xor(sec, o);
+        const bool oa = __shfl_xor((int)any_point, o) != 0;
+        const bool better = ok2 < bkey;
+        const float loser = m3d_key_d2(better ? bkey : ok2);
+        sec = fminf(sec, os);
+        sec = (ok2 != bkey) ? fminf(sec, loser) : sec;   // equal keys: the same point (the shared seed)
+        bkey = better ? ok2 : bkey;
+        best = better ? ob : best;
+        any_point = any_point || oa;
+    }
+    if (sub == 0) {
+        int m = -1;
+        if (ok) {
+            if (best >= 0 && m3d_key_d2(bkey) <= dmax2) m = best;
+            else m = (SEEDED || any_point) ? -1 : M3D_NN_NONE_CACHED;
+        }
+        out[i] = m;
+        if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+        if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+    }
+}
+
+// k_nn_seeded: list S, compacted. Every lane holds a query whose previous match seeds the search.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_nn_seeded(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    NN_SETUP();
+    const unsigned int* pS = A.pref + (size_t)pair * 2 * (bpp + 1);
+    const unsigned int j = (unsigned int)(blk * 256 + (int)threadIdx.x);
+    if (pS[bpp] * (unsigned int)A.coop_div < (unsigned int)n) return;   // short list: k_nn_coop<true> handles it
+    if (j >= pS[bpp]) return;
+    const int pb = m3d_find_block(pS, bpp, j);
+    const int i = list[pb * 256 + (int)(j - pS[pb])];
+    const float4 p = m3d_ld(src, i);
+    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+    float sec;
+    const int m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, out[i], 0ll, A.seed_reach, sec);
+    out[i] = m;   // the seed is a valid candidate, so m is never M3D_NN_HEAVY here
+    if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void k_nn_heavy(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
-    const int j = blk * 256 + (int)threadIdx.x;
-    const int count = first_of_level ? n : (int)A.heavy_cnt[pair];
-    if (j >= count) return;
-    const int i = first_of_level ? j : list[j];
-    const float4 p = m3d_ld(src, i);
+    int i = blk * 256 + (int)threadIdx.x;
+    if (first_of_level) { if (i >= n) return; }
+    else {
+        const unsigned int* pH = A.pref + (size_t)pair * 2 * (bpp + 1) + (bpp + 1);
+        const unsigned int j = (unsigned int)i;
+        if (pH[bpp] * (unsigned int)A.coop_div < (unsigned int)n) return;   // short list: k_nn_coop<false> handles it
+        if (j >= pH[bpp]) return;
+        const int pb = m3d_find_block(pH, bpp, j);
+        i = list[pb * 256 + 255 - (int)(j - pH[pb])];
+    }
+    const float4 p = NT ? m3d_ld_stream(src, i) : m3d_ld(src, i);
     const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
     const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
     const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
     int m = -1;
     long long code = 0;
-    if (m3d_finite3(ux, uy, uz)) m = A.full_rows ? m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code) : m3d_nn27_full(g, tab, pts, ux, uy, uz, dmax2, code);
+    float sec = 0.0f;
+    if (m3d_finite3(ux, uy, uz)) m = A.full_rows ? m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code, sec) : m3d_nn27_full(g, tab, pts, ux, uy, uz, dmax2, code, sec);
     out[i] = m;
     if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+    if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
 }
 
 template <int METRIC>
@@ -804,7 +1068,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     m3d_map_block(n_pairs, bpp, pair, blk);
     const M3dJob& J = jobs[pair];
     M3dPairState* st = J.st;
-    if (blk == 0 && threadIdx.x == 0) { st->ctr[0] += heavy_cnt[pair]; st->ctr[1] += 1u; heavy_cnt[pair] = 0u; }   // diagnostics, then reset for the next iteration
+
     if (st->done || (!first_of_level && st->level_done)) return;
     float R[9], tt[3];
     m3d_load_pose(st, R, tt);
@@ -1011,13 +1275,23 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.cache = w.cache; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows;
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.pref = w.heavy_cnt + (size_t)2 * n_pairs * bpp_s; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.coop_div = w.coop_div; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows;
         if (!first_of_level) {
-            if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
-            hipLaunchKernelGGL(k_nn_light, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            if (k1) (void)hipEventRecord(k1, s);
+            hipEvent_t c0 = k0, c1 = k1;
+            if (w.nontemporal) hipLaunchKernelGGL(k_nn_light<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            else hipLaunchKernelGGL(k_nn_light<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            hipLaunchKernelGGL(k_nn_scan, dim3(n_pairs), dim3(512), 0, s, d_jobs, bpp_s, first_of_level, (const unsigned int*)A.heavy_cnt, A.pref);
+            if (w.coop_div > 1) hipLaunchKernelGGL(k_nn_seeded<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            // short-list regime (< n/8 entries): 8 lanes per query; at most n/8 queries -> n/256 blocks of 32 queries
+            const int bpp_c = 2 * ((max_n_src / w.coop_div + 31) / 32 + 1);   // per pair: half for each list
+            if (c0) (void)hipEventRecord(c0, s);    // the dominant kernel alone (bench.py roofline)
+            hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A, bpp_s);
+            if (c1) (void)hipEventRecord(c1, s);
         }
-        hipLaunchKernelGGL(k_nn_heavy, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        if (first_of_level || w.coop_div > 1) {   // full search of all queries (first iteration) / of a long worklist
+            if (w.nontemporal) hipLaunchKernelGGL(k_nn_heavy<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            else hipLaunchKernelGGL(k_nn_heavy<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        }
         int bpp_a = (max_n_src + 256 * 8 - 1) / (256 * 8); if (bpp_a < 1) bpp_a = 1;
         if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
         else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);

@@ -121,6 +121,9 @@ __device__ __forceinline__ m3d_gf4 m3d_as_global(const float4* p) { return (m3d_
 __device__ __forceinline__ m3d_gu32 m3d_as_global(const uint32_t* p) { return (m3d_gu32)(const void M3D_GLOBAL*)p; }
 __device__ __forceinline__ uint4 m3d_ld(m3d_gu4 p, size_t i) { const m3d_u32x4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 m3d_ld(m3d_gf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+// streamed-once data (source points, per-query results): non-temporal so it does not evict the gathered
+// target points / bucket table from the XCD's 4 MiB L2 (one pair's gather set is ~2.6 MB)
+__device__ __forceinline__ float4 m3d_ld_stream(m3d_gf4 p, size_t i) { const m3d_f32x4 v = __builtin_nontemporal_load(&p[i]); return make_float4(v.x, v.y, v.z, v.w); }
 
 // slot of the bucket `key` or -1; `lo` receives the first half of its entry {key, start, count, big}
 __device__ __forceinline__ int m3d_find_bucket(const M3dBucket* __restrict__ htab, uint32_t hmask, int hshift, uint32_t key, uint4& lo) {

@@ -59,11 +59,15 @@ hipError_t m3d_launch_aggregate(hipStream_t s, const M3dAggArgs& A);
 struct M3dNnWork {               // variant-2 workspace, all per pair with the same stride
     int* match;                  // [n_pairs * stride] result of every query, kept between iterations (seeds the next search)
     int* heavy;                  // [n_pairs * stride] worklist of queries that need the full walk
-    unsigned int* heavy_cnt;     // [n_pairs] worklist lengths (zeroed at batch start, reset by k_accumulate_matches)
+    unsigned int* heavy_cnt;     // [(pair * blocks + blk) * 2 + {0,1}] block-local worklist lengths, rewritten every iteration
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
+    float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
+    int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
+    int coop_div;                // worklists shorter than n / coop_div use the cooperative kernel (M3DREG_COOP_DIV)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
     int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)
+    int nontemporal;             // A/B: stream the source points / per-query results with non-temporal accesses (M3DREG_NT)
 };
 // e0/e1 (optional): events recorded immediately before / after the launches of one linearisation (search + reduction);
 // k0/k1 (optional): events around the dominant kernel alone (k_nn_light; not launched on the first iteration of a level)

@@ -94,6 +94,9 @@ struct m3dreg_handle {
     unsigned int seq = 0;
     uint64_t launched_iters = 0, skipped_iters = 0;
     int full_rows = 1;                 // full search walks voxel rows (default); 0 = whole-bucket scan (M3DREG_FULL_ROWS, A/B: rows win by 10 %)
+    int nontemporal = 0;
+    int certify = 1;
+    int coop_div = 1;                  // 1 = worklists are always searched cooperatively (A/B: best); k > 1 = only lists shorter than n / k
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
     int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
@@ -485,19 +488,19 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         if (h->d_match) hipFree(h->d_match);
         h->d_match = nullptr; h->match_cap = 0;
         const size_t cap = n_pairs * stride + n_pairs * stride / 4;
-        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // match | heavy list | cache (int64)
+        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | heavy list | cache (int64) | certificate state (float4)
         h->match_cap = cap;
     }
-    if (n_pairs > h->match_pairs_cap) {
+    const size_t n_cnt = 4 * n_pairs * (stride / 256 + 3);   // per 256-query block: two worklist lengths + their two prefixes
+    if (n_cnt > h->match_pairs_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_heavy_cnt) hipFree(h->d_heavy_cnt);
         h->d_heavy_cnt = nullptr;
-        HIPCHK(h, hipMalloc((void**)&h->d_heavy_cnt, sizeof(unsigned int) * (n_pairs + 8)));
-        h->match_pairs_cap = n_pairs + 8;
+        HIPCHK(h, hipMalloc((void**)&h->d_heavy_cnt, sizeof(unsigned int) * (n_cnt + n_cnt / 4)));
+        h->match_pairs_cap = n_cnt + n_cnt / 4;
     }
     h->match_stride = int(stride);
     h->match_pairs = n_pairs;
-    HIPCHK(h, hipMemsetAsync(h->d_heavy_cnt, 0, sizeof(unsigned int) * n_pairs, h->stream));
     return M3DREG_OK;
 }
 
@@ -505,8 +508,12 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     M3dNnWork w;
     w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
+    w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
+    w.certify = h->certify;
+    w.coop_div = h->coop_div;
     w.seed_reach = h->seed_reach;
     w.full_rows = h->full_rows;
+    w.nontemporal = h->nontemporal;
     return w;
 }
 
@@ -619,6 +626,9 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     h->device = device;
     h->params = *params;
     if (const char* v = getenv("M3DREG_FULL_ROWS")) h->full_rows = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_COOP_DIV")) { int q = atoi(v); if (q >= 1 && q <= 64) h->coop_div = q; }
+    if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_NT")) h->nontemporal = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }

@@ -552,6 +552,20 @@ static int solve_update(const int64_t sums[ORC_NSUMS], const int32_t exps[6], co
 /* ------------------------------------------------------------------------------------------- */
 /* exported C entry points (ctypes)                                                             */
 /* ------------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* thread count of the OpenMP build (bench.py cpu_baseline); a no-op in the serial build */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 int orc_default_params(orc_params* p) {
     if (!p) return ORC_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));

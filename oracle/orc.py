@@ -39,6 +39,7 @@ def _lib(omp=False):
         L.orc_debug_nn.argtypes = [vp, C.c_int, f32p, C.c_size_t, C.c_float, i32p, f32p]
         L.orc_debug_accumulate.argtypes = [C.POINTER(abi.Params), vp, vp, C.c_int, f32p, i64p, i32p, i32p, f32p]
         L.orc_align_clouds.argtypes = [C.POINTER(abi.Params), vp, vp, f32p, f32p, C.POINTER(abi.Stats), f64p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_agg_create.argtypes = [f64p]
         L.orc_agg_create.restype = vp
         L.orc_agg_destroy.argtypes = [vp]
@@ -59,6 +60,11 @@ def _lib(omp=False):
         L.orc_agg_ready.argtypes = [vp]
         _LIBS[name] = L
     return _LIBS[name]
+
+
+def set_threads(n, omp=True):
+    """OpenMP thread count of the oracle (the env var is read too early when torch loaded libgomp first)."""
+    return _lib(omp).orc_set_threads(int(n))
 
 
 def _ptr(a, ct):
