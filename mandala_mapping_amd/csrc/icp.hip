@@ -939,9 +939,9 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     const unsigned int* pref = A.pref + (size_t)pair * 2 * (bpp_list + 1) + (SEEDED ? 0 : (bpp_list + 1));
     const unsigned int total = pref[bpp_list];
     if (total * (unsigned int)A.coop_div >= (unsigned int)n) return;   // long list: the one-query-per-lane kernel handles it
-    const unsigned int j = (unsigned int)(blk * 32 + ((int)threadIdx.x >> 3));   // 32 queries per block
-    if (j >= total) return;                                          // uniform over the 8 lanes of a query
     const int sub = threadIdx.x & 7;
+    // a fixed number of blocks per list strides over it: no empty workgroups however short the list is
+    for (unsigned int j = (unsigned int)(blk * 32 + ((int)threadIdx.x >> 3)); j < total; j += (unsigned int)((bpp >> 1) * 32)) {   // j is uniform over the 8 lanes of a query
     const int pb = m3d_find_block(pref, bpp_list, j);
     const int i = SEEDED ? list[pb * 256 + (int)(j - pref[pb])] : list[pb * 256 + 255 - (int)(j - pref[pb])];
     const float4 p = m3d_ld(src, i);
@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
         out[i] = m;
         if (m == M3D_NN_NONE_CACHED) cache[i] = code;
         if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+    }
     }
 }
 
@@ -1283,7 +1284,9 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
             hipLaunchKernelGGL(k_nn_scan, dim3(n_pairs), dim3(512), 0, s, d_jobs, bpp_s, first_of_level, (const unsigned int*)A.heavy_cnt, A.pref);
             if (w.coop_div > 1) hipLaunchKernelGGL(k_nn_seeded<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
             // short-list regime (< n/8 entries): 8 lanes per query; at most n/8 queries -> n/256 blocks of 32 queries
-            const int bpp_c = 2 * ((max_n_src / w.coop_div + 31) / 32 + 1);   // per pair: half for each list
+            int bpp_c = 2 * ((max_n_src / w.coop_div + 31) / 32 + 1);         // per pair: half for each list ...
+            const int cap_c = 2 * ((256 * w.coop_cap) / (2 * (n_pairs < 1 ? 1 : n_pairs)) + 1);   // ... but never more than coop_cap blocks per CU in total: they stride
+            if (bpp_c > cap_c) bpp_c = cap_c;
             if (c0) (void)hipEventRecord(c0, s);    // the dominant kernel alone (bench.py roofline)
             hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A, bpp_s);
             if (c1) (void)hipEventRecord(c1, s);

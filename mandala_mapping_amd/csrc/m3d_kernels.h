@@ -64,6 +64,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int coop_div;                // worklists shorter than n / coop_div use the cooperative kernel (M3DREG_COOP_DIV)
+    int coop_cap;                // at most this many cooperative-search workgroups per CU (they stride over the lists; M3DREG_COOP_CAP)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
     int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)
