@@ -293,3 +293,36 @@ def test_degenerate_clouds(reg, orc):
     _check_bucketing(R.cloud(two), orc.Cloud(p, two), 1)
     T, st = R.align(R.cloud(two), R.cloud(two))
     assert st.status == abi.TOO_FEW_CORR
+
+
+def test_randomised_stress_against_oracle(reg, orc):
+    """24 random registrations (cloud sizes, leaf, metric, levels, noise, initial offsets, non-finite points,
+    batch composition all drawn from a seeded RNG): every per-iteration pose must match the oracle bit for bit.
+    Exercises the certificate / worklist / cooperative-search chain on many different fill patterns."""
+    rng = np.random.default_rng(2026)
+    for case in range(6):
+        metric = int(rng.integers(0, 2))
+        two_levels = bool(rng.integers(0, 2))
+        leaf = float(rng.choice([0.15, 0.2, 0.3]))
+        p = _params(leaf=(2 * leaf, leaf) if two_levels else leaf, iterations=(6, 9) if two_levels else 12,
+                    max_corr_dist=(4 * leaf, 2.5 * leaf) if two_levels else 2.5 * leaf, metric=metric, normal_leaf=max(0.4, 2 * leaf),
+                    eps_rot=1e-6, eps_trans=1e-6)
+        R = reg.Registrar(p)
+        pairs, refs = [], []
+        for k in range(4):
+            n_az = int(rng.integers(150, 500))
+            src, tgt, Tgt = synth.hdl32_pair(n_az, int(rng.integers(1, 10**6)), int(rng.integers(1, 10**6)), dx=float(rng.uniform(-0.3, 0.3)),
+                                             dy=float(rng.uniform(-0.2, 0.2)), dyaw_deg=float(rng.uniform(-3, 3)),
+                                             base=(float(rng.uniform(-5, 5)), float(rng.uniform(-3, 3)), float(rng.uniform(-180, 180))))
+            if k == 1:
+                src = src.copy(); src[:: 41] = np.nan
+            T0 = synth.perturb(Tgt, rng, 0.8, 0.08) if k % 2 else np.eye(4)
+            cs, ct = R.clouds([src, tgt])
+            pairs.append((cs, ct, T0))
+            refs.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=32))
+        Tb, stb = R.align_batch(pairs)
+        for k in range(4):
+            assert np.array_equal(Tb[k], refs[k][0]), (case, k)
+            _same_stats(stb[k], refs[k][1])
+            T1, st1 = R.align(*pairs[k])
+            assert np.array_equal(R.trace(), refs[k][2]), (case, k)
