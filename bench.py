@@ -43,6 +43,9 @@ def parse():
                     help="hand over HOST PointCloud2 buffers every step (PCIe-inclusive rate; reported in DESIGN.md, never the headline)")
     ap.add_argument("--converge", action="store_true",
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="do not overlap the bucketing of batch k+1 (second handle, second HIP stream) with the iterations of batch k")
+    ap.add_argument("--icp-priority", action="store_true", help="run the iteration chain on a high-priority stream (A/B)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -69,8 +72,12 @@ def main():
     # fixed iteration count: eps = 0 never triggers, so every launch of the dominant kernel does full work
     params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE,
                              normal_leaf=0.4, eps_rot=1e-5 if args.converge else 0.0, eps_trans=1e-5 if args.converge else 0.0)
-    stream = torch.cuda.Stream(device=dev)
+    stream = torch.cuda.Stream(device=dev, priority=(-1 if args.icp_priority else 0))
     reg = binding.Registrar(params, device=local_rank, stream=C.c_void_p(stream.cuda_stream))
+    # second handle on its own stream: buckets the NEXT batch while this one iterates (copy/compute-style overlap;
+    # every step still does all of its own work, steps merely overlap in time inside the timed region)
+    stream_b = torch.cuda.Stream(device=dev)
+    reg_b = reg if args.no_overlap else binding.Registrar(params, device=local_rank, stream=C.c_void_p(stream_b.cuda_stream))
 
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
     payloads, gts, host_pairs, host_msgs = [], [], [], []
@@ -88,21 +95,38 @@ def main():
 
     last = {}
 
-    def step():
+    def make_clouds():
+        """decode + AABB + bucketing + normals of this rank's 2B clouds, one batched pipeline"""
         if args.from_host:
-            cl = reg.clouds(host_msgs)              # host buffers cross PCIe inside the timed region
+            cl = reg_b.clouds(host_msgs)            # host buffers cross PCIe inside the timed region
         else:
             items = []
             for ds, ns, dt, nt in payloads:
                 items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
-            cl = reg.clouds_from_device(items)      # all 2B clouds bucketed by one batched pipeline
-        clouds = [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
-        T, st = reg.align_batch([(s, t, None) for s, t in clouds])
+            cl = reg_b.clouds_from_device(items)
+        return [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
+
+    def finish(T, st, clouds):
         if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI)
             allT, allst = sharding.gather_results([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, dev)
             last["all"] = (allT, allst)
         last["T"], last["st"], last["clouds"] = T, st, clouds
+
+    def run_steps(k):
+        """k steps; with overlap the bucketing of step i+1 is enqueued while step i iterates"""
+        nxt = make_clouds()
+        for i in range(k):
+            clouds = nxt
+            reg.align_batch_async(reg._pairs([(s_, t_, None) for s_, t_ in clouds]), B)
+            nxt = make_clouds() if (i + 1 < k and not args.no_overlap) else None
+            T, st = reg.batch_wait(B)
+            finish(T, st, clouds)
+            if nxt is None and i + 1 < k:
+                nxt = make_clouds()
         return clouds
+
+    def step():
+        return run_steps(1)
 
     # algorithmic bytes of one launch of the dominant kernel (SURVEY.md §8d), from the real clouds
     clouds0 = step()
@@ -129,8 +153,7 @@ def main():
     reg.profile_read(1, reset=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
-        step()
+    run_steps(K)
     barrier()
     t1 = time.perf_counter()
     launches, kern_ms = reg.profile_read(1, reset=True)       # k_nn_coop alone
@@ -167,7 +190,8 @@ def main():
                                    f"{n_pts} pts/cloud, point-to-plane, leaf 0.1 m, {args.iters} fixed iterations, "
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
-                       "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step"},
+                       "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step",
+                       "overlap": "none" if args.no_overlap else "bucketing of step k+1 on a second HIP stream while step k iterates"},
             "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
             "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
             "iteration_algorithmic_GBps": alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9,
