@@ -35,9 +35,10 @@ EXPORTS = [
 def lib():
     """Load libm3dreg.so once. torch (when installed) is imported first so that this process ends up
     with a single HIP runtime: torch bundles libamdhip64.so.7 under the same soname the library needs."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    LIB_PATH = os.environ.get("M3DREG_LIB", LIB_PATH)   # A/B of two builds on one box (scripts/ab.sh)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the registration path)")

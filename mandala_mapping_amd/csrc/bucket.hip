@@ -497,6 +497,16 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     nrm_in[oi] = out;
 }
 
+// normals re-ordered into each level's sorted order: the reduction kernel gathers them by MATCH position, and
+// neighbouring queries match neighbouring sorted positions (same cache lines) but unrelated input indices
+__global__ __launch_bounds__(256) void k_gather_normals(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.nrm_sorted) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B.n) return;
+    B.nrm_sorted[j] = B.nrm_in[B.perm_out[j]];
+}
+
 // ---- export helpers (introspection API) -----------------------------------------------------------
 __global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __restrict__ nrm, int n, float* __restrict__ xyz,
                                 float* __restrict__ nxyz) {
@@ -504,10 +514,7 @@ __global__ void k_export_sorted(const float4* __restrict__ pts, const float4* __
     if (j >= n) return;
     const float4 p = pts[j];
     xyz[3 * j] = p.x; xyz[3 * j + 1] = p.y; xyz[3 * j + 2] = p.z;
-    if (nrm && nxyz) {   // normals are stored by input index: gather into sorted order for the export
-        const float4 q = nrm[__float_as_uint(p.w) & M3D_IDX_MASK];
-        nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z;
-    }
+    if (nrm && nxyz) { const float4 q = nrm[j]; nxyz[3 * j] = q.x; nxyz[3 * j + 1] = q.y; nxyz[3 * j + 2] = q.z; }
 }
 
 // ---- host-side launchers ----------------------------------------------------------------------------
@@ -545,6 +552,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         hipLaunchKernelGGL(k_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);
+        hipLaunchKernelGGL(k_gather_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     }
     return hipGetLastError();
 }

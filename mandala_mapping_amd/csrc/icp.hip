@@ -250,7 +250,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_accumulate(const M3dJob* __
         const int j = m3d_nn27(L, ux, uy, uz, dmax2, d2, q);
         if (j < 0) continue;
         float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & M3D_IDX_MASK];
+        if (METRIC == 1) nq = L.nrm_in[__float_as_uint(q.w) & M3D_IDX_MASK];
         m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
     }
     block_reduce_to_global<NACC>(acc, st->sums);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_lds(const M3dJob* __restric
         if (lane == 0) atomicAdd(&st->ctr[fast ? 0 : 1], 1u);
         if (B.found >= 0) {
             float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (METRIC == 1) nq = L.nrm[__float_as_uint(B.q.w) & M3D_IDX_MASK];
+            if (METRIC == 1) nq = L.nrm_in[__float_as_uint(B.q.w) & M3D_IDX_MASK];
             m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, B.q, B.d2, nq, cx, cy, cz, S);
         }
     }
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
         const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
         const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
         float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm[__float_as_uint(q.w) & M3D_IDX_MASK];
+        if (METRIC == 1) nq = L.nrm[m];   // sorted order: neighbouring matches share cache lines
         m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
     }
     block_reduce_to_global<NACC>(acc, st->sums);

@@ -9,7 +9,7 @@
 //                     per-voxel populations (uint16). T = smallest power of two >= 2 * occupied buckets,
 //                     derived on the device after the sort (no host round trip).
 //                     A query's 27 voxels live in at most 2x2x2 buckets: 8 probes instead of 27.
-//   nrm   float4[n]   unit normals by INPUT index ({0,0,0,0} = no usable normal), point-to-plane only
+//   nrm   float4[n]   unit normals in the level's sorted order ({0,0,0,0} = no usable normal), point-to-plane only
 // The source side of a registration streams the source cloud's own sorted float4 array (16 B per lane,
 // 1 KiB per wave instruction: fully coalesced), so the 64 lanes of a wave hold spatially adjacent queries.
 #pragma once
@@ -46,6 +46,7 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* pts;
     const float4* nrm;
+    const float4* nrm_in;      // the same normals by INPUT index (fused kernel variants 0/1 only)
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
     M3dGrid g;

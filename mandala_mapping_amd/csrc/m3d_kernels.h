@@ -28,7 +28,8 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t bigcap;
     uint32_t* dyn;               // [8] (zeroed) out: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
-    float4* nrm_in;              // [n] out: normals by input index, normal grids only
+    float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
+    float4* nrm_sorted;          // [n] out: the same normals in this level's sorted order (level builds of point-to-plane clouds, else null)
 };
 
 float m3d_unord_f32(uint32_t u);

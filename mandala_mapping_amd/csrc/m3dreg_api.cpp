@@ -32,6 +32,7 @@ struct DevLevel {
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
     uint32_t* perm = nullptr;
+    float4* nrm = nullptr;         // normals in this level's sorted order (point-to-plane)
     uint32_t n_cells_host = 0;
 };
 
@@ -281,6 +282,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.htab = k.take<M3dBucket>(L.hcap);
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
+        L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
     }
     return (k.off + 255) & ~size_t(255);
 }
@@ -415,7 +417,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = W.dyn;
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
-            B.nrm_in = is_ng ? c->nrm_in : nullptr;
+            B.nrm_in = c->nrm_in;
+            B.nrm_sorted = is_ng ? nullptr : L.nrm;
         }
     }
     B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
@@ -439,7 +442,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
 
 M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
     M3dLevelDev d{};
-    d.pts = L.pts; d.nrm = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.g = L.grid;
+    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.g = L.grid;
     return d;
 }
 
@@ -1032,7 +1035,7 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
     if (sorted_xyz || normals) {
         HIPCHK(h, hipMalloc((void**)&dx, 12 * n));
         if (normals) { hipError_t e = hipMalloc((void**)&dn, 12 * n); if (e != hipSuccess) { hipFree(dx); return fail(h, M3DREG_ERR_HIP, "hipMalloc", e); } }
-        hipError_t e = m3d_launch_export_sorted(h->stream, L.pts, normals ? c->nrm_in : nullptr, int(n), dx, dn);
+        hipError_t e = m3d_launch_export_sorted(h->stream, L.pts, normals ? L.nrm : nullptr, int(n), dx, dn);
         if (e == hipSuccess && sorted_xyz) e = hipMemcpyAsync(sorted_xyz, dx, 12 * n, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && normals) e = hipMemcpyAsync(normals, dn, 12 * n, hipMemcpyDeviceToHost, h->stream);
         hipError_t e2 = hipStreamSynchronize(h->stream);
