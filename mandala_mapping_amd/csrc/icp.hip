@@ -212,13 +212,16 @@ __device__ __forceinline__ void m3d_accumulate_match(long long (&acc)[NACC], flo
     }
 }
 
+// the pose is the same for every lane of a pair's workgroups: keep it in scalar registers (12 VGPRs less per kernel;
+// the search kernels are latency-bound, so their throughput is their occupancy)
+__device__ __forceinline__ float m3d_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ void m3d_load_pose(const M3dPairState* st, float (&R)[9], float (&tt)[3]) {
     // current pose rounded to float (spec: R row-major from the column-major double pose)
 #pragma unroll
     for (int r = 0; r < 3; r++) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) R[3 * r + c] = (float)st->T[c * 4 + r];
-        tt[r] = (float)st->T[12 + r];
+        for (int c = 0; c < 3; c++) R[3 * r + c] = m3d_uniform((float)st->T[c * 4 + r]);
+        tt[r] = m3d_uniform((float)st->T[12 + r]);
     }
 }
 
@@ -751,6 +754,7 @@ struct M3dNnArgs {
     int coop_div;                      // a worklist shorter than n / coop_div is searched cooperatively (8 lanes per query)
     float seed_reach;                  // seeds farther than this many voxel edges go to the heavy list (<= 0.99)
     int full_rows;                     // A/B: 1 = voxel-row full search, 0 = whole-bucket scan
+    int thread_div;                    // a worklist of >= n / thread_div entries is searched one query per LANE inside k_nn_coop (0 = never)
 };
 
 #define NN_SETUP()                                                                                          \
@@ -932,13 +936,33 @@ __device__ __forceinline__ void m3d_walk_bucket(const M3dQuery& Q, const uint4& 
 }
 
 // one launch serves both worklists: the first half of a pair's blocks takes the seeded list, the second half the full-search list
-__global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A, int bpp_list) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A, int bpp_list) {
     NN_SETUP();
     const bool SEEDED = blk < (bpp >> 1);
     blk = SEEDED ? blk : blk - (bpp >> 1);
     const unsigned int* pref = A.pref + (size_t)pair * 2 * (bpp_list + 1) + (SEEDED ? 0 : (bpp_list + 1));
     const unsigned int total = pref[bpp_list];
     if (total * (unsigned int)A.coop_div >= (unsigned int)n) return;   // long list: the one-query-per-lane kernel handles it
+    if (A.thread_div > 0 && (unsigned long long)total * (unsigned int)A.thread_div >= (unsigned int)n) {
+        // LONG list (the first iterations after a big pose update): throughput matters, not latency. One query per
+        // lane prunes voxel after voxel against its running best, which the 8 parallel lanes of a group cannot do:
+        // measured 150 us for ALL 800 k queries this way against 284 us for the cooperative walk of most of them.
+        for (unsigned int j = (unsigned int)(blk * 256 + (int)threadIdx.x); j < total; j += (unsigned int)((bpp >> 1) * 256)) {
+            const int pb = m3d_find_block(pref, bpp_list, j);
+            const int i = SEEDED ? list[pb * 256 + (int)(j - pref[pb])] : list[pb * 256 + 255 - (int)(j - pref[pb])];
+            const float4 p = m3d_ld(src, i);
+            const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+            const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+            const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+            int m = -1; long long code = 0; float sec = 0.0f;
+            if (SEEDED) m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, out[i], 0ll, A.seed_reach, sec);
+            else if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code, sec);
+            out[i] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+            if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+        }
+        return;
+    }
     const int sub = threadIdx.x & 7;
     // a fixed number of blocks per list strides over it: no empty workgroups however short the list is
     for (unsigned int j = (unsigned int)(blk * 32 + ((int)threadIdx.x >> 3)); j < total; j += (unsigned int)((bpp >> 1) * 32)) {   // j is uniform over the 8 lanes of a query
@@ -1082,19 +1106,33 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     for (int i = 0; i < NACC; i++) acc[i] = 0;
     const int n = J.n_src;
     const int* in = match + (size_t)pair * match_stride;
-    for (int i = blk * ICP_THREADS + threadIdx.x; i < n; i += bpp * ICP_THREADS) {
-        const int m = in[i];
-        if (m < 0) continue;
-        const float4 p = J.src[i];
-        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        const float4 q = L.pts[m];
-        const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
-        const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
-        float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm[m];   // sorted order: neighbouring matches share cache lines
-        m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
+    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
+    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
+    // dependent gathers (match -> point, normal), so its speed is the number of them in flight
+    constexpr int NB = 4;
+    const int stride = bpp * ICP_THREADS;
+    for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
+        int m[NB]; float4 p[NB], q[NB], nq[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const size_t mm = (size_t)max(m[k], 0);
+            q[k] = m3d_ld(pts, mm);
+            nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (m[k] < 0) continue;
+            const float ux = fmaf(R[0], p[k].x, fmaf(R[1], p[k].y, fmaf(R[2], p[k].z, tt[0])));
+            const float uy = fmaf(R[3], p[k].x, fmaf(R[4], p[k].y, fmaf(R[5], p[k].z, tt[1])));
+            const float uz = fmaf(R[6], p[k].x, fmaf(R[7], p[k].y, fmaf(R[8], p[k].z, tt[2])));
+            const float ex = ux - q[k].x, ey = uy - q[k].y, ez = uz - q[k].z;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
+            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
+        }
     }
     block_reduce_to_global<NACC>(acc, st->sums);
 }
@@ -1276,7 +1314,7 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.pref = w.heavy_cnt + (size_t)2 * n_pairs * bpp_s; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.coop_div = w.coop_div; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows;
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.pref = w.heavy_cnt + (size_t)2 * n_pairs * bpp_s; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.coop_div = w.coop_div; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows; A.thread_div = w.thread_div;
         if (!first_of_level) {
             hipEvent_t c0 = k0, c1 = k1;
             if (w.nontemporal) hipLaunchKernelGGL(k_nn_light<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);

@@ -66,6 +66,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int coop_div;                // worklists shorter than n / coop_div use the cooperative kernel (M3DREG_COOP_DIV)
     int coop_cap;                // at most this many cooperative-search workgroups per CU (they stride over the lists; M3DREG_COOP_CAP)
+    int thread_div;              // worklists of >= n / thread_div entries are searched one query per lane inside k_nn_coop (M3DREG_THREAD_DIV, 0 = never)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
     int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)

@@ -97,6 +97,7 @@ struct m3dreg_handle {
     int full_rows = 1;                 // full search walks voxel rows (default); 0 = whole-bucket scan (M3DREG_FULL_ROWS, A/B: rows win by 10 %)
     int nontemporal = 0;
     int certify = 1;
+    int thread_div = 8;                // worklists of >= n/8 entries: one query per lane (throughput) instead of 8 lanes per query (latency)
     int coop_cap = 32;                 // A/B on one box: 32 workgroups per CU beat both 8 (serialises) and uncapped (empty workgroups)
     int coop_div = 1;                  // 1 = worklists are always searched cooperatively (A/B: best); k > 1 = only lists shorter than n / k
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
@@ -516,6 +517,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.certify = h->certify;
     w.coop_div = h->coop_div;
     w.coop_cap = h->coop_cap;
+    w.thread_div = h->thread_div;
     w.seed_reach = h->seed_reach;
     w.full_rows = h->full_rows;
     w.nontemporal = h->nontemporal;
@@ -631,6 +633,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     h->device = device;
     h->params = *params;
     if (const char* v = getenv("M3DREG_FULL_ROWS")) h->full_rows = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_THREAD_DIV")) { int q = atoi(v); if (q >= 0 && q <= 1024) h->thread_div = q; }
     if (const char* v = getenv("M3DREG_COOP_CAP")) { int q = atoi(v); if (q >= 1 && q <= 4096) h->coop_cap = q; }
     if (const char* v = getenv("M3DREG_COOP_DIV")) { int q = atoi(v); if (q >= 1 && q <= 64) h->coop_div = q; }
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
