@@ -145,22 +145,39 @@ __device__ __forceinline__ long long m3d_quant(float term, float scale) {
 __host__ __device__ constexpr int hslot21(int k, int l) { return k * 6 - (k * (k - 1)) / 2 + (l - k); }
 
 template <int NACC>
-__device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], long long* __restrict__ sums) {
-    __shared__ long long red[ICP_WAVES][NACC];
+__device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], long long* __restrict__ sums, long long* __restrict__ partial = nullptr) {
+    __shared__ long long red[ICP_WAVES][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Transposed butterfly: at every step a lane gives away half of the values it still holds and adds the
+    // partner's copy of the half it keeps, so the wave reduces all (up to 32) sums with 16+8+4+2+1+1 = 32
+    // 64-bit shuffles instead of 6 per sum (174 for 29 sums). The shuffles go through the CU's single LDS
+    // pipeline, which all its waves share: they were half of the reduction pass.
+    long long v[32];
 #pragma unroll
-    for (int i = 0; i < NACC; i++) {
-        long long v = acc[i];
+    for (int i = 0; i < 32; i++) v[i] = (i < NACC) ? acc[i] : 0ll;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if (lane == 0) red[wave][i] = v;
+    for (int h = 16; h >= 1; h >>= 1) {
+        const bool up = (lane & (2 * h)) != 0;     // h = 16 pairs with lane ^ 32, ... h = 1 with lane ^ 2
+#pragma unroll
+        for (int k = 0; k < h; k++) {
+            const long long send = up ? v[k] : v[k + h];
+            const long long keep = up ? v[k + h] : v[k];
+            v[k] = keep + __shfl_xor(send, 2 * h);
+        }
     }
+    v[0] += __shfl_xor(v[0], 1);
+    const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0 && slot < NACC) red[wave][slot] = v[0];
     __syncthreads();
     if (threadIdx.x < NACC) {
         long long v = 0;
 #pragma unroll
         for (int w = 0; w < ICP_WAVES; w++) v += red[w][threadIdx.x];
-        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[threadIdx.x]), (unsigned long long)v);
+        // `partial`: this block's own slot, summed by the solve kernel (integer sums: any order gives the same bits).
+        // Atomics on the pair's 29 shared words serialise at ~50-100 ns each; with ~50 blocks per pair they were
+        // a quarter of the reduction pass.
+        if (partial) partial[threadIdx.x] = v;
+        else if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[threadIdx.x]), (unsigned long long)v);
     }
 }
 
@@ -1088,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_nn_heavy(const M3dJob* __restrict__ job
 template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
-                                                                    unsigned int* __restrict__ heavy_cnt) {
+                                                                    long long* __restrict__ partials) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk);
     const M3dJob& J = jobs[pair];
@@ -1134,7 +1151,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
             m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
         }
     }
-    block_reduce_to_global<NACC>(acc, st->sums);
+    block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
 }
 
 // point-to-point: expand the 17 transported sums into the spec's 29 slots (exact integer identities:
@@ -1223,13 +1240,15 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
 // at this level} as ONE 8-byte store into host-mapped memory: the host polls it between launches and stops
 // enqueuing a level's remaining iterations once nothing is active — early termination without any
 // host-device synchronisation (a stale read only costs a few empty launches, never correctness).
-__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level) {
+__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr) {
     M3dPairState* st = J.st;
     if (st->done || (!first_of_level && st->level_done)) return;
     long long sums[M3D_NSUMS];
-    if (J.metric == 1) { for (int i = 0; i < M3D_NSUMS; i++) sums[i] = st->sums[i]; }
-    else { long long in[17]; for (int i = 0; i < 17; i++) in[i] = st->sums[i]; expand_pt2pt(in, sums); }
-    for (int i = 0; i < M3D_NSUMS; i++) st->sums[i] = 0;
+    const bool own = raw == nullptr;   // sums accumulated by atomics in the state (fused variants) or handed in (block partials)
+    if (own) raw = st->sums;
+    if (J.metric == 1) { for (int i = 0; i < M3D_NSUMS; i++) sums[i] = raw[i]; }
+    else { long long in[17]; for (int i = 0; i < 17; i++) in[i] = raw[i]; expand_pt2pt(in, sums); }
+    if (own) for (int i = 0; i < M3D_NSUMS; i++) st->sums[i] = 0;
     int exps[6];
     for (int i = 0; i < 6; i++) exps[i] = J.exps[i];
     double T[16];
@@ -1260,21 +1279,43 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
 }
 
 __global__ __launch_bounds__(256) void k_solve_update(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, unsigned int seq,
-                                                      unsigned long long* __restrict__ progress) {
-    __shared__ int s_active;
-    if (threadIdx.x == 0) s_active = 0;
-    __syncthreads();
-    int active = 0;
-    for (int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
-        m3d_solve_pair(jobs[p], first_of_level);
-        const M3dPairState* st = jobs[p].st;
-        if (!st->done && !st->level_done) active++;
+                                                      unsigned long long* __restrict__ progress, const long long* __restrict__ partials, int bpp_a) {
+    // one workgroup per pair: add up the reduction pass's block partials (8 segments x 32 slots), then one thread solves
+    __shared__ long long s_part[8][M3D_PARTIAL_STRIDE];
+    const int p = blockIdx.x;
+    const M3dJob& J = jobs[p];
+    M3dPairState* st = J.st;
+    const bool skip = st->done || (!first_of_level && st->level_done);
+    if (!skip && partials) {
+        const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
+        long long v = 0;
+        if (slot < M3D_NSUMS) for (int b = seg; b < bpp_a; b += 8) v += partials[((size_t)p * bpp_a + b) * M3D_PARTIAL_STRIDE + slot];
+        s_part[seg][slot] = v;
+        __syncthreads();
+        if (threadIdx.x < M3D_NSUMS) {
+            long long t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
+            s_part[0][threadIdx.x] = t;
+        }
+        __syncthreads();
     }
-    if (active) atomicAdd(&s_active, active);
-    __syncthreads();
-    if (threadIdx.x == 0 && progress) {
+    if (threadIdx.x != 0) return;
+    if (!skip) m3d_solve_pair(J, first_of_level, partials ? s_part[0] : nullptr);
+    // batch-wide arrival: the last pair to report publishes {sequence number, pairs still active at this level};
+    // the two counters live in pair 0's state and are only touched by agent-scope atomics
+    M3dPairState* g0 = jobs[0].st;
+    if (!st->done && !st->level_done) {
+        __hip_atomic_fetch_add(&g0->gsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned int t = __hip_atomic_fetch_add(&g0->gsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != (unsigned int)n_pairs - 1u) return;
+    const unsigned int active = __hip_atomic_exchange(&g0->gsync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g0->gsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (progress) {
         __threadfence_system();
-        *reinterpret_cast<volatile unsigned long long*>(progress) = ((unsigned long long)seq << 32) | (unsigned int)s_active;
+        *reinterpret_cast<volatile unsigned long long*>(progress) = ((unsigned long long)seq << 32) | active;
     }
 }
 
@@ -1309,8 +1350,15 @@ static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
     return b < 1 ? 1 : b;
 }
 
+// workgroups per pair of the reduction pass: ~8 queries per thread, so the 29-term block reduction is amortised
+int m3d_acc_blocks(int max_n_src) {
+    static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
+    const int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
+    return b < 1 ? 1 : b;
+}
+
 static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
-                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr) {
+                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr, long long* partials = nullptr) {
     if (variant == 2) {
         // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
@@ -1333,9 +1381,9 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
             if (w.nontemporal) hipLaunchKernelGGL(k_nn_heavy<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
             else hipLaunchKernelGGL(k_nn_heavy<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         }
-        int bpp_a = (max_n_src + 256 * 8 - 1) / (256 * 8); if (bpp_a < 1) bpp_a = 1;
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, w.heavy_cnt);
+        const int bpp_a = m3d_acc_blocks(max_n_src);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);
         if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
@@ -1358,9 +1406,10 @@ hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_p
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
                                     hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
     if (e0) (void)hipEventRecord(e0, s);
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1);
+    long long* partials = (variant == 2) ? w.partials : nullptr;   // the fused variants add into the state with atomics
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, partials);
     if (e1) (void)hipEventRecord(e1, s);
-    hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress);
+    hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)partials, m3d_acc_blocks(max_n_src));
     return hipGetLastError();
 }
 

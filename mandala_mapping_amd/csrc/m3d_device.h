@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #define M3D_NSUMS 29
+#define M3D_PARTIAL_STRIDE 32      // int64 words per block partial of the reduction pass (29 used)
 #define M3D_INVALID_KEY 0xFFFFFFFFu
 #define M3D_IDX_MASK 0x0FFFFFFFu   // pts[].w = input index (28 bits) | voxel position inside its bucket << 28
 #define M3D_SUB_SHIFT 28
@@ -64,6 +65,7 @@ struct M3dPairState {      // per-registration state, lives in HBM for the whole
     int32_t level_done;            // current level converged: skip its remaining iterations
     uint32_t ticket;
     uint32_t ctr[2];               // diagnostics: chunks served from LDS / chunks that fell back to the global walk
+    uint32_t gsync[2];             // pair 0 only: {pairs that reported this iteration, of which still active} (k_solve_update)
 };
 
 struct M3dJob {            // one pair at one level

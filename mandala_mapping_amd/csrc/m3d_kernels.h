@@ -67,6 +67,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     int coop_div;                // worklists shorter than n / coop_div use the cooperative kernel (M3DREG_COOP_DIV)
     int coop_cap;                // at most this many cooperative-search workgroups per CU (they stride over the lists; M3DREG_COOP_CAP)
     int thread_div;              // worklists of >= n / thread_div entries are searched one query per lane inside k_nn_coop (M3DREG_THREAD_DIV, 0 = never)
+    long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
     int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)
@@ -79,6 +80,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
                                     hipEvent_t e1, hipEvent_t k0, hipEvent_t k1);
+int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
                                       const M3dNnWork& w);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,

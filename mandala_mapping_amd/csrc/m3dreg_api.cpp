@@ -104,6 +104,8 @@ struct m3dreg_handle {
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
     int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
     unsigned int* d_heavy_cnt = nullptr;
+    long long* d_partials = nullptr;   // block partial sums of the reduction pass
+    size_t partials_cap = 0;
     size_t match_cap = 0;
     size_t match_pairs_cap = 0;
     int match_stride = 0;
@@ -504,6 +506,14 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         HIPCHK(h, hipMalloc((void**)&h->d_heavy_cnt, sizeof(unsigned int) * (n_cnt + n_cnt / 4)));
         h->match_pairs_cap = n_cnt + n_cnt / 4;
     }
+    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src)) * M3D_PARTIAL_STRIDE;
+    if (n_part > h->partials_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_partials) hipFree(h->d_partials);
+        h->d_partials = nullptr; h->partials_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_partials, sizeof(long long) * (n_part + n_part / 4)));
+        h->partials_cap = n_part + n_part / 4;
+    }
     h->match_stride = int(stride);
     h->match_pairs = n_pairs;
     return M3DREG_OK;
@@ -511,7 +521,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
 
 M3dNnWork nn_work(const m3dreg_handle* h) {
     M3dNnWork w;
-    w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride;
+    w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride; w.partials = h->d_partials;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
     w.certify = h->certify;
@@ -657,7 +667,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_heavy_cnt }) if (p) hipFree(p);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_heavy_cnt, (void*)h->d_partials }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
