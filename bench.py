@@ -43,9 +43,8 @@ def parse():
                     help="hand over HOST PointCloud2 buffers every step (PCIe-inclusive rate; reported in DESIGN.md, never the headline)")
     ap.add_argument("--converge", action="store_true",
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="do not overlap the bucketing of batch k+1 (second handle, second HIP stream) with the iterations of batch k")
-    ap.add_argument("--icp-priority", action="store_true", help="run the iteration chain on a high-priority stream (A/B)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -72,12 +71,14 @@ def main():
     # fixed iteration count: eps = 0 never triggers, so every launch of the dominant kernel does full work
     params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE,
                              normal_leaf=0.4, eps_rot=1e-5 if args.converge else 0.0, eps_trans=1e-5 if args.converge else 0.0)
-    stream = torch.cuda.Stream(device=dev, priority=(-1 if args.icp_priority else 0))
-    reg = binding.Registrar(params, device=local_rank, stream=C.c_void_p(stream.cuda_stream))
-    # second handle on its own stream: buckets the NEXT batch while this one iterates (copy/compute-style overlap;
-    # every step still does all of its own work, steps merely overlap in time inside the timed region)
-    stream_b = torch.cuda.Stream(device=dev)
-    reg_b = reg if args.no_overlap else binding.Registrar(params, device=local_rank, stream=C.c_void_p(stream_b.cuda_stream))
+    # --inflight D handles, each on its own HIP stream; step i runs entirely (bucketing + iterations) on handle i % D.
+    # With D = 2 the host enqueues step i+1 while step i is still iterating, so two 8-pair chains share the GPU:
+    # every iteration kernel is latency-bound, a second chain fills the idle CUs. Every step still
+    # does all of its own work inside the timed region; steps merely overlap in time.
+    D = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
+    regs = [binding.Registrar(params, device=local_rank, stream=C.c_void_p(st_.cuda_stream)) for st_ in streams]
+    reg = regs[0]
 
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
     payloads, gts, host_pairs, host_msgs = [], [], [], []
@@ -95,15 +96,15 @@ def main():
 
     last = {}
 
-    def make_clouds():
-        """decode + AABB + bucketing + normals of this rank's 2B clouds, one batched pipeline"""
+    def make_clouds(r):
+        """decode + AABB + bucketing + normals of this rank's 2B clouds, one batched pipeline on r's stream"""
         if args.from_host:
-            cl = reg_b.clouds(host_msgs)            # host buffers cross PCIe inside the timed region
+            cl = r.clouds(host_msgs)            # host buffers cross PCIe inside the timed region
         else:
             items = []
             for ds, ns, dt, nt in payloads:
                 items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
-            cl = reg_b.clouds_from_device(items)
+            cl = r.clouds_from_device(items)
         return [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
 
     def finish(T, st, clouds):
@@ -112,17 +113,25 @@ def main():
             last["all"] = (allT, allst)
         last["T"], last["st"], last["clouds"] = T, st, clouds
 
+    def enqueue(i):
+        r = regs[i % D]
+        clouds = make_clouds(r)
+        r.align_batch_async(r._pairs([(s_, t_, None) for s_, t_ in clouds]), B)
+        return clouds
+
     def run_steps(k):
-        """k steps; with overlap the bucketing of step i+1 is enqueued while step i iterates"""
-        nxt = make_clouds()
+        """k steps, at most D in flight: step i+D-1 is enqueued (its bucketing runs, its iterations queue up on its own
+        stream) before the host waits for step i"""
+        pending, nxt = [], 0
+        while nxt < min(D, k):
+            pending.append((nxt, enqueue(nxt))); nxt += 1
+        clouds = None
         for i in range(k):
-            clouds = nxt
-            reg.align_batch_async(reg._pairs([(s_, t_, None) for s_, t_ in clouds]), B)
-            nxt = make_clouds() if (i + 1 < k and not args.no_overlap) else None
-            T, st = reg.batch_wait(B)
+            idx, clouds = pending.pop(0)
+            T, st = regs[idx % D].batch_wait(B)
             finish(T, st, clouds)
-            if nxt is None and i + 1 < k:
-                nxt = make_clouds()
+            if nxt < k:
+                pending.append((nxt, enqueue(nxt))); nxt += 1
         return clouds
 
     def step():
@@ -139,26 +148,29 @@ def main():
     n_pts = int(np.mean([s.n for s, _ in clouds0]))
     del clouds0
     last.clear()
-    for _ in range(max(0, W - 1)):
-        step()
-        last.clear()
+    run_steps(max(W - 1, D if W > 0 else 0))   # untimed; at least one step per handle so that every pool is allocated
+    last.clear()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    reg.profile_enable(True)
-    reg.profile_read(0, reset=True)
-    reg.profile_read(1, reset=True)
+    for r in regs:
+        r.profile_enable(True)
+        r.profile_read(0, reset=True)
+        r.profile_read(1, reset=True)
     barrier()
     t0 = time.perf_counter()
     run_steps(K)
     barrier()
     t1 = time.perf_counter()
-    launches, kern_ms = reg.profile_read(1, reset=True)       # k_nn_coop alone
-    iters_timed, iter_ms = reg.profile_read(0, reset=True)    # search + reduction of one linearisation
-    reg.profile_enable(False)
+    launches = kern_ms = iters_timed = iter_ms = 0
+    for r in regs:
+        a, b = r.profile_read(1, reset=True)       # k_nn_coop alone
+        c, d = r.profile_read(0, reset=True)       # search + reduction of one linearisation
+        launches, kern_ms, iters_timed, iter_ms = launches + a, kern_ms + b, iters_timed + c, iter_ms + d
+        r.profile_enable(False)
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -191,7 +203,7 @@ def main():
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step",
-                       "overlap": "none" if args.no_overlap else "bucketing of step k+1 on a second HIP stream while step k iterates"},
+                       "overlap": "none (serial steps)" if D == 1 else f"{D} steps in flight, one HIP stream each"},
             "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
             "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
             "iteration_algorithmic_GBps": alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9,

@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void k_agg_scatter(M3dAggArgs A) {
 hipError_t m3d_launch_aggregate(hipStream_t s, const M3dAggArgs& A) {
     const int nblocks = (A.n + 255) / 256;
     hipLaunchKernelGGL(k_agg_count, dim3(nblocks), dim3(256), 0, s, A);
+    M3D_DBG(s, "k_agg_count");
     hipLaunchKernelGGL(k_agg_scan, dim3(1), dim3(1024), 0, s, A, nblocks);
+    M3D_DBG(s, "k_agg_scan");
     hipLaunchKernelGGL(k_agg_scatter, dim3(nblocks), dim3(256), 0, s, A);
+    M3D_DBG(s, "k_agg_scatter");
     return hipGetLastError();
 }

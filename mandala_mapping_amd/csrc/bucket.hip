@@ -527,6 +527,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_decode_aabb, dim3(blocks, n_clouds), dim3(256), 0, s, d_descs);
+    M3D_DBG(s, "k_decode_aabb");
     return hipGetLastError();
 }
 
@@ -537,27 +538,41 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
     const int ntiles = m3d_sort_tiles(max_n);
     const int cb = blocks > 256 ? 256 : blocks;
     hipLaunchKernelGGL(k_voxel_keys, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_voxel_keys");
     for (int pass = 0; pass < max_passes; pass++) {
         hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+        M3D_DBG(s, "k_rs_hist");
         hipLaunchKernelGGL(k_rs_scan, dim3(n_builds), dim3(1024), 0, s, d_builds, pass);
+        M3D_DBG(s, "k_rs_scan");
         hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+        M3D_DBG(s, "k_rs_scatter");
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_count_cells, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3((n_builds + 63) / 64), dim3(64), 0, s, d_builds, n_builds);
+    M3D_DBG(s, "k_table_params");
     hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_clear_table");
     hipLaunchKernelGGL(k_finalize_level, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_finalize_level");
     hipLaunchKernelGGL(k_bucket_counts, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_bucket_counts");
     hipLaunchKernelGGL(k_bucket_cum, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_bucket_cum");
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+        M3D_DBG(s, "k_cell_moments");
         hipLaunchKernelGGL(k_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);
+        M3D_DBG(s, "k_normals");
         hipLaunchKernelGGL(k_gather_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+        M3D_DBG(s, "k_gather_normals");
     }
     return hipGetLastError();
 }
 
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz) {
     hipLaunchKernelGGL(k_export_sorted, dim3((n + 255) / 256), dim3(256), 0, s, pts, nrm, n, xyz, nxyz);
+    M3D_DBG(s, "k_export_sorted");
     return hipGetLastError();
 }

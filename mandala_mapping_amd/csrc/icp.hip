@@ -1367,32 +1367,40 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
             hipEvent_t c0 = k0, c1 = k1;
             if (w.nontemporal) hipLaunchKernelGGL(k_nn_light<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
             else hipLaunchKernelGGL(k_nn_light<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            M3D_DBG(s, "k_nn_light");
             hipLaunchKernelGGL(k_nn_scan, dim3(n_pairs), dim3(512), 0, s, d_jobs, bpp_s, first_of_level, (const unsigned int*)A.heavy_cnt, A.pref);
+            M3D_DBG(s, "k_nn_scan");
             if (w.coop_div > 1) hipLaunchKernelGGL(k_nn_seeded<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            M3D_DBG(s, "k_nn_seeded");
             // short-list regime (< n/8 entries): 8 lanes per query; at most n/8 queries -> n/256 blocks of 32 queries
             int bpp_c = 2 * ((max_n_src / w.coop_div + 31) / 32 + 1);         // per pair: half for each list ...
             const int cap_c = 2 * ((256 * w.coop_cap) / (2 * (n_pairs < 1 ? 1 : n_pairs)) + 1);   // ... but never more than coop_cap blocks per CU in total: they stride
             if (bpp_c > cap_c) bpp_c = cap_c;
             if (c0) (void)hipEventRecord(c0, s);    // the dominant kernel alone (bench.py roofline)
             hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A, bpp_s);
+            M3D_DBG(s, "k_nn_coop");
             if (c1) (void)hipEventRecord(c1, s);
         }
         if (first_of_level || w.coop_div > 1) {   // full search of all queries (first iteration) / of a long worklist
             if (w.nontemporal) hipLaunchKernelGGL(k_nn_heavy<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
             else hipLaunchKernelGGL(k_nn_heavy<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            M3D_DBG(s, "k_nn_heavy");
         }
         const int bpp_a = m3d_acc_blocks(max_n_src);
         if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
         else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
+        M3D_DBG(s, "k_accumulate_matches");
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);
         if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
         else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
+        M3D_DBG(s, "k_icp_accumulate");
     } else {
         const int bpp = icp_lds_bpp(max_n_src, n_pairs);
         dim3 grid(bpp * n_pairs);
         if (metric == 1) hipLaunchKernelGGL(k_icp_lds<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
         else hipLaunchKernelGGL(k_icp_lds<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
+        M3D_DBG(s, "k_icp_lds");
     }
 }
 
@@ -1410,11 +1418,13 @@ hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_p
     launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, partials);
     if (e1) (void)hipEventRecord(e1, s);
     hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)partials, m3d_acc_blocks(max_n_src));
+    M3D_DBG(s, "k_solve_update");
     return hipGetLastError();
 }
 
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2) {
     hipLaunchKernelGGL(k_debug_nn, dim3((nq + 255) / 256), dim3(256), 0, s, L, q_xyz, nq, dmax2, out_idx, out_d2);
+    M3D_DBG(s, "k_debug_nn");
     return hipGetLastError();
 }

@@ -2,6 +2,19 @@
 // kernels (bucket.hip, icp.hip). Nothing here is exported from libm3dreg.so.
 #pragma once
 #include "m3d_device.h"
+#include <cstdio>
+#include <cstdlib>
+
+// M3DREG_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (locates a faulting kernel)
+static inline bool m3d_dbg_on() { static const bool on = getenv("M3DREG_DEBUG_SYNC") != nullptr; return on; }
+#define M3D_DBG(s, name)                                                                       \
+    do {                                                                                       \
+        if (m3d_dbg_on()) {                                                                    \
+            fprintf(stderr, "[m3dreg] %s ...", name); fflush(stderr);                          \
+            const hipError_t _de = hipStreamSynchronize(s);                                    \
+            fprintf(stderr, " %s\n", hipGetErrorString(_de)); fflush(stderr);                  \
+        }                                                                                      \
+    } while (0)
 
 struct M3dDecode {               // one cloud of a decode batch (a2)
     const uint8_t* raw;          // PointCloud2 payload on the device

@@ -489,7 +489,10 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
 }
 
 int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
-    const size_t stride = (size_t(max_n_src) + 63) & ~size_t(63);
+    // per-pair stride of the per-query arrays: a whole number of 256-query blocks — k_nn_light's block b owns worklist
+    // slots [256 b, 256 b + 256) of its pair, so a shorter stride lets a pair's last block spill into the next pair's
+    // first slots (a cross-pair race: found with 64 identical pairs giving different results)
+    const size_t stride = (size_t(max_n_src) + 255) & ~size_t(255);
     if (n_pairs * stride > h->match_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_match) hipFree(h->d_match);

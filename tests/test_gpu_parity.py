@@ -326,3 +326,24 @@ def test_randomised_stress_against_oracle(reg, orc):
             _same_stats(stb[k], refs[k][1])
             T1, st1 = R.align(*pairs[k])
             assert np.array_equal(R.trace(), refs[k][2]), (case, k)
+
+
+@pytest.mark.parametrize("copies", [9, 16])
+def test_identical_pairs_in_one_batch_give_identical_results(reg, orc, copies):
+    """The same scan pair `copies` times in one batch: every copy must reproduce the single registration (and the
+    oracle) bit for bit. Cloud sizes are chosen so that the last 256-query block of a pair is nearly empty — the
+    per-pair worklist segments must not overlap (regression: stride rounded to 64 instead of 256)."""
+    p = _params(leaf=0.2, iterations=10, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    src, tgt, Tgt = synth.hdl32_pair(400, 7, 8, dx=0.25, dy=-0.1, dyaw_deg=2.0)
+    keep = (len(src) // 256) * 256 + 3          # 3 queries in the pair's last block
+    src = src[:keep] if keep <= len(src) else src[: (len(src) // 256 - 1) * 256 + 3]
+    cs, ct = R.clouds([src, tgt])
+    assert cs.grid_info().n_valid % 256 == 3
+    To, sto, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+    T1, st1 = R.align(cs, ct)
+    assert np.array_equal(T1, To)
+    Tb, stb = R.align_batch([(cs, ct, None)] * copies)
+    for k in range(copies):
+        assert np.array_equal(Tb[k], To), k
+        _same_stats(stb[k], sto)
