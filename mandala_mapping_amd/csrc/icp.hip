@@ -176,7 +176,7 @@ __device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], l
         // `partial`: this block's own slot, summed by the solve kernel (integer sums: any order gives the same bits).
         // Atomics on the pair's 29 shared words serialise at ~50-100 ns each; with ~50 blocks per pair they were
         // a quarter of the reduction pass.
-        if (partial) partial[threadIdx.x] = v;
+        if (partial) __hip_atomic_store(&partial[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by another block (maybe another XCD) in the same launch
         else if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[threadIdx.x]), (unsigned long long)v);
     }
 }
@@ -474,304 +474,134 @@ __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
     return (long long)(Q.ic[0] + 1) | ((long long)(Q.ic[1] + 1) << 16) | ((long long)(Q.ic[2] + 1) << 32);
 }
 
-// 8-bit mask of the voxels of the bucket whose first voxel is (vx0,vy0,vz0) that lie inside the query's
-// neighbourhood, plus the conservative squared distance from the query to that part of the bucket
-__device__ __forceinline__ uint32_t m3d_bucket_mask(const M3dQuery& Q, int vx0, int vy0, int vz0, float& lb2) {
+// ---- the search of variant 2 -----------------------------------------------------------------------------------
+// Per-query state kept between the iterations of a level (see above): match[i], cache[i], state[i] = {u0, sec}.
+//
+// One walk routine serves every case. Order of the walk (the RESULT is order-independent: exact argmin, ties to the lowest
+// input index; only the amount of work depends on it):
+//   * buckets: the one holding the query's own voxel first (XOR enumeration of the 2x2x2), then its neighbours;
+//   * rows of a bucket: the (y,z) row nearest to the query first.
+// In dense regions the home voxel row already yields a bound of a few centimetres, after which nearly every other row
+// is discarded by its box distance without a single gather. Bucket entries are fetched one ahead (software pipeline)
+// instead of all eight up front: 16 VGPRs instead of 64, so the kernel fits 8 waves per SIMD — the walk is a chain of
+// dependent gathers, its throughput is the number of waves in flight.
+struct M3dWalk { unsigned long long bkey; int best; float bound, sec; bool any_point; };
+
+// rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first
+__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, int vx0, int vy0,
+                                              int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
     const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
+    if (sx0 > sx1) return;
+    const int ny = min(max(Q.ic[1] - vy0, 0), 1), nz = min(max(Q.ic[2] - vz0, 0), 1);   // nearest row of this bucket
     const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
-    const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy0, vy0 + sy1, Q.gl[1], Q.gh[1]);
-    const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz0, vz0 + sz1, Q.gl[2], Q.gh[2]);
-    lb2 = gx * gx + gy * gy + gz * gz;
-    if (sx0 > sx1 || sy0 > sy1 || sz0 > sz1) return 0u;
-    const uint32_t mx = (sx0 == sx1) ? (sx0 ? 0xAAu : 0x55u) : 0xFFu;   // bit s <-> voxel (s&1, (s>>1)&1, s>>2)
-    const uint32_t my = (sy0 == sy1) ? (sy0 ? 0xCCu : 0x33u) : 0xFFu;
-    const uint32_t mz = (sz0 == sz1) ? (sz0 ? 0xF0u : 0x0Fu) : 0xFFu;
-    return mx & my & mz;
-}
-
-// Scan ONE bucket as one contiguous run: every point carries its voxel position (3 bits of .w), so the
-// neighbourhood test is a mask lookup — no per-voxel loops, no cumulative tables on the hot path.
-// Four independent 16-B gathers per wait; indices are clamped into the run (a repeated point cannot change
-// the argmin). Returns true when at least one point of the neighbourhood was seen.
-__device__ __forceinline__ bool m3d_scan_bucket(m3d_gf4 pts, uint32_t base, uint32_t count, uint32_t mask, float ux, float uy, float uz,
-                                                unsigned long long& bkey, int& best) {
-    bool seen = false;
-    const uint32_t t1 = base + count;
-    for (uint32_t t = base; t < t1; t += 4) {
-        float4 c4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t w = __float_as_uint(c4[k].w);
-            const bool in = (mask >> (w >> M3D_SUB_SHIFT)) & 1u;
-            const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
-            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            const unsigned long long key = in ? (((unsigned long long)__float_as_uint(dd) << 32) | (w & M3D_IDX_MASK)) : ~0ull;
-            const bool better = key < bkey;
-            bkey = better ? key : bkey;
-            best = better ? (int)min(t + k, t1 - 1) : best;
-            seen = seen || in;
+    const float gx2 = gx * gx;
+    const uint32_t base = lo.y;
+    const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
+    for (int k = k0; k < k1; k++) {
+        const int sy = (k & 1) ^ ny, sz = (k >> 1) ^ nz;
+        if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
+        const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
+        uint32_t c0, c1;
+        if (lo.w == 0) {
+            c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
+            const int sm = s_first - 1;
+            c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
+        } else {
+            const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
+            c1 = bc[s_last];
+            c0 = s_first ? bc[s_first - 1] : 0u;
         }
+        W.any_point = W.any_point || (c1 > c0);
+        const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
+        const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
+        const float lb2 = gx2 + gy * gy + gz * gz;
+        if (lb2 > W.bound) { W.sec = fminf(W.sec, lb2); continue; }
+        const uint32_t t1 = base + c1;
+        for (uint32_t t = base + c0; t < t1; t += 4) {
+            // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
+            float4 c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) c4[j] = m3d_ld(pts, min(t + j, t1 - 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float ex = ux - c4[j].x, ey = uy - c4[j].y, ez = uz - c4[j].z;
+                const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                m3d_argmin_step2(W.bkey, W.best, W.sec, dd, __float_as_uint(c4[j].w) & M3D_IDX_MASK, (int)min(t + j, t1 - 1));
+            }
+        }
+        W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
     }
-    return seen;
 }
 
-// LIGHT path (voxel-row walk: fewest gathers; the whole-bucket scan used by the full search costs 2.7x more
-// gathers here because a seeded neighbourhood covers ~6 of the ~16 voxels of its buckets). m_prev: this query's result in the previous iteration of the same level. When the previous
-// match is still closer than one voxel edge it necessarily lies inside the 27-voxel neighbourhood, so it
-// is a legitimate candidate: seeding the search with it changes nothing in the result (the argmin rule is
-// order-independent) but lets the box pruning discard most voxels — and whole buckets — before any probe.
-// Queries that cannot be seeded return M3D_NN_HEAVY and are searched later, compacted into dense waves.
-__device__ __forceinline__ int m3d_nn27_light(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                              float dmax2, int m_prev, long long cache_prev, float seed_reach, float& sec) {
+// start of a walk: the seed (previous match, known to lie inside the neighbourhood) bounds the search and shrinks the
+// neighbourhood before any probe
+__device__ __forceinline__ void m3d_walk_seed(M3dQuery& Q, m3d_gf4 pts, int m_prev, float ux, float uy, float uz, M3dWalk& W) {
+    const float4 c4 = m3d_ld(pts, (size_t)m_prev);
+    const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
+    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    m3d_argmin_step(W.bkey, W.best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, m_prev);
+    W.bound = fminf(W.bound, dd * 1.0001f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
+        if (Q.gl[a] * Q.gl[a] > W.bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); W.sec = fminf(W.sec, Q.gl[a] * Q.gl[a]); }
+        if (Q.gh[a] * Q.gh[a] > W.bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); W.sec = fminf(W.sec, Q.gh[a] * Q.gh[a]); }
+    }
+}
+
+__device__ __forceinline__ int m3d_walk_result(const M3dWalk& W, float dmax2, bool seeded) {
+    if (W.best >= 0 && m3d_key_d2(W.bkey) <= dmax2) return W.best;
+    return (seeded || W.any_point) ? -1 : M3D_NN_NONE_CACHED;
+}
+
+// ONE QUERY PER LANE (long worklists, first iteration of a level): throughput-shaped
+__device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz, float dmax2,
+                                             bool seeded, int m_prev, long long& code_out, float& sec) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
-    if (m_prev == M3D_NN_NONE_CACHED) return (m3d_voxel_code(Q) == cache_prev) ? M3D_NN_NONE_CACHED : M3D_NN_HEAVY;
-    if (m_prev < 0) return M3D_NN_HEAVY;
-    int best = -1; unsigned long long bkey = ~0ull;
-    float bound = dmax2 * 1.0001f;
-    sec = 3.0e38f;
-    bool seeded = false;
-    {
-        const float4 c4 = m3d_ld(pts, (size_t)m_prev);
-        const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
-        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        const float reach = seed_reach * g.leaf;   // <= 0.99: closer than one voxel edge => inside the neighbourhood
-        if (dd < reach * reach) {
-            seeded = true;
-            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, m_prev);
-            bound = fminf(bound, dd * 1.0001f);
-#pragma unroll
-            for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
-                if (Q.gl[a] * Q.gl[a] > bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); sec = fminf(sec, Q.gl[a] * Q.gl[a]); }
-                if (Q.gh[a] * Q.gh[a] > bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); sec = fminf(sec, Q.gh[a] * Q.gh[a]); }
+    code_out = m3d_voxel_code(Q);
+    M3dWalk W; W.bkey = ~0ull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = 3.0e38f; W.any_point = false;
+    if (seeded) m3d_walk_seed(Q, pts, m_prev, ux, uy, uz, W);
+    if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
+        const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+        const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+        const int hx = min(max((Q.ic[0] >> 1) - b0x, 0), nbx), hy = min(max((Q.ic[1] >> 1) - b0y, 0), nby), hz = min(max((Q.ic[2] >> 1) - b0z, 0), nbz);
+        const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
+        const int shy = nbx, shz = nbx + nby;                 // bit positions of the y / z choice inside the bucket counter
+        // bucket bi of the walk: offsets (bi's bits) XOR (home bucket's offsets): bi = 0 is the home bucket
+        uint32_t key_n = m3d_bucket_key(g, b0x + hx, b0y + hy, b0z + hz);
+        uint32_t slot_n = m3d_hash_slot(key_n, g.hshift);
+        uint4 lo_n = m3d_ld(tab, 2 * (size_t)slot_n), hi_n = m3d_ld(tab, 2 * (size_t)slot_n + 1);
+        for (int bi = 0; bi < nb; bi++) {
+            uint4 lo = lo_n, hi = hi_n; const uint32_t key = key_n; uint32_t slot = slot_n;
+            const int ox = (bi & nbx) ^ hx, oy = ((bi >> shy) & nby) ^ hy, oz = ((bi >> shz) & nbz) ^ hz;
+            if (bi + 1 < nb) {   // software pipelining: the next bucket's entry is in flight while this one is walked
+                const int b2 = bi + 1;
+                key_n = m3d_bucket_key(g, b0x + ((b2 & nbx) ^ hx), b0y + (((b2 >> shy) & nby) ^ hy), b0z + (((b2 >> shz) & nbz) ^ hz));
+                slot_n = m3d_hash_slot(key_n, g.hshift);
+                lo_n = m3d_ld(tab, 2 * (size_t)slot_n); hi_n = m3d_ld(tab, 2 * (size_t)slot_n + 1);
             }
-        }
-    }
-    if (!seeded) return M3D_NN_HEAVY;
-    if (Q.lo[0] > Q.hi[0] || Q.lo[1] > Q.hi[1] || Q.lo[2] > Q.hi[2]) return (best >= 0 && m3d_key_d2(bkey) <= dmax2) ? best : -1;
-    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
-    // Compact per-lane bucket list: the loop runs max-over-lanes(#buckets) times, not 8 — after seeding most
-    // lanes need 1-2 buckets, and a fully unrolled 2x2x2 walk would make every wave pay for all 8.
-    const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
-    const int shy = nbx, shz = nbx + nby;                 // bit positions of the y / z choice inside the bucket counter
-    uint4 lo_n = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi_n = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t key_n = m3d_bucket_key(g, b0x, b0y, b0z);
-    {   // prefetch bucket 0
-        const uint32_t slot = m3d_hash_slot(key_n, g.hshift);
-        lo_n = m3d_ld(tab, 2 * (size_t)slot); hi_n = m3d_ld(tab, 2 * (size_t)slot + 1);
-    }
-    for (int bi = 0; bi < nb; bi++) {
-        uint4 lo = lo_n, hi = hi_n; const uint32_t key = key_n;
-        const int ox = bi & nbx, oy = (bi >> shy) & nby, oz = (bi >> shz) & nbz;
-        if (bi + 1 < nb) {   // software pipelining: the next bucket's entry is in flight while this one is walked
-            const int b2 = bi + 1;
-            key_n = m3d_bucket_key(g, b0x + (b2 & nbx), b0y + ((b2 >> shy) & nby), b0z + ((b2 >> shz) & nbz));
-            const uint32_t slot = m3d_hash_slot(key_n, g.hshift);
-            lo_n = m3d_ld(tab, 2 * (size_t)slot); hi_n = m3d_ld(tab, 2 * (size_t)slot + 1);
-        }
-        if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
-            uint32_t slot = m3d_hash_slot(key, g.hshift);
-            do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
-            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
-        }
-        if (lo.x != key) continue;
-        // voxels of this bucket inside the neighbourhood: a sub-box, per axis [s0, s1] with s in {0,1}
-        const int vx0 = 2 * (b0x + ox), vy0 = 2 * (b0y + oy), vz0 = 2 * (b0z + oz);
-        const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
-        const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
-        const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
-        const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
-        const float gx2 = gx * gx;
-        const uint32_t base = lo.y;
-        const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
-        // the (y,z) rows of the sub-box; the x-adjacent voxels of a row are adjacent runs: one merged range
-        for (int sz = sz0; sz <= sz1; sz++) {
-            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
-            for (int sy = sy0; sy <= sy1; sy++) {
-                const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
-                { const float lb2 = gx2 + gy * gy + gz * gz; if (lb2 > bound) { sec = fminf(sec, lb2); continue; } }
-                const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
-                uint32_t c0, c1;
-                if (lo.w == 0) {
-                    c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
-                    const int sm = s_first - 1;
-                    c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
-                } else {
-                    const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
-                    c1 = bc[s_last];
-                    c0 = s_first ? bc[s_first - 1] : 0u;
-                }
-                const uint32_t t1 = base + c1;
-                for (uint32_t t = base + c0; t < t1; t += 4) {
-                    // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
-                    float4 c4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
-                        const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                        const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
-                        m3d_argmin_step2(bkey, best, sec, dd, oi, (int)min(t + k, t1 - 1));
-                    }
-                }
-                bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+            if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+                do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
+                hi = m3d_ld(tab, 2 * (size_t)slot + 1);
             }
+            if (lo.x != key) continue;
+            m3d_walk_rows(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4);
         }
     }
-    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return -1;
-    return best;
+    sec = W.sec;
+    return m3d_walk_result(W, dmax2, seeded);
 }
 
-// FULL search (no seed): all (up to eight) bucket entries are requested before the first one is used.
-// Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
-// always with every lane of the wave doing the same amount of work.
-__device__ __forceinline__ int m3d_nn27_full(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, float ux, float uy, float uz, float dmax2,
-                                             long long& cache_out, float& sec) {
-    sec = 0.0f;   // this variant keeps no second-best bound: its results are never certified
-    M3dQuery Q;
-    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
-    cache_out = m3d_voxel_code(Q);
-    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
-    bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
-    int best = -1; unsigned long long bkey = ~0ull;
-    float bound = dmax2 * 1.0001f;
-    uint4 lo[8]; uint32_t key[8]; bool act[8];
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
-        act[b] = (ox <= nbx) && (oy <= nby) && (oz <= nbz);
-        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
-        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
-        if (act[b]) lo[b] = m3d_ld(tab, 2 * (size_t)m3d_hash_slot(key[b], g.hshift));
-    }
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        if (!act[b]) continue;
-        if (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
-            uint32_t slot = m3d_hash_slot(key[b], g.hshift);
-            do { slot = (slot + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot); } while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY);
-        }
-        if (lo[b].x != key[b]) continue;
-        float lb2;
-        const uint32_t mask = m3d_bucket_mask(Q, 2 * (b0x + (b & 1)), 2 * (b0y + ((b >> 1) & 1)), 2 * (b0z + (b >> 2)), lb2);
-        if (mask == 0u) continue;
-        if (lb2 > bound) { any_point = true; continue; }   // conservatively "some point may be there": never cache a pruned bucket as empty
-        any_point = m3d_scan_bucket(pts, lo[b].y, lo[b].z, mask, ux, uy, uz, bkey, best) || any_point;
-        bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
-    }
-    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
-    return best;
-}
-
-// FULL search, voxel-row variant (A/B: M3DREG_FULL_ROWS=1): all (up to eight) bucket entries are requested before the first one is used.
-// Used for the first iteration of a level and for the compacted heavy queries of later iterations, i.e.
-// always with every lane of the wave doing the same amount of work.
-__device__ __forceinline__ int m3d_nn27_full_rows(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz,
-                                             float dmax2, long long& cache_out, float& sec) {
-    M3dQuery Q;
-    if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
-    cache_out = m3d_voxel_code(Q);
-    sec = 3.0e38f;
-    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
-    bool any_point = false;   // did any voxel of the neighbourhood hold a point (pruned or not)?
-    int best = -1; unsigned long long bkey = ~0ull;
-    float bound = dmax2 * 1.0001f;
-    // all (up to eight) bucket entries, both halves, are requested before the first one is used: 16 loads in flight
-    uint4 lo[8], hi[8]; uint32_t key[8]; bool act[8];
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
-        act[b] = (ox <= nbx) && (oy <= nby) && (oz <= nbz);
-        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
-        const uint32_t slot = m3d_hash_slot(key[b], g.hshift);
-        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
-        hi[b] = make_uint4(0u, 0u, 0u, 0u);
-        if (act[b]) { lo[b] = m3d_ld(tab, 2 * (size_t)slot); hi[b] = m3d_ld(tab, 2 * (size_t)slot + 1); }
-    }
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        if (!act[b]) continue;
-        if (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
-            uint32_t slot = m3d_hash_slot(key[b], g.hshift);
-            do { slot = (slot + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot); } while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY);
-            hi[b] = m3d_ld(tab, 2 * (size_t)slot + 1);
-        }
-        if (lo[b].x != key[b]) continue;
-        // voxels of this bucket inside the neighbourhood: a sub-box, per axis [s0, s1] with s in {0,1}
-        const int vx0 = 2 * (b0x + (b & 1)), vy0 = 2 * (b0y + ((b >> 1) & 1)), vz0 = 2 * (b0z + (b >> 2));
-        const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
-        const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
-        const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
-        const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
-        const float gx2 = gx * gx;
-        const uint32_t base = lo[b].y;
-        const bool big = lo[b].w != 0;
-        // the four (y,z) rows of a bucket; the x-adjacent voxels of a row are adjacent runs: one merged range
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int sy = r & 1, sz = r >> 1;
-            if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
-            uint32_t c0, c1;
-            if (!big) {
-                const uint32_t w = (r == 0) ? hi[b].x : (r == 1 ? hi[b].y : (r == 2 ? hi[b].z : hi[b].w));
-                const uint32_t wp = (r == 0) ? 0u : (r == 1 ? hi[b].x : (r == 2 ? hi[b].y : hi[b].z));
-                c1 = sx1 ? (w >> 16) : (w & 0xFFFFu);
-                c0 = sx0 ? (w & 0xFFFFu) : (wp >> 16);
-            } else {
-                const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo[b].w - 1);
-                c1 = bc[2 * r + sx1];
-                c0 = (2 * r + sx0) ? bc[2 * r + sx0 - 1] : 0u;
-            }
-            any_point = any_point || (c1 > c0);
-            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
-            const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
-            { const float lb2 = gx2 + gy * gy + gz * gz; if (lb2 > bound) { sec = fminf(sec, lb2); continue; } }
-            const uint32_t t1 = base + c1;
-            for (uint32_t t = base + c0; t < t1; t += 4) {
-                // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
-                float4 c4[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
-                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                    const uint32_t oi = __float_as_uint(c4[k].w) & M3D_IDX_MASK;
-                    m3d_argmin_step2(bkey, best, sec, dd, oi, (int)min(t + k, t1 - 1));
-                }
-            }
-            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
-        }
-    }
-    if (best < 0 || !(m3d_key_d2(bkey) <= dmax2)) return any_point ? -1 : M3D_NN_NONE_CACHED;
-    return best;
-}
-
-// Three kernels per iteration. k_nn_light: one query per thread, no search — certify or classify; k_nn_seeded
-// and k_nn_heavy: the two block-local worklists, packed so that every active lane of a wave does the same
-// kind of work. On the first iteration of a level there is nothing to certify or seed from: k_nn_heavy runs
-// over all queries in their own (Morton) order and the other two are skipped.
 struct M3dNnArgs {
     int* match; int match_stride;      // per pair: result of every query (see the encoding above)
-    int* heavy; int heavy_stride;      // per pair: worklist of query indices
-    unsigned int* heavy_cnt;           // [(pair * bpp + blk) * 2 + {0: seeded, 1: full}]: block-local worklist lengths
-    unsigned int* pref;                // [pair][2][bpp + 1]: exclusive prefixes of those lengths (k_nn_scan)
     long long* cache;                  // per pair: voxel code of the "-2" verdicts (same stride as match)
     float4* state;                     // per pair: {u0.xyz, sec}: where the query was at its last real search and the squared
                                        //           lower bound of every non-best candidate seen there (NN certificate)
     int certify;                       // 1 = use the NN certificates (default); 0 = always search (A/B, M3DREG_CERTIFY)
-    int coop_div;                      // a worklist shorter than n / coop_div is searched cooperatively (8 lanes per query)
-    float seed_reach;                  // seeds farther than this many voxel edges go to the heavy list (<= 0.99)
-    int full_rows;                     // A/B: 1 = voxel-row full search, 0 = whole-bucket scan
-    int thread_div;                    // a worklist of >= n / thread_div entries is searched one query per LANE inside k_nn_coop (0 = never)
+    float seed_reach;                  // seeds farther than this many voxel edges are not used (<= 0.99)
+    int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
 };
 
 #define NN_SETUP()                                                                                          \
@@ -785,373 +615,181 @@ struct M3dNnArgs {
     const M3dGrid g = J.tgt.g;                                                                              \
     const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));                          \
     const m3d_gf4 pts = m3d_as_global(J.tgt.pts);                                                           \
-    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum); (void)bigcum;                                      \
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);                                                    \
     const m3d_gf4 src = m3d_as_global(J.src);                                                               \
     const float dmax2 = J.dmax2;                                                                            \
     const int n = J.n_src;                                                                                  \
     M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);     \
-    M3D_GLOBAL int* list = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.heavy + (size_t)pair * A.heavy_stride);         \
     M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);      \
     M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
 
-// k_nn_light: one query per thread, NO search: certify, or classify into the two worklists.
-//   certified            -> nothing to do (result and state stay)
-//   cached "none", same voxel -> nothing to do
-//   seedable (previous match closer than one voxel edge) -> list S (front of the worklist buffer, ascending)
-//   everything else      -> list H (back of the buffer, descending)
-template <bool NT>
-__global__ __launch_bounds__(256) void k_nn_light(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+// k_nn_iter: the whole correspondence step of one iteration in ONE launch. A block owns 256 consecutive queries of a pair.
+//   1. classify (no search): a query whose previous match is still PROVABLY the exact argmin (NN certificate) is done, so is
+//      a cached "nothing within the 27 voxels" verdict while the query stays in its voxel; the rest needs a search — seeded
+//      with the previous match when that is still closer than one voxel edge (then it lies inside the new neighbourhood).
+//   2. search: a block with many queries left (>= lane_min: the first iterations) walks one query per lane, each thread
+//      its own query; a block with few compacts them into an LDS worklist (wave64 ballots) and walks them 8 LANES PER
+//      QUERY — one bucket of the 2x2x2 per lane, the nearest row of every bucket first, then a bound exchange, then the
+//      other rows — so the block's latency is a handful of dependent waits however sparse its list is.
+// No global worklists, no atomics, no scan: what the earlier three-kernel chain (classify / scan / search) exchanged through
+// HBM stays inside the block.
+__global__ __launch_bounds__(256) void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
-    const int i = blk * 256 + (int)threadIdx.x;
+    __shared__ int s_cnt[4];
+    __shared__ int s_list[256];
+    const int tid = (int)threadIdx.x;
+    const int i = blk * 256 + tid;
     int cls = 0;   // 0 = done, 1 = seeded search, 2 = full search
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    int mp = -1;
     if (i < n) {
-        const float4 p = NT ? m3d_ld_stream(src, i) : m3d_ld(src, i);
-        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        const int mp = NT ? __builtin_nontemporal_load(&out[i]) : out[i];
-        if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; }
-        else {
-            const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
-            const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
-                                  (f1z >= -1.0f && f1z <= (float)g.dims[2]);
-            if (!in_range) { if (mp != -1) out[i] = -1; }
-            else if (mp == M3D_NN_NONE_CACHED) {
-                const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
-                cls = (code == cache[i]) ? 0 : 2;
-            } else if (mp < 0) cls = 2;
+        const float4 p = m3d_ld(src, i);
+        ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        if (first_of_level) {
+            if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i] = -1;
+        } else {
+            mp = out[i];
+            if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; }
             else {
-                // NN certificate: at its last real search (position u0) every candidate other than the match was at
-                // least sqrt(sec) away [inside the 27 voxels] / dout away [outside them]. The query has moved by
-                // delta since, so those are still farther than (bound - delta); if the match's CURRENT distance is
-                // below that, with margins far above float rounding, it is provably still the exact argmin.
-                const m3d_f32x4 s0 = state[i];
-                const float4 q1 = m3d_ld(pts, (size_t)mp);
-                const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
-                const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                const float mx = ux - s0.x, my = uy - s0.y, mz = uz - s0.z;
-                const float delta = sqrtf(mx * mx + my * my + mz * mz);
-                const float f0x = m3d_cell_f(s0.x, g.mn[0], g.inv_leaf), f0y = m3d_cell_f(s0.y, g.mn[1], g.inv_leaf), f0z = m3d_cell_f(s0.z, g.mn[2], g.inv_leaf);
-                const bool same_voxel = (f0x == f1x) && (f0y == f1y) && (f0z == f1z);
-                const float r0x = (s0.x - g.mn[0]) - f0x * g.leaf, r0y = (s0.y - g.mn[1]) - f0y * g.leaf, r0z = (s0.z - g.mn[2]) - f0z * g.leaf;
-                const float gm = fmaxf(fminf(fminf(fminf(r0x, g.leaf - r0x), fminf(r0y, g.leaf - r0y)), fminf(r0z, g.leaf - r0z)) - g.prune_slack, 0.f);
-                const float dout = 0.999f * g.leaf + gm;
-                const float reach = A.seed_reach * g.leaf;
-                const bool seedable = dd1 < reach * reach;   // closer than one voxel edge => inside the (new) neighbourhood
-                const float others = same_voxel ? sqrtf(s0.w) : fminf(sqrtf(s0.w), dout);   // same voxel => same 27 voxels => only `sec` matters
-                const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
-                                       (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
-                cls = certified ? 0 : (seedable ? 1 : 2);
-            }
-        }
-    }
-    // block-local compaction, no atomics (one contended atomic per wave cost more than the classification itself):
-    // this block owns slots [blk*256, blk*256+256) of the pair's worklist buffer; seeded queries are packed at the
-    // front, full-search queries at the back, in query order; the two counts go to cnt[(pair*bpp + blk)*2 + {0,1}].
-    __shared__ int s_cnt[2][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bS = __ballot(cls == 1), bH = __ballot(cls == 2);
-    if (lane == 0) { s_cnt[0][wave] = (int)__popcll(bS); s_cnt[1][wave] = (int)__popcll(bH); }
-    __syncthreads();
-    int offS = 0, offH = 0, totS = 0, totH = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { if (w < wave) { offS += s_cnt[0][w]; offH += s_cnt[1][w]; } totS += s_cnt[0][w]; totH += s_cnt[1][w]; }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    M3D_GLOBAL int* seg = list + blk * 256;
-    if (cls == 1) seg[offS + (int)__popcll(bS & lt)] = i;
-    if (cls == 2) seg[255 - (offH + (int)__popcll(bH & lt))] = i;
-    if (threadIdx.x == 0) { A.heavy_cnt[2 * (pair * bpp + blk)] = (unsigned int)totS; A.heavy_cnt[2 * (pair * bpp + blk) + 1] = (unsigned int)totH; }
-}
-
-// Block-local worklists -> dense global order without contended atomics: one workgroup per pair scans the
-// per-block counts; consumers map a dense index j to (producer block, slot) by binary search in the prefix.
-// cnt layout per pair: [2*bpp] counts {S,H per block}; pref layout per pair: [2*(bpp+1)] exclusive prefixes (S then H).
-__global__ __launch_bounds__(512) void k_nn_scan(const M3dJob* __restrict__ jobs, int bpp, int first_of_level, const unsigned int* __restrict__ cnt,
-                                                 unsigned int* __restrict__ pref) {
-    const int pair = blockIdx.x;
-    const M3dPairState* st = jobs[pair].st;
-    if (st->done || (!first_of_level && st->level_done)) return;
-    __shared__ unsigned int sh[2][512];
-    const unsigned int* c = cnt + (size_t)pair * 2 * bpp;
-    unsigned int* pS = pref + (size_t)pair * 2 * (bpp + 1);
-    unsigned int* pH = pS + (bpp + 1);
-    unsigned int carryS = 0, carryH = 0;
-    const int t = threadIdx.x;
-    for (int base = 0; base < bpp; base += 512) {
-        const int b = base + t;
-        const unsigned int vS = b < bpp ? c[2 * b] : 0u, vH = b < bpp ? c[2 * b + 1] : 0u;
-        sh[0][t] = vS; sh[1][t] = vH;
-        __syncthreads();
-        for (int o = 1; o < 512; o <<= 1) {
-            const unsigned int aS = t >= o ? sh[0][t - o] : 0u, aH = t >= o ? sh[1][t - o] : 0u;
-            __syncthreads();
-            sh[0][t] += aS; sh[1][t] += aH;
-            __syncthreads();
-        }
-        if (b < bpp) { pS[b] = carryS + sh[0][t] - vS; pH[b] = carryH + sh[1][t] - vH; }
-        carryS += sh[0][511]; carryH += sh[1][511];
-        __syncthreads();
-    }
-    if (t == 0) { pS[bpp] = carryS; pH[bpp] = carryH; }
-}
-
-// dense index j -> producer block (largest b with pref[b] <= j); pref[bpp] = total
-__device__ __forceinline__ int m3d_find_block(const unsigned int* __restrict__ pref, int bpp, unsigned int j) {
-    int lo = 0, hi = bpp;   // invariant: pref[lo] <= j < pref[hi]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= j) lo = mid; else hi = mid; }
-    return lo;
-}
-
-// ---- cooperative search for SHORT worklists: 8 lanes per query, one bucket of the 2x2x2 per lane ------------
-// The one-query-per-lane kernels are throughput-shaped: a wave walks up to 8 buckets x 4 rows x n batches one
-// after the other (~50 dependent waits), so even a nearly empty worklist costs 50-100 us. Here the 8 buckets
-// of a query are walked by 8 lanes at once (chain: 1 probe + <= 4 rows) and merged with three xor-shuffles.
-// Twice the instructions per query, a fifth of the latency — used when a list holds < 1/8 of the queries.
-__device__ __forceinline__ void m3d_walk_bucket(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, int vx0, int vy0,
-                                                int vz0, float ux, float uy, float uz, float& bound, unsigned long long& bkey, int& best, float& sec,
-                                                bool& any_point) {
-    const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
-    const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
-    const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
-    const float gx = m3d_axis_gap(Q.ic[0], vx0 + sx0, vx0 + sx1, Q.gl[0], Q.gh[0]);
-    const float gx2 = gx * gx;
-    const uint32_t base = lo.y;
-    const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
-    for (int sz = sz0; sz <= sz1; sz++) {
-        const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
-        for (int sy = sy0; sy <= sy1; sy++) {
-            const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
-            const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
-            uint32_t c0, c1;
-            if (lo.w == 0) {
-                c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
-                const int sm = s_first - 1;
-                c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
-            } else {
-                const M3D_GLOBAL uint32_t* bc = bigcum + 8 * (size_t)(lo.w - 1);
-                c1 = bc[s_last];
-                c0 = s_first ? bc[s_first - 1] : 0u;
-            }
-            any_point = any_point || (c1 > c0);
-            const float lb2 = gx2 + gy * gy + gz * gz;
-            if (lb2 > bound) { sec = fminf(sec, lb2); continue; }
-            const uint32_t t1 = base + c1;
-            for (uint32_t t = base + c0; t < t1; t += 4) {
-                float4 c4[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) c4[k] = m3d_ld(pts, min(t + k, t1 - 1));
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float ex = ux - c4[k].x, ey = uy - c4[k].y, ez = uz - c4[k].z;
-                    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                    m3d_argmin_step2(bkey, best, sec, dd, __float_as_uint(c4[k].w) & M3D_IDX_MASK, (int)min(t + k, t1 - 1));
+                const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
+                const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
+                                      (f1z >= -1.0f && f1z <= (float)g.dims[2]);
+                if (!in_range) { if (mp != -1) out[i] = -1; }
+                else if (mp == M3D_NN_NONE_CACHED) {
+                    const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
+                    cls = (code == cache[i]) ? 0 : 2;
+                } else if (mp < 0) cls = 2;
+                else {
+                    // NN certificate: at its last real search (position u0) every candidate other than the match was at
+                    // least sqrt(sec) away [inside the 27 voxels] / dout away [outside them]. The query has moved by
+                    // delta since, so those are still farther than (bound - delta); if the match's CURRENT distance is
+                    // below that, with margins far above float rounding, it is provably still the exact argmin.
+                    const m3d_f32x4 s0 = state[i];
+                    const float4 q1 = m3d_ld(pts, (size_t)mp);
+                    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+                    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float mx = ux - s0.x, my = uy - s0.y, mz = uz - s0.z;
+                    const float delta = sqrtf(mx * mx + my * my + mz * mz);
+                    const float f0x = m3d_cell_f(s0.x, g.mn[0], g.inv_leaf), f0y = m3d_cell_f(s0.y, g.mn[1], g.inv_leaf), f0z = m3d_cell_f(s0.z, g.mn[2], g.inv_leaf);
+                    const bool same_voxel = (f0x == f1x) && (f0y == f1y) && (f0z == f1z);
+                    const float r0x = (s0.x - g.mn[0]) - f0x * g.leaf, r0y = (s0.y - g.mn[1]) - f0y * g.leaf, r0z = (s0.z - g.mn[2]) - f0z * g.leaf;
+                    const float gm = fmaxf(fminf(fminf(fminf(r0x, g.leaf - r0x), fminf(r0y, g.leaf - r0y)), fminf(r0z, g.leaf - r0z)) - g.prune_slack, 0.f);
+                    const float dout = 0.999f * g.leaf + gm;
+                    const float reach = A.seed_reach * g.leaf;
+                    const bool seedable = dd1 < reach * reach;   // closer than one voxel edge => inside the (new) neighbourhood
+                    const float others = same_voxel ? sqrtf(s0.w) : fminf(sqrtf(s0.w), dout);   // same voxel => same 27 voxels => only `sec` matters
+                    const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
+                                           (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
+                    cls = certified ? 0 : (seedable ? 1 : 2);
                 }
             }
-            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
         }
     }
-}
-
-// one launch serves both worklists: the first half of a pair's blocks takes the seeded list, the second half the full-search list
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A, int bpp_list) {
-    NN_SETUP();
-    const bool SEEDED = blk < (bpp >> 1);
-    blk = SEEDED ? blk : blk - (bpp >> 1);
-    const unsigned int* pref = A.pref + (size_t)pair * 2 * (bpp_list + 1) + (SEEDED ? 0 : (bpp_list + 1));
-    const unsigned int total = pref[bpp_list];
-    if (total * (unsigned int)A.coop_div >= (unsigned int)n) return;   // long list: the one-query-per-lane kernel handles it
-    if (A.thread_div > 0 && (unsigned long long)total * (unsigned int)A.thread_div >= (unsigned int)n) {
-        // LONG list (the first iterations after a big pose update): throughput matters, not latency. One query per
-        // lane prunes voxel after voxel against its running best, which the 8 parallel lanes of a group cannot do:
-        // measured 150 us for ALL 800 k queries this way against 284 us for the cooperative walk of most of them.
-        for (unsigned int j = (unsigned int)(blk * 256 + (int)threadIdx.x); j < total; j += (unsigned int)((bpp >> 1) * 256)) {
-            const int pb = m3d_find_block(pref, bpp_list, j);
-            const int i = SEEDED ? list[pb * 256 + (int)(j - pref[pb])] : list[pb * 256 + 255 - (int)(j - pref[pb])];
-            const float4 p = m3d_ld(src, i);
-            const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-            const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-            const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-            int m = -1; long long code = 0; float sec = 0.0f;
-            if (SEEDED) m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, out[i], 0ll, A.seed_reach, sec);
-            else if (m3d_finite3(ux, uy, uz)) m = m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code, sec);
+    // how many queries of this block need a search?
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bW = __ballot(cls != 0);
+    if (lane == 0) s_cnt[wave] = (int)__popcll(bW);
+    __syncthreads();
+    int offW = 0, nW = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) offW += s_cnt[w]; nW += s_cnt[w]; }
+    if (nW == 0) return;   // block-uniform
+    if (nW >= A.lane_min) {
+        // ---- one query per lane: every thread walks its own query -------------------------------------------------
+        if (cls != 0) {
+            long long code = 0; float sec = 0.f;
+            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, mp, code, sec);
             out[i] = m;
             if (m == M3D_NN_NONE_CACHED) cache[i] = code;
             if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
         }
         return;
     }
-    const int sub = threadIdx.x & 7;
-    // a fixed number of blocks per list strides over it: no empty workgroups however short the list is
-    for (unsigned int j = (unsigned int)(blk * 32 + ((int)threadIdx.x >> 3)); j < total; j += (unsigned int)((bpp >> 1) * 32)) {   // j is uniform over the 8 lanes of a query
-    const int pb = m3d_find_block(pref, bpp_list, j);
-    const int i = SEEDED ? list[pb * 256 + (int)(j - pref[pb])] : list[pb * 256 + 255 - (int)(j - pref[pb])];
-    const float4 p = m3d_ld(src, i);
-    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-    M3dQuery Q;
-    int best = -1; unsigned long long bkey = ~0ull;
-    float bound = dmax2 * 1.0001f, sec = 3.0e38f;
-    bool any_point = false;
-    long long code = 0;
-    const bool ok = m3d_finite3(ux, uy, uz) && m3d_query_setup(g, ux, uy, uz, Q);
-    if (ok) {
-        code = m3d_voxel_code(Q);
-        if (SEEDED) {   // every lane of the group starts from the seed (classification guaranteed it is inside the neighbourhood)
-            const int mp = out[i];
-            const float4 c4 = m3d_ld(pts, (size_t)mp);
-            const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
-            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            m3d_argmin_step(bkey, best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, mp);
-            bound = fminf(bound, dd * 1.0001f);
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                if (Q.gl[a] * Q.gl[a] > bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); sec = fminf(sec, Q.gl[a] * Q.gl[a]); }
-                if (Q.gh[a] * Q.gh[a] > bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); sec = fminf(sec, Q.gh[a] * Q.gh[a]); }
-            }
-        }
-        if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
-            const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-            const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
-            const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
-            if (sub < nb) {   // this lane's bucket
-                const int shy = nbx, shz = nbx + nby;
-                const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
-                const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
-                uint32_t slot = m3d_hash_slot(key, g.hshift);
-                uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
-                while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
-                if (lo.x == key) {
-                    const uint4 hi = m3d_ld(tab, 2 * (size_t)slot + 1);
-                    m3d_walk_bucket(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, bound, bkey, best, sec, any_point);
+    // ---- few queries: LDS worklist, 8 lanes per query ------------------------------------------------------------
+    if (cls != 0) s_list[offW + (int)__popcll(bW & ((1ull << lane) - 1ull))] = tid | (cls == 1 ? 256 : 0);
+    __syncthreads();
+    const int sub = tid & 7;
+    for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles below need every lane
+        const int q = base + (tid >> 3);
+        const bool act = q < nW;
+        const int e = act ? s_list[q] : 0;
+        const bool seeded = (e & 256) != 0;
+        const int qi = blk * 256 + (e & 255);
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+        M3dQuery Q;
+        M3dWalk W; W.bkey = ~0ull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = 3.0e38f; W.any_point = false;
+        bool ok = false, found = false;
+        long long code = 0;
+        uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
+        int vx0 = 0, vy0 = 0, vz0 = 0;
+        if (act) {
+            const float4 p = m3d_ld(src, qi);
+            vx = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+            vy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+            vz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+            ok = m3d_query_setup(g, vx, vy, vz, Q);   // finite by classification
+            if (ok) {
+                code = m3d_voxel_code(Q);
+                if (seeded) m3d_walk_seed(Q, pts, out[qi], vx, vy, vz, W);   // every lane of the group starts from the seed
+                if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
+                    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+                    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
+                    const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
+                    if (sub < nb) {   // this lane's bucket
+                        const int shy = nbx, shz = nbx + nby;
+                        const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
+                        const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+                        uint32_t slot = m3d_hash_slot(key, g.hshift);
+                        lo = m3d_ld(tab, 2 * (size_t)slot);
+                        while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
+                        if (lo.x == key) {
+                            found = true;
+                            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
+                            vx0 = 2 * (b0x + ox); vy0 = 2 * (b0y + oy); vz0 = 2 * (b0z + oz);
+                        }
+                    }
                 }
             }
         }
-    }
-    // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
+        // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
+        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1);
+        {
+            float bnd = W.bound;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        const unsigned long long ok2 = __shfl_xor(bkey, o);
-        const int ob = __shfl_xor(best, o);
-        const float os = __shfl_xor(sec, o);
-        const bool oa = __shfl_xor((int)any_point, o) != 0;
-        const bool better = ok2 < bkey;
-        const float loser = m3d_key_d2(better ? bkey : ok2);
-        sec = fminf(sec, os);
-        sec = (ok2 != bkey) ? fminf(sec, loser) : sec;   // equal keys: the same point (the shared seed)
-        bkey = better ? ok2 : bkey;
-        best = better ? ob : best;
-        any_point = any_point || oa;
-    }
-    if (sub == 0) {
-        int m = -1;
-        if (ok) {
-            if (best >= 0 && m3d_key_d2(bkey) <= dmax2) m = best;
-            else m = (SEEDED || any_point) ? -1 : M3D_NN_NONE_CACHED;
+            for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
+            W.bound = bnd;
         }
-        out[i] = m;
-        if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-        if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
-    }
-    }
-}
-
-// k_nn_seeded: list S, compacted. Every lane holds a query whose previous match seeds the search.
-template <bool NT>
-__global__ __launch_bounds__(256) void k_nn_seeded(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
-    NN_SETUP();
-    const unsigned int* pS = A.pref + (size_t)pair * 2 * (bpp + 1);
-    const unsigned int j = (unsigned int)(blk * 256 + (int)threadIdx.x);
-    if (pS[bpp] * (unsigned int)A.coop_div < (unsigned int)n) return;   // short list: k_nn_coop<true> handles it
-    if (j >= pS[bpp]) return;
-    const int pb = m3d_find_block(pS, bpp, j);
-    const int i = list[pb * 256 + (int)(j - pS[pb])];
-    const float4 p = m3d_ld(src, i);
-    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-    float sec;
-    const int m = m3d_nn27_light(g, tab, pts, bigcum, ux, uy, uz, dmax2, out[i], 0ll, A.seed_reach, sec);
-    out[i] = m;   // the seed is a valid candidate, so m is never M3D_NN_HEAVY here
-    if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
-}
-
-template <bool NT>
-__global__ __launch_bounds__(256) void k_nn_heavy(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
-    NN_SETUP();
-    int i = blk * 256 + (int)threadIdx.x;
-    if (first_of_level) { if (i >= n) return; }
-    else {
-        const unsigned int* pH = A.pref + (size_t)pair * 2 * (bpp + 1) + (bpp + 1);
-        const unsigned int j = (unsigned int)i;
-        if (pH[bpp] * (unsigned int)A.coop_div < (unsigned int)n) return;   // short list: k_nn_coop<false> handles it
-        if (j >= pH[bpp]) return;
-        const int pb = m3d_find_block(pH, bpp, j);
-        i = list[pb * 256 + 255 - (int)(j - pH[pb])];
-    }
-    const float4 p = NT ? m3d_ld_stream(src, i) : m3d_ld(src, i);
-    const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-    const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-    const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-    int m = -1;
-    long long code = 0;
-    float sec = 0.0f;
-    if (m3d_finite3(ux, uy, uz)) m = A.full_rows ? m3d_nn27_full_rows(g, tab, pts, bigcum, ux, uy, uz, dmax2, code, sec) : m3d_nn27_full(g, tab, pts, ux, uy, uz, dmax2, code, sec);
-    out[i] = m;
-    if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-    if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
-}
-
-template <int METRIC>
-__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
-                                                                    const int* __restrict__ match, int match_stride,
-                                                                    long long* __restrict__ partials) {
-    int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk);
-    const M3dJob& J = jobs[pair];
-    M3dPairState* st = J.st;
-
-    if (st->done || (!first_of_level && st->level_done)) return;
-    float R[9], tt[3];
-    m3d_load_pose(st, R, tt);
-    const M3dLevelDev& L = J.tgt;
-    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
-    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
-    constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
+        // ... and the other rows are mostly discarded by their box distance
+        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4);
+        // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
+        unsigned long long bkey = W.bkey; int best = W.best; float sec = W.sec; bool any_point = W.any_point;
 #pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
-    const int n = J.n_src;
-    const int* in = match + (size_t)pair * match_stride;
-    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
-    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
-    // dependent gathers (match -> point, normal), so its speed is the number of them in flight
-    constexpr int NB = 4;
-    const int stride = bpp * ICP_THREADS;
-    for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
-        int m[NB]; float4 p[NB], q[NB], nq[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
-#pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const size_t mm = (size_t)max(m[k], 0);
-            q[k] = m3d_ld(pts, mm);
-            nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
+        for (int o = 1; o < 8; o <<= 1) {
+            const unsigned long long ok2 = __shfl_xor(bkey, o);
+            const int ob = __shfl_xor(best, o);
+            const float os = __shfl_xor(sec, o);
+            const bool oa = __shfl_xor((int)any_point, o) != 0;
+            const bool better = ok2 < bkey;
+            const float loser = m3d_key_d2(better ? bkey : ok2);
+            sec = fminf(sec, os);
+            sec = (ok2 != bkey) ? fminf(sec, loser) : sec;   // equal keys: the same point (the shared seed)
+            bkey = better ? ok2 : bkey;
+            best = better ? ob : best;
+            any_point = any_point || oa;
         }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            if (m[k] < 0) continue;
-            const float ux = fmaf(R[0], p[k].x, fmaf(R[1], p[k].y, fmaf(R[2], p[k].z, tt[0])));
-            const float uy = fmaf(R[3], p[k].x, fmaf(R[4], p[k].y, fmaf(R[5], p[k].z, tt[1])));
-            const float uz = fmaf(R[6], p[k].x, fmaf(R[7], p[k].y, fmaf(R[8], p[k].z, tt[2])));
-            const float ex = ux - q[k].x, ey = uy - q[k].y, ez = uz - q[k].z;
-            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
-            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
+        if (act && sub == 0) {
+            int m = -1;
+            if (ok) {
+                if (best >= 0 && m3d_key_d2(bkey) <= dmax2) m = best;
+                else m = (seeded || any_point) ? -1 : M3D_NN_NONE_CACHED;
+            }
+            out[qi] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
         }
     }
-    block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
 }
 
 // point-to-point: expand the 17 transported sums into the spec's 29 slots (exact integer identities:
@@ -1235,11 +873,7 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
     return -1;
 }
 
-// One workgroup for the whole batch, one thread per pair (looping): consume the sums of the iteration that
-// just ran, update the pose, decide. Finally publish {iteration sequence number, pairs that still have work
-// at this level} as ONE 8-byte store into host-mapped memory: the host polls it between launches and stops
-// enqueuing a level's remaining iterations once nothing is active — early termination without any
-// host-device synchronisation (a stale read only costs a few empty launches, never correctness).
+// One thread per pair: consume the sums of the iteration that just ran, update the pose, decide.
 __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr) {
     M3dPairState* st = J.st;
     if (st->done || (!first_of_level && st->level_done)) return;
@@ -1278,6 +912,123 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
     st->level_done = level_done;
 }
 
+// Batch-wide arrival: the last pair to report publishes {iteration sequence number, pairs that still have work at this
+// level} as ONE 8-byte store into host-mapped memory: the host polls it between launches and stops enqueuing a level's
+// remaining iterations once nothing is active — early termination without any host-device synchronisation (a stale read
+// only costs a few empty launches, never correctness). The two counters live in pair 0's state, agent-scope atomics only.
+__device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ jobs, int n_pairs, bool still_active, unsigned int seq,
+                                                    unsigned long long* __restrict__ progress) {
+    M3dPairState* g0 = jobs[0].st;
+    if (still_active) {
+        __hip_atomic_fetch_add(&g0->gsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned int t = __hip_atomic_fetch_add(&g0->gsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != (unsigned int)n_pairs - 1u) return;
+    const unsigned int active = __hip_atomic_exchange(&g0->gsync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g0->gsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (progress) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long*>(progress) = ((unsigned long long)seq << 32) | active;
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
+                                                                    const int* __restrict__ match, int match_stride,
+                                                                    long long* __restrict__ partials,
+                                                                    unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk);
+    const M3dJob& J = jobs[pair];
+    M3dPairState* st = J.st;
+
+    if (st->done || (!first_of_level && st->level_done)) {
+        // a finished pair still reports to the batch-wide progress word (one thread per pair)
+        if (fuse_solve && blk == 0 && threadIdx.x == 0) m3d_report_progress(jobs, n_pairs, false, seq, progress);
+        return;
+    }
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
+    const M3dLevelDev& L = J.tgt;
+    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
+    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
+    constexpr int NACC = (METRIC == 1) ? 29 : 17;
+    long long acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    const int n = J.n_src;
+    const int* in = match + (size_t)pair * match_stride;
+    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
+    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
+    // dependent gathers (match -> point, normal), so its speed is the number of them in flight
+    constexpr int NB = 4;
+    const int stride = bpp * ICP_THREADS;
+    for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
+        int m[NB]; float4 p[NB], q[NB], nq[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const size_t mm = (size_t)max(m[k], 0);
+            q[k] = m3d_ld(pts, mm);
+            nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (m[k] < 0) continue;
+            const float ux = fmaf(R[0], p[k].x, fmaf(R[1], p[k].y, fmaf(R[2], p[k].z, tt[0])));
+            const float uy = fmaf(R[3], p[k].x, fmaf(R[4], p[k].y, fmaf(R[5], p[k].z, tt[1])));
+            const float uz = fmaf(R[6], p[k].x, fmaf(R[7], p[k].y, fmaf(R[8], p[k].z, tt[2])));
+            const float ex = ux - q[k].x, ey = uy - q[k].y, ez = uz - q[k].z;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
+            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
+        }
+    }
+    block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
+    if (!fuse_solve || !partials) return;
+    // ---- a8 in the same launch: the LAST block of the pair to finish adds up the pair's block partials and solves.
+    // (A separate solve kernel cost its ~10 us plus a dependent-launch gap of ~5 us in every iteration.)
+    // The partials are stored and loaded with agent-scope (write-through / coherent) accesses and the writers wait for
+    // their stores before the block takes its ticket: no __threadfence(), whose agent-scope release writes back the whole
+    // L2 — including the megabytes of match/state lines the search kernel left dirty (measured: +50 us per iteration).
+    // (The blocks of a pair sit on one XCD only when the batch is a multiple of 8 pairs; the L2s of different XCDs are
+    // not coherent for plain accesses.)
+    __shared__ int s_last;
+    __shared__ long long s_part[8][M3D_PARTIAL_STRIDE];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)bpp - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
+        long long v = 0;
+        if (slot < M3D_NSUMS)
+            for (int b = seg; b < bpp; b += 8)
+                v += __hip_atomic_load(&partials[((size_t)pair * bpp + b) * M3D_PARTIAL_STRIDE + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part[seg][slot] = v;
+        __syncthreads();
+        if (threadIdx.x < M3D_NSUMS) {
+            long long t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
+            s_part[0][threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    st->ticket = 0u;
+    m3d_solve_pair(J, first_of_level, s_part[0]);
+    m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
+}
+
+
 __global__ __launch_bounds__(256) void k_solve_update(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, unsigned int seq,
                                                       unsigned long long* __restrict__ progress, const long long* __restrict__ partials, int bpp_a) {
     // one workgroup per pair: add up the reduction pass's block partials (8 segments x 32 slots), then one thread solves
@@ -1302,21 +1053,7 @@ __global__ __launch_bounds__(256) void k_solve_update(const M3dJob* __restrict__
     }
     if (threadIdx.x != 0) return;
     if (!skip) m3d_solve_pair(J, first_of_level, partials ? s_part[0] : nullptr);
-    // batch-wide arrival: the last pair to report publishes {sequence number, pairs still active at this level};
-    // the two counters live in pair 0's state and are only touched by agent-scope atomics
-    M3dPairState* g0 = jobs[0].st;
-    if (!st->done && !st->level_done) {
-        __hip_atomic_fetch_add(&g0->gsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const unsigned int t = __hip_atomic_fetch_add(&g0->gsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t != (unsigned int)n_pairs - 1u) return;
-    const unsigned int active = __hip_atomic_exchange(&g0->gsync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&g0->gsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (progress) {
-        __threadfence_system();
-        *reinterpret_cast<volatile unsigned long long*>(progress) = ((unsigned long long)seq << 32) | active;
-    }
+    m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
 }
 
 // ---- introspection: NN of arbitrary queries --------------------------------------------------------
@@ -1358,37 +1095,19 @@ int m3d_acc_blocks(int max_n_src) {
 }
 
 static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
-                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr, long long* partials = nullptr) {
+                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr, long long* partials = nullptr,
+                              unsigned int seq = 0, unsigned long long* progress = nullptr, int fuse_solve = 0) {
     if (variant == 2) {
-        // search: one query per thread; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
+        // search: one block per 256 queries; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.heavy = w.heavy; A.heavy_stride = w.stride; A.heavy_cnt = w.heavy_cnt; A.pref = w.heavy_cnt + (size_t)2 * n_pairs * bpp_s; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.coop_div = w.coop_div; A.seed_reach = w.seed_reach; A.full_rows = w.full_rows; A.thread_div = w.thread_div;
-        if (!first_of_level) {
-            hipEvent_t c0 = k0, c1 = k1;
-            if (w.nontemporal) hipLaunchKernelGGL(k_nn_light<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            else hipLaunchKernelGGL(k_nn_light<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            M3D_DBG(s, "k_nn_light");
-            hipLaunchKernelGGL(k_nn_scan, dim3(n_pairs), dim3(512), 0, s, d_jobs, bpp_s, first_of_level, (const unsigned int*)A.heavy_cnt, A.pref);
-            M3D_DBG(s, "k_nn_scan");
-            if (w.coop_div > 1) hipLaunchKernelGGL(k_nn_seeded<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            M3D_DBG(s, "k_nn_seeded");
-            // short-list regime (< n/8 entries): 8 lanes per query; at most n/8 queries -> n/256 blocks of 32 queries
-            int bpp_c = 2 * ((max_n_src / w.coop_div + 31) / 32 + 1);         // per pair: half for each list ...
-            const int cap_c = 2 * ((256 * w.coop_cap) / (2 * (n_pairs < 1 ? 1 : n_pairs)) + 1);   // ... but never more than coop_cap blocks per CU in total: they stride
-            if (bpp_c > cap_c) bpp_c = cap_c;
-            if (c0) (void)hipEventRecord(c0, s);    // the dominant kernel alone (bench.py roofline)
-            hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A, bpp_s);
-            M3D_DBG(s, "k_nn_coop");
-            if (c1) (void)hipEventRecord(c1, s);
-        }
-        if (first_of_level || w.coop_div > 1) {   // full search of all queries (first iteration) / of a long worklist
-            if (w.nontemporal) hipLaunchKernelGGL(k_nn_heavy<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            else hipLaunchKernelGGL(k_nn_heavy<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            M3D_DBG(s, "k_nn_heavy");
-        }
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min;
+        if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
+        hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_iter");
+        if (k1) (void)hipEventRecord(k1, s);
         const int bpp_a = m3d_acc_blocks(max_n_src);
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, seq, progress, fuse_solve);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, seq, progress, fuse_solve);
         M3D_DBG(s, "k_accumulate_matches");
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);
@@ -1414,10 +1133,23 @@ hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_p
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
                                     hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
     if (e0) (void)hipEventRecord(e0, s);
-    long long* partials = (variant == 2) ? w.partials : nullptr;   // the fused variants add into the state with atomics
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, partials);
+    static const bool fuse = [] { const char* v = getenv("M3DREG_FUSE_SOLVE"); return v ? atoi(v) != 0 : true; }();   // A/B switch
+    if (variant == 2 && fuse) {
+        // search kernels + reduction pass; the reduction's last block of every pair solves and updates the pose (a8)
+        launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials, seq, progress, 1);
+        if (e1) (void)hipEventRecord(e1, s);
+        return hipGetLastError();
+    }
+    if (variant == 2) {
+        launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials);
+        if (e1) (void)hipEventRecord(e1, s);
+        hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)w.partials, m3d_acc_blocks(max_n_src));
+        M3D_DBG(s, "k_solve_update");
+        return hipGetLastError();
+    }
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, nullptr);   // fused variants add into the state with atomics
     if (e1) (void)hipEventRecord(e1, s);
-    hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)partials, m3d_acc_blocks(max_n_src));
+    hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)nullptr, 0);
     M3D_DBG(s, "k_solve_update");
     return hipGetLastError();
 }

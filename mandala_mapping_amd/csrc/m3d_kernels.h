@@ -69,26 +69,21 @@ hipError_t m3d_launch_aggregate(hipStream_t s, const M3dAggArgs& A);
 
 // icp.hip
 // variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
-//          2 = split (default): k_nn_light + k_nn_heavy (one int32 result per query) + k_accumulate_matches
-struct M3dNnWork {               // variant-2 workspace, all per pair with the same stride
-    int* match;                  // [n_pairs * stride] result of every query, kept between iterations (seeds the next search)
-    int* heavy;                  // [n_pairs * stride] worklist of queries that need the full walk
-    unsigned int* heavy_cnt;     // [(pair * blocks + blk) * 2 + {0,1}] block-local worklist lengths, rewritten every iteration
+//          2 = split (default): k_nn_iter (classify + search, one int32 result per query), then k_accumulate_matches,
+//              whose last block per pair also solves and updates the pose
+struct M3dNnWork {               // variant-2 workspace, all per pair with the same stride (a whole number of 256-query blocks)
+    int* match;                  // [n_pairs * stride] result of every query, kept between iterations (certified / seeds the next search)
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
     float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
-    int coop_div;                // worklists shorter than n / coop_div use the cooperative kernel (M3DREG_COOP_DIV)
-    int coop_cap;                // at most this many cooperative-search workgroups per CU (they stride over the lists; M3DREG_COOP_CAP)
-    int thread_div;              // worklists of >= n / thread_div entries are searched one query per lane inside k_nn_coop (M3DREG_THREAD_DIV, 0 = never)
+    int lane_min;                // a 256-query block with >= lane_min queries to search walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
     long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
     int stride;
-    float seed_reach;            // seeds farther than this many voxel edges are searched by the heavy kernel (<= 0.99)
-    int full_rows;               // A/B switch of the full search (M3DREG_FULL_ROWS)
-    int nontemporal;             // A/B: stream the source points / per-query results with non-temporal accesses (M3DREG_NT)
+    float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
 };
 // e0/e1 (optional): events recorded immediately before / after the launches of one linearisation (search + reduction);
-// k0/k1 (optional): events around the dominant kernel alone (k_nn_light; not launched on the first iteration of a level)
-// seq / progress: k_solve_update stores {seq, pairs still active at this level} to *progress (device view of
+// k0/k1 (optional): events around the dominant kernel alone (k_nn_iter)
+// seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of
 // host-mapped memory, may be null) so that the host can stop enqueuing iterations without synchronising
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,

@@ -94,16 +94,11 @@ struct m3dreg_handle {
     unsigned long long* d_progress = nullptr;            // device view of the same word
     unsigned int seq = 0;
     uint64_t launched_iters = 0, skipped_iters = 0;
-    int full_rows = 1;                 // full search walks voxel rows (default); 0 = whole-bucket scan (M3DREG_FULL_ROWS, A/B: rows win by 10 %)
-    int nontemporal = 0;
     int certify = 1;
-    int thread_div = 8;                // worklists of >= n/8 entries: one query per lane (throughput) instead of 8 lanes per query (latency)
-    int coop_cap = 32;                 // A/B on one box: 32 workgroups per CU beat both 8 (serialises) and uncapped (empty workgroups)
-    int coop_div = 1;                  // 1 = worklists are always searched cooperatively (A/B: best); k > 1 = only lists shorter than n / k
+    int lane_min = 96;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
-    int* d_match = nullptr;            // [2][pairs * match_stride]: NN result per query + heavy worklist (variant 2)
-    unsigned int* d_heavy_cnt = nullptr;
+    int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
     size_t partials_cap = 0;
     size_t match_cap = 0;
@@ -498,16 +493,8 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         if (h->d_match) hipFree(h->d_match);
         h->d_match = nullptr; h->match_cap = 0;
         const size_t cap = n_pairs * stride + n_pairs * stride / 4;
-        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | heavy list | cache (int64) | certificate state (float4)
+        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | (unused) | cache (int64) | certificate state (float4)
         h->match_cap = cap;
-    }
-    const size_t n_cnt = 4 * n_pairs * (stride / 256 + 3);   // per 256-query block: two worklist lengths + their two prefixes
-    if (n_cnt > h->match_pairs_cap) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->d_heavy_cnt) hipFree(h->d_heavy_cnt);
-        h->d_heavy_cnt = nullptr;
-        HIPCHK(h, hipMalloc((void**)&h->d_heavy_cnt, sizeof(unsigned int) * (n_cnt + n_cnt / 4)));
-        h->match_pairs_cap = n_cnt + n_cnt / 4;
     }
     const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src)) * M3D_PARTIAL_STRIDE;
     if (n_part > h->partials_cap) {
@@ -524,16 +511,12 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
 
 M3dNnWork nn_work(const m3dreg_handle* h) {
     M3dNnWork w;
-    w.match = h->d_match; w.heavy = h->d_match + h->match_cap; w.heavy_cnt = h->d_heavy_cnt; w.stride = h->match_stride; w.partials = h->d_partials;
+    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
     w.certify = h->certify;
-    w.coop_div = h->coop_div;
-    w.coop_cap = h->coop_cap;
-    w.thread_div = h->thread_div;
+    w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
-    w.full_rows = h->full_rows;
-    w.nontemporal = h->nontemporal;
     return w;
 }
 
@@ -645,12 +628,8 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
-    if (const char* v = getenv("M3DREG_FULL_ROWS")) h->full_rows = atoi(v) ? 1 : 0;
-    if (const char* v = getenv("M3DREG_THREAD_DIV")) { int q = atoi(v); if (q >= 0 && q <= 1024) h->thread_div = q; }
-    if (const char* v = getenv("M3DREG_COOP_CAP")) { int q = atoi(v); if (q >= 1 && q <= 4096) h->coop_cap = q; }
-    if (const char* v = getenv("M3DREG_COOP_DIV")) { int q = atoi(v); if (q >= 1 && q <= 64) h->coop_div = q; }
+    if (const char* v = getenv("M3DREG_LANE_MIN")) { int q = atoi(v); if (q >= 1 && q <= 257) h->lane_min = q; }
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
-    if (const char* v = getenv("M3DREG_NT")) h->nontemporal = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
@@ -670,7 +649,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_heavy_cnt, (void*)h->d_partials }) if (p) hipFree(p);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
