@@ -45,6 +45,7 @@ def parse():
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
     ap.add_argument("--inflight", type=int, default=2,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
+    ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -157,7 +158,7 @@ def main():
         torch.cuda.synchronize()
 
     for r in regs:
-        r.profile_enable(True)
+        r.profile_enable(not args.no_events, every=3)   # 3 does not divide the 20 iterations of a step: every iteration index is sampled
         r.profile_read(0, reset=True)
         r.profile_read(1, reset=True)
     barrier()
@@ -185,7 +186,7 @@ def main():
         total_regs = world * B * K
         value = total_regs / elapsed
         avg_launch_s = (kern_ms / 1e3) / max(1, launches)
-        achieved = alg_bytes / avg_launch_s / 1e9
+        achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
@@ -206,7 +207,7 @@ def main():
                        "overlap": "none (serial steps)" if D == 1 else f"{D} steps in flight, one HIP stream each"},
             "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
             "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
-            "iteration_algorithmic_GBps": alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9,
+            "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
             "roofline": {"bound": "hbm", "kernel": "k_nn_coop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -176,11 +176,11 @@ int m3dagg_restart(m3dagg* a);                       /* requestCallback (:224-22
 int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* When enabled, hipEvents are recorded on the handle's stream (a) around all launches of every
- * linearisation (NN search + residual reduction of the whole batch) and (b) around every launch of the
- * dominant kernel alone (`k_nn_coop`, the exact 27-voxel NN search of every query that no certificate could
- * answer; the first iteration of a level runs `k_nn_heavy` over all queries instead), so bench.py can report
- * that kernel's average launch duration from inside its timed region. */
+/* on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration of the handle is bracketed by three hipEvents on
+ * its stream: before and after the dominant kernel (`k_nn_iter`: certificate check + exact 27-voxel NN search of
+ * every query of every pair of the batch) and at the end of the iteration (search + reduction + solve), so
+ * bench.py can report that kernel's average launch duration from inside its timed region. (An event record is
+ * a barrier packet on the queue: bracketing every iteration cost 4 % of the throughput it measured.) */
 int m3dreg_profile_enable(m3dreg_handle* h, int on);
 #define M3DREG_PROFILE_ITERATION 0
 #define M3DREG_PROFILE_DOMINANT_KERNEL 1

@@ -183,12 +183,13 @@ class Registrar:
     def synchronize(self):
         self._check(lib().m3dreg_synchronize(self._h), "synchronize")
 
-    def profile_enable(self, on=True):
-        self._check(lib().m3dreg_profile_enable(self._h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, on=True, every=1):
+        """every = n: bracket every n-th iteration only (each event record is a barrier packet on the stream)"""
+        self._check(lib().m3dreg_profile_enable(self._h, max(1, int(every)) if on else 0), "profile_enable")
 
     def profile_read(self, what=1, reset=True):
         """(launches, total ms) since the last reset, from hipEvents on the stream.
-        what = 0: whole linearisations (search + reduction); what = 1: the dominant kernel (k_nn_light) alone."""
+        what = 0: whole iterations (search + reduction + solve); what = 1: the dominant kernel (k_nn_iter) alone."""
         n, ms = C.c_uint64(0), C.c_double(0.0)
         self._check(lib().m3dreg_profile_read(self._h, what, C.byref(n), C.byref(ms), 1 if reset else 0), "profile_read")
         return n.value, ms.value

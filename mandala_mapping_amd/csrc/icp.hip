@@ -633,7 +633,12 @@ struct M3dNnArgs {
 //      other rows — so the block's latency is a handful of dependent waits however sparse its list is.
 // No global worklists, no atomics, no scan: what the earlier three-kernel chain (classify / scan / search) exchanged through
 // HBM stays inside the block.
-__global__ __launch_bounds__(256) void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+#ifdef M3D_NN_WAVES   // A/B builds: force the occupancy of the search kernel (make CXXFLAGS+=-DM3D_NN_WAVES=6)
+#define M3D_NN_OCC __attribute__((amdgpu_waves_per_eu(M3D_NN_WAVES, M3D_NN_WAVES)))
+#else
+#define M3D_NN_OCC
+#endif
+__global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
     __shared__ int s_cnt[4];
     __shared__ int s_list[256];
@@ -1130,25 +1135,23 @@ hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
-                                    hipEvent_t e1, hipEvent_t k0, hipEvent_t k1) {
-    if (e0) (void)hipEventRecord(e0, s);
+                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
+                                    hipEvent_t k1) {
     static const bool fuse = [] { const char* v = getenv("M3DREG_FUSE_SOLVE"); return v ? atoi(v) != 0 : true; }();   // A/B switch
     if (variant == 2 && fuse) {
-        // search kernels + reduction pass; the reduction's last block of every pair solves and updates the pose (a8)
+        // search kernel + reduction pass; the reduction's last block of every pair solves and updates the pose (a8)
         launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials, seq, progress, 1);
-        if (e1) (void)hipEventRecord(e1, s);
         return hipGetLastError();
     }
     if (variant == 2) {
         launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials);
-        if (e1) (void)hipEventRecord(e1, s);
         hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)w.partials, m3d_acc_blocks(max_n_src));
         M3D_DBG(s, "k_solve_update");
         return hipGetLastError();
     }
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, nullptr);   // fused variants add into the state with atomics
-    if (e1) (void)hipEventRecord(e1, s);
+    if (k0) (void)hipEventRecord(k0, s);
+    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, nullptr, nullptr, nullptr);   // fused variants add into the state with atomics
+    if (k1) (void)hipEventRecord(k1, s);
     hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)nullptr, 0);
     M3D_DBG(s, "k_solve_update");
     return hipGetLastError();

@@ -81,13 +81,12 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
 };
-// e0/e1 (optional): events recorded immediately before / after the launches of one linearisation (search + reduction);
-// k0/k1 (optional): events around the dominant kernel alone (k_nn_iter)
+// k0/k1 (optional): events recorded immediately before / after the dominant kernel of the iteration (k_nn_iter)
 // seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of
 // host-mapped memory, may be null) so that the host can stop enqueuing iterations without synchronising
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t e0,
-                                    hipEvent_t e1, hipEvent_t k0, hipEvent_t k1);
+                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
+                                    hipEvent_t k1);
 int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
                                       const M3dNnWork& w);
