@@ -8,11 +8,11 @@ decode + exact AABB + voxel bucketing + normals of BOTH clouds, then --iters poi
 iterations (0.1 m voxel NN), then the pose read-back; with N > 1 the poses of all ranks are gathered
 over RCCL (one all_gather per step — the only collective; pairs never exchange data).
 
-Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_coop: source transform +
-exact 27-voxel nearest-neighbour search, 8 lanes per query, of every query of every pair of the batch that
-the previous iteration's NN certificate could not answer) by its algorithmic bytes (NN part: 12 N + 12 M + 8 C_occ per
-pair) over its average launch duration, taken from hipEvents the library records on its stream around
-every launch of that kernel inside the timed region. `cpu_baseline` is the CPU oracle (OpenMP build)
+Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_iter: source transform, NN-certificate
+check and exact 27-voxel nearest-neighbour search of every query of every pair of the batch) by its algorithmic
+bytes (NN part: 12 N + 12 M + 8 C_occ per pair) over its average launch duration, taken from
+hipEvents the library records on its stream around launches of that kernel inside the timed region (every third
+launch: an event record is a barrier packet, bracketing all of them cost 4 % of the throughput being measured). `cpu_baseline` is the CPU oracle (OpenMP build)
 timed on a bounded sample of the same workload on this host's cores.
 """
 import argparse
@@ -168,7 +168,7 @@ def main():
     t1 = time.perf_counter()
     launches = kern_ms = iters_timed = iter_ms = 0
     for r in regs:
-        a, b = r.profile_read(1, reset=True)       # k_nn_coop alone
+        a, b = r.profile_read(1, reset=True)       # k_nn_iter alone
         c, d = r.profile_read(0, reset=True)       # search + reduction of one linearisation
         launches, kern_ms, iters_timed, iter_ms = launches + a, kern_ms + b, iters_timed + c, iter_ms + d
         r.profile_enable(False)
@@ -191,7 +191,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_nn_coop", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("k_nn_iter", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -210,7 +210,7 @@ def main():
             "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_coop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
         }

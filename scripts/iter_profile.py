@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 nm = lambda r: r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-idx = [i for i, r in enumerate(rows) if nm(r) == "k_nn_heavy"]
+idx = [i for i, r in enumerate(rows) if nm(r) == "k_nn_iter"]
 i0 = idx[-1]
 j = i0
 while j > 0 and nm(rows[j]) != "k_decode_aabb":
