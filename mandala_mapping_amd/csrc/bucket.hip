@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
     float4 p;
     p.x = B.x[oi]; p.y = B.y[oi]; p.z = B.z[oi];
-    p.w = __uint_as_float(oi | ((k & 7u) << M3D_SUB_SHIFT));   // the voxel's position inside its bucket rides along
+    p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
     B.pts[j] = p;
     if (bhead) {
         const uint32_t bk = bucket_key_of_point(B.grid, p);

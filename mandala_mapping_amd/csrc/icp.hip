@@ -12,6 +12,32 @@
 // associative, so the result does not depend on launch geometry. No MFMA: there is no contraction.
 #include "m3d_kernels.h"
 
+// -DM3D_STATS: instrumented build (scripts/walk_stats.py): counts, per Gauss-Newton iteration of pair 0's clock, what the
+// search does — one wave-aggregated atomic per event. Never defined in the shipped library.
+#ifdef M3D_STATS
+__device__ unsigned long long g_m3d_stats[64][16];
+__device__ __forceinline__ void m3d_stat(int it, int what, unsigned int v = 1u) {
+    const unsigned long long m = __ballot(1);
+    unsigned int tot = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);   // inactive lanes contribute garbage-free zeros only if masked below
+    (void)tot;
+    // sum over ACTIVE lanes only: use ballot-popcount for unit events, atomics per lane otherwise
+    if (v == 1u) { if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_m3d_stats[it & 63][what], (unsigned long long)__popcll(m)); }
+    else atomicAdd(&g_m3d_stats[it & 63][what], (unsigned long long)v);
+}
+#define M3D_STAT(it, what) m3d_stat(it, what)
+#define M3D_STATV(it, what, v) m3d_stat(it, what, v)
+extern "C" hipError_t m3d_debug_read_stats(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_stats), sizeof(unsigned long long) * 64 * 16);
+    if (e == hipSuccess && reset) { static unsigned long long z[64 * 16]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_stats), z, sizeof(z)); }
+    return e;
+}
+#else
+#define M3D_STAT(it, what) ((void)0)
+#define M3D_STATV(it, what, v) ((void)0)
+#endif
+
 #define ICP_THREADS 256
 #define ICP_WAVES (ICP_THREADS / 64)
 // LDS staging capacity per wave (k_icp_lds): buckets of the wave's query box / target points staged
@@ -485,11 +511,19 @@ __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
 // is discarded by its box distance without a single gather. Bucket entries are fetched one ahead (software pipeline)
 // instead of all eight up front: 16 VGPRs instead of 64, so the kernel fits 8 waves per SIMD — the walk is a chain of
 // dependent gathers, its throughput is the number of waves in flight.
-struct M3dWalk { unsigned long long bkey; int best; float bound, sec; bool any_point; };
+// bkey = (d2 bits << 32 | input index) of the best candidate so far, initially (+inf, ~0): every real candidate is smaller.
+// sec  = BITS of a lower bound of d2 over every candidate that is not the winner (second-best seen, boxes of pruned rows);
+//        non-negative floats order like their bit patterns, so it is maintained with integer min/max (no canonicalisation
+//        instructions, no NaN cases).
+struct M3dWalk { unsigned long long bkey; int best; float bound; uint32_t sec; bool any_point; };
+#define M3D_INF_BITS 0x7F800000u
+__device__ __forceinline__ void m3d_walk_init(M3dWalk& W, float dmax2) {
+    W.bkey = ((unsigned long long)M3D_INF_BITS << 32) | 0xFFFFFFFFull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = M3D_INF_BITS; W.any_point = false;
+}
 
 // rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first
 __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, int vx0, int vy0,
-                                              int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1) {
+                                              int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
     const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
@@ -514,39 +548,50 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
             c0 = s_first ? bc[s_first - 1] : 0u;
         }
         W.any_point = W.any_point || (c1 > c0);
+        M3D_STAT(sit, 9);
+        if (c1 > c0) M3D_STAT(sit, 10);
         const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
         const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
         const float lb2 = gx2 + gy * gy + gz * gz;
-        if (lb2 > W.bound) { W.sec = fminf(W.sec, lb2); continue; }
+        if (lb2 > W.bound) { W.sec = min(W.sec, __float_as_uint(lb2)); if (c1 > c0) M3D_STAT(sit, 11); continue; }
         const uint32_t t1 = base + c1;
+        if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
         for (uint32_t t = base + c0; t < t1; t += 4) {
-            // four independent 16-B gathers per wait (indices clamped into the run; a repeated point cannot change the argmin)
-            float4 c4[4];
+            M3D_STAT(sit, 12);
+            // four independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
+            const uint32_t last = t1 - 1u - t;   // >= 0
+            uint32_t idx[4]; float4 c4[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) c4[j] = m3d_ld(pts, min(t + j, t1 - 1));
+            for (int j = 0; j < 4; j++) { idx[j] = t + min((uint32_t)j, last); c4[j] = m3d_ld(pts, idx[j]); }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float ex = ux - c4[j].x, ey = uy - c4[j].y, ez = uz - c4[j].z;
                 const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                m3d_argmin_step2(W.bkey, W.best, W.sec, dd, __float_as_uint(c4[j].w) & M3D_IDX_MASK, (int)min(t + j, t1 - 1));
+                const uint32_t db = (j == 0 || (uint32_t)j <= last) ? __float_as_uint(dd) : M3D_INF_BITS;
+                const unsigned long long key = ((unsigned long long)db << 32) | __float_as_uint(c4[j].w);   // .w = input index
+                W.sec = min(W.sec, max(db, (uint32_t)(W.bkey >> 32)));   // the loser of (candidate, best so far) is a non-winner
+                const bool better = key < W.bkey;
+                W.bkey = better ? key : W.bkey;
+                W.best = better ? (int)idx[j] : W.best;
             }
         }
         W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
     }
 }
 
-// start of a walk: the seed (previous match, known to lie inside the neighbourhood) bounds the search and shrinks the
-// neighbourhood before any probe
+// Start of a seeded walk: the previous match is known to lie inside the neighbourhood (closer than one voxel edge), so its
+// distance bounds the search and shrinks the neighbourhood before any probe. It is NOT entered as a candidate: its own row
+// can only be discarded after a strictly closer point was found (box distance of its row <= its distance <= bound), so the
+// walk meets it again as an ordinary candidate whenever it can still win — and `sec` never sees the winner twice.
 __device__ __forceinline__ void m3d_walk_seed(M3dQuery& Q, m3d_gf4 pts, int m_prev, float ux, float uy, float uz, M3dWalk& W) {
     const float4 c4 = m3d_ld(pts, (size_t)m_prev);
     const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
     const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-    m3d_argmin_step(W.bkey, W.best, dd, __float_as_uint(c4.w) & M3D_IDX_MASK, m_prev);
     W.bound = fminf(W.bound, dd * 1.0001f);
 #pragma unroll
     for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
-        if (Q.gl[a] * Q.gl[a] > W.bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); W.sec = fminf(W.sec, Q.gl[a] * Q.gl[a]); }
-        if (Q.gh[a] * Q.gh[a] > W.bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); W.sec = fminf(W.sec, Q.gh[a] * Q.gh[a]); }
+        if (Q.gl[a] * Q.gl[a] > W.bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); W.sec = min(W.sec, __float_as_uint(Q.gl[a] * Q.gl[a])); }
+        if (Q.gh[a] * Q.gh[a] > W.bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); W.sec = min(W.sec, __float_as_uint(Q.gh[a] * Q.gh[a])); }
     }
 }
 
@@ -557,11 +602,11 @@ __device__ __forceinline__ int m3d_walk_result(const M3dWalk& W, float dmax2, bo
 
 // ONE QUERY PER LANE (long worklists, first iteration of a level): throughput-shaped
 __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz, float dmax2,
-                                             bool seeded, int m_prev, long long& code_out, float& sec) {
+                                             bool seeded, int m_prev, long long& code_out, float& sec, int sit = 0) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     code_out = m3d_voxel_code(Q);
-    M3dWalk W; W.bkey = ~0ull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = 3.0e38f; W.any_point = false;
+    M3dWalk W; m3d_walk_init(W, dmax2);
     if (seeded) m3d_walk_seed(Q, pts, m_prev, ux, uy, uz, W);
     if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
         const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
@@ -586,11 +631,13 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
                 do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
                 hi = m3d_ld(tab, 2 * (size_t)slot + 1);
             }
+            M3D_STAT(sit, 7);
             if (lo.x != key) continue;
-            m3d_walk_rows(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4);
+            M3D_STAT(sit, 8);
+            m3d_walk_rows(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
         }
     }
-    sec = W.sec;
+    sec = __uint_as_float(W.sec);
     return m3d_walk_result(W, dmax2, seeded);
 }
 
@@ -644,6 +691,12 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __shared__ int s_list[256];
     const int tid = (int)threadIdx.x;
     const int i = blk * 256 + tid;
+#ifdef M3D_STATS
+    const int sit = st->iters;
+#else
+    const int sit = 0;
+#endif
+    (void)sit;
     int cls = 0;   // 0 = done, 1 = seeded search, 2 = full search
     float ux = 0.f, uy = 0.f, uz = 0.f;
     int mp = -1;
@@ -665,6 +718,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 else if (mp == M3D_NN_NONE_CACHED) {
                     const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
                     cls = (code == cache[i]) ? 0 : 2;
+                    if (cls == 0) M3D_STAT(sit, 2);
                 } else if (mp < 0) cls = 2;
                 else {
                     // NN certificate: at its last real search (position u0) every candidate other than the match was at
@@ -688,6 +742,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
                                            (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
                     cls = certified ? 0 : (seedable ? 1 : 2);
+                    if (certified) M3D_STAT(sit, 1);
                 }
             }
         }
@@ -700,12 +755,14 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     int offW = 0, nW = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) { if (w < wave) offW += s_cnt[w]; nW += s_cnt[w]; }
+    if (i < n) { M3D_STAT(sit, 0); if (cls == 1) M3D_STAT(sit, 3); if (cls == 2) M3D_STAT(sit, 4); }
     if (nW == 0) return;   // block-uniform
+    if (tid == 0) M3D_STAT(sit, nW >= A.lane_min ? 5 : 6);
     if (nW >= A.lane_min) {
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
             long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, mp, code, sec);
+            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, mp, code, sec, sit);
             out[i] = m;
             if (m == M3D_NN_NONE_CACHED) cache[i] = code;
             if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
@@ -724,7 +781,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         const int qi = blk * 256 + (e & 255);
         float vx = 0.f, vy = 0.f, vz = 0.f;
         M3dQuery Q;
-        M3dWalk W; W.bkey = ~0ull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = 3.0e38f; W.any_point = false;
+        M3dWalk W; m3d_walk_init(W, dmax2);
         bool ok = false, found = false;
         long long code = 0;
         uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
@@ -759,7 +816,9 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             }
         }
         // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
-        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1);
+        if (tid == 0) M3D_STAT(sit, 15);
+        if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
+        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
         {
             float bnd = W.bound;
 #pragma unroll
@@ -767,23 +826,23 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             W.bound = bnd;
         }
         // ... and the other rows are mostly discarded by their box distance
-        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4);
+        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
         // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
-        unsigned long long bkey = W.bkey; int best = W.best; float sec = W.sec; bool any_point = W.any_point;
+        // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
+        unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
             const unsigned long long ok2 = __shfl_xor(bkey, o);
             const int ob = __shfl_xor(best, o);
-            const float os = __shfl_xor(sec, o);
+            const uint32_t os = (uint32_t)__shfl_xor((int)secb, o);
             const bool oa = __shfl_xor((int)any_point, o) != 0;
             const bool better = ok2 < bkey;
-            const float loser = m3d_key_d2(better ? bkey : ok2);
-            sec = fminf(sec, os);
-            sec = (ok2 != bkey) ? fminf(sec, loser) : sec;   // equal keys: the same point (the shared seed)
+            secb = min(min(secb, os), (uint32_t)((better ? bkey : ok2) >> 32));
             bkey = better ? ok2 : bkey;
             best = better ? ob : best;
             any_point = any_point || oa;
         }
+        const float sec = __uint_as_float(secb);
         if (act && sub == 0) {
             int m = -1;
             if (ok) {

@@ -1,7 +1,7 @@
 // m3d_device.h — device-visible data layout of libm3dreg (gfx950 only; no CUDA/dual path).
 //
 // HBM layout of one bucketed cloud level (DESIGN.md §Data layout):
-//   pts   float4[n]   points sorted by voxel key {x, y, z, bits(input_index | sub_voxel << 28)}: one
+//   pts   float4[n]   points sorted by voxel key {x, y, z, bits(input_index)}: one
 //                     16-B gather per candidate. Voxels are grouped in 2x2x2 BUCKETS; buckets follow a
 //                     compact Morton curve, the 8 voxels of a bucket are consecutive runs.
 //   htab  M3dBucket[T] open-addressing hash of occupied buckets, 32 B per entry (two 16-B halves):
@@ -19,8 +19,7 @@
 #define M3D_NSUMS 29
 #define M3D_PARTIAL_STRIDE 32      // int64 words per block partial of the reduction pass (29 used)
 #define M3D_INVALID_KEY 0xFFFFFFFFu
-#define M3D_IDX_MASK 0x0FFFFFFFu   // pts[].w = input index (28 bits) | voxel position inside its bucket << 28
-#define M3D_SUB_SHIFT 28
+#define M3D_IDX_MASK 0x0FFFFFFFu   // pts[].w = bits of the input index (at most 2^28 - 1 points per cloud)
 #define M3D_MAX_TRACE 256
 
 struct M3dGrid {           // geometry of one voxel grid (host computes it from the exact AABB)
