@@ -384,8 +384,24 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
         v[0] = 1; v[1] = qx; v[2] = qy; v[3] = qz;
         v[4] = qx * qx; v[5] = qx * qy; v[6] = qx * qz; v[7] = qy * qy; v[8] = qy * qz; v[9] = qz * qz;
     }
-    const uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
+    uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
     const bool head = (lane == 0) || (kprev != key);
+    {   // list of the first sorted position of every occupied voxel (k_normals runs once per VOXEL): ranks by wave64 ballot
+        // + LDS, one atomic per block reserves the block's segment; the order of the list is irrelevant
+        if (lane == 0 && ok && j > 0) kprev = B.skey_out[j - 1];
+        const bool ghead = ok && (j == 0 || kprev != key);
+        __shared__ uint32_t s_hc[4], s_hbase;
+        const int wave = threadIdx.x >> 6;
+        const unsigned long long bh = __ballot(ghead);
+        if (lane == 0) s_hc[wave] = (uint32_t)__popcll(bh);
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { if (w < wave) off += s_hc[w]; tot += s_hc[w]; }
+        if (threadIdx.x == 0) s_hbase = tot ? atomicAdd(&B.dyn[5], tot) : 0u;
+        __syncthreads();
+        if (ghead) B.ka[s_hbase + off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
+    }
     const unsigned long long heads = __ballot(head);
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const int seg_start = 63 - __clzll((long long)(heads & le));
@@ -409,13 +425,16 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
     }
 }
 
-// Pass 2: per point, add the (shifted) moments of the 27 voxels around it and take the smallest
-// eigenvector of the covariance.
+// Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same
+// normal — the per-point version did 10x the hash probes for identical results): add the (shifted) moments of the 27
+// voxels around it and take the smallest eigenvector of the covariance. The result is stored in the slot of the voxel's
+// first point; k_spread_normals copies it to the others.
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B.n) return;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= B.dyn[5]) return;
+    const int j = (int)B.ka[v];   // first sorted position of the voxel (a finite point)
     const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const long long* mom = B.mom;
@@ -423,7 +442,6 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const float4 pj = L.pts[j];
     const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j >= g.n_valid) { nrm_in[oi] = out; return; }   // non-finite points sort last: no normal
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
               icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
@@ -497,6 +515,23 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     nrm_in[oi] = out;
 }
 
+// Pass 3: every other point takes the normal of its voxel's first point; non-finite points (sorted last) get none
+__global__ __launch_bounds__(256) void k_spread_normals(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.mom) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B.n) return;
+    const M3dLevelDev L = build_level(B);
+    const M3dGrid& g = L.g;
+    const float4 pj = L.pts[j];
+    const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
+    if (j >= g.n_valid) { B.nrm_in[oi] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
+                                       (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
+    if (hp == j) return;
+    B.nrm_in[oi] = B.nrm_in[__float_as_uint(L.pts[hp].w) & M3D_IDX_MASK];
+}
+
 // normals re-ordered into each level's sorted order: the reduction kernel gathers them by MATCH position, and
 // neighbouring queries match neighbouring sorted positions (same cache lines) but unrelated input indices
 __global__ __launch_bounds__(256) void k_gather_normals(const M3dBuild* __restrict__ builds) {
@@ -565,6 +600,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
         M3D_DBG(s, "k_cell_moments");
         hipLaunchKernelGGL(k_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);
         M3D_DBG(s, "k_normals");
+        hipLaunchKernelGGL(k_spread_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+        M3D_DBG(s, "k_spread_normals");
         hipLaunchKernelGGL(k_gather_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_gather_normals");
     }
