@@ -275,30 +275,11 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     }
 }
 
-// second pass: the last point of every bucket writes the population (and claims a bigcum row when it
-// does not fit 16 bits)
+// second pass, one probe per occupied voxel: the last point of every VOXEL writes the cumulative population of its voxel
+// and of the empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0); when it is also
+// the last point of its BUCKET it writes the bucket's population and, should that exceed 16 bits, claims a bigcum row.
+// The 16-bit cum values of such a bucket are meaningless (and unused): k_bucket_big rewrites them as 32-bit rows.
 __global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = B.n;
-    if (j >= n) return;
-    const uint32_t* skey = B.skey_out;
-    const uint32_t k = skey[j];
-    if (k == M3D_INVALID_KEY) return;
-    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
-    if ((kn >> 3) == (k >> 3) && kn != M3D_INVALID_KEY) return;     // not the last point of its bucket
-    const uint32_t hmask = B.dyn[1];
-    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
-    while (B.htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t cnt = (uint32_t)j - B.htab[h].start + 1u;
-    B.htab[h].count = cnt;
-    B.htab[h].big = (cnt > 65535u) ? (1u + atomicAdd(&B.dyn[4], 1u)) : 0u;
-}
-
-// third pass: the last point of every voxel writes the cumulative population of its voxel and of the
-// empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0)
-__global__ __launch_bounds__(256) void k_bucket_cum(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = B.n;
@@ -315,9 +296,35 @@ __global__ __launch_bounds__(256) void k_bucket_cum(const M3dBuild* __restrict__
     uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
     while (B.htab[h].key != bk) h = (h + 1) & hmask;
     const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
+    for (int t = s0; t < s1; t++) B.htab[h].cum[t] = (uint16_t)v;
+    if (!same_bucket) {                                               // last point of the bucket
+        B.htab[h].count = v;
+        B.htab[h].big = (v > 65535u) ? (1u + atomicAdd(&B.dyn[4], 1u)) : 0u;
+    }
+}
+
+// third pass, almost always empty (a bucket of 2x2x2 voxels with more than 65535 points): 32-bit cumulative rows
+__global__ __launch_bounds__(256) void k_bucket_big(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (B.dyn[4] == 0u) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B.n;
+    if (j >= n) return;
+    const uint32_t* skey = B.skey_out;
+    const uint32_t k = skey[j];
+    if (k == M3D_INVALID_KEY) return;
+    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
+    if (kn == k) return;
+    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
+    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
+    const uint32_t hmask = B.dyn[1];
+    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
+    while (B.htab[h].key != bk) h = (h + 1) & hmask;
     const uint32_t big = B.htab[h].big;
-    if (big == 0) { for (int t = s0; t < s1; t++) B.htab[h].cum[t] = (uint16_t)v; }
-    else if (big - 1u < B.bigcap) { for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v; }
+    if (big == 0u || big - 1u >= B.bigcap) return;
+    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
+    for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v;
 }
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
@@ -583,7 +590,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
         M3D_DBG(s, "k_rs_scatter");
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_count_cells, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    const int cc = blocks > 32 ? 32 : blocks;   // k_count_cells ends in two atomics per block on the build's counters: few, fat blocks
+    hipLaunchKernelGGL(k_count_cells, dim3(cc, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3((n_builds + 63) / 64), dim3(64), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
@@ -593,8 +601,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
     M3D_DBG(s, "k_finalize_level");
     hipLaunchKernelGGL(k_bucket_counts, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_bucket_counts");
-    hipLaunchKernelGGL(k_bucket_cum, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
-    M3D_DBG(s, "k_bucket_cum");
+    hipLaunchKernelGGL(k_bucket_big, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_bucket_big");
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");
