@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict
         const float px = *reinterpret_cast<const float*>(p + D.ox);
         const float py = *reinterpret_cast<const float*>(p + D.oy);
         const float pz = *reinterpret_cast<const float*>(p + D.oz);
-        D.x[i] = px; D.y[i] = py; D.z[i] = pz;
+        D.xyz[i] = make_float4(px, py, pz, 0.f);
         if (m3d_finite3(px, py, pz)) {
             const uint32_t a = ord_f32(px), b = ord_f32(py), c = ord_f32(pz);
             mn[0] = max(mn[0], ~a); mx[0] = max(mx[0], a);
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__
     const M3dBuild& B = builds[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B.n) return;
-    const float px = B.x[i], py = B.y[i], pz = B.z[i];
+    const float4 pi = B.xyz[i];
+    const float px = pi.x, py = pi.y, pz = pi.z;
     uint32_t key = M3D_INVALID_KEY;
     if (m3d_finite3(px, py, pz)) {
         const int ix = (int)m3d_cell_f(px, B.grid.mn[0], B.grid.inv_leaf);
@@ -260,8 +261,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const bool valid = k != M3D_INVALID_KEY;
     const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
-    float4 p;
-    p.x = B.x[oi]; p.y = B.y[oi]; p.z = B.z[oi];
+    float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
     B.pts[j] = p;
     if (bhead) {

@@ -19,7 +19,7 @@ static inline bool m3d_dbg_on() { static const bool on = getenv("M3DREG_DEBUG_SY
 struct M3dDecode {               // one cloud of a decode batch (a2)
     const uint8_t* raw;          // PointCloud2 payload on the device
     int n, step, ox, oy, oz;
-    float *x, *y, *z;            // [n] out: SoA coordinates, input order
+    float4* xyz;                 // [n] out: coordinates in input order, one 16-B element per point (finalize gathers them by permutation)
     uint32_t* aabb;              // [8] out (zeroed): ~ordered min[3] (as max), ordered max[3], finite count
 };
 
@@ -27,7 +27,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     int n;
     int sort_passes;             // 8-bit LSD passes needed to order this grid's keys
     int ntiles;
-    const float *x, *y, *z;      // SoA input-order coordinates of the cloud
+    const float4* xyz;           // input-order coordinates of the cloud
     M3dGrid grid;                // hmask/hshift are filled on the device (dyn)
     uint32_t* keys;              // [n] out: key per input point
     uint32_t *ka, *va, *kb, *vb; // [n] sort ping-pong workspace

@@ -58,7 +58,7 @@ struct m3dreg_cloud {
     int32_t n_levels = 0;
     float leaf[M3DREG_MAX_LEVELS]{};
     bool has_normals = false;
-    float *x = nullptr, *y = nullptr, *z = nullptr;
+    float4* xyz = nullptr;         // coordinates in input order
     float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
@@ -271,7 +271,7 @@ uint32_t table_cap(size_t n) { uint32_t hs = 16; while (hs < 2u * uint32_t(n)) h
 size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     Carver k(base);
     const size_t n = size_t(c->n);
-    c->x = k.take<float>(n); c->y = k.take<float>(n); c->z = k.take<float>(n);
+    c->xyz = k.take<float4>(n);
     c->nrm_in = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
     for (int l = 0; l < P.n_levels; l++) {
         DevLevel& L = c->lv[l];
@@ -384,7 +384,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             raw = staged[i];
         }
         D.raw = raw; D.n = int(in[i].n); D.step = int(step); D.ox = int(ox); D.oy = int(oy); D.oz = int(oz);
-        D.x = cl[i]->x; D.y = cl[i]->y; D.z = cl[i]->z; D.aabb = aabb[i];
+        D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
     B_HIP(hipMemcpyAsync(d_dec, h_dec, sizeof(M3dDecode) * k, hipMemcpyHostToDevice, h->stream));
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
@@ -411,7 +411,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             memset(&B, 0, sizeof(B));
             B.n = c->n; B.sort_passes = sort_passes_for(L, c->n_valid != c->n); B.ntiles = m3d_sort_tiles(c->n);
             if (B.sort_passes > max_passes) max_passes = B.sort_passes;
-            B.x = c->x; B.y = c->y; B.z = c->z; B.grid = L.grid;
+            B.xyz = c->xyz; B.grid = L.grid;
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
             B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = W.dyn;
