@@ -95,6 +95,9 @@ __device__ __forceinline__ void sort_buffers(const M3dBuild& B, int pass, const 
 }
 __device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return (B.sort_passes & 1) ? B.kb : B.ka; }
 __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { return (B.sort_passes & 1) ? B.vb : B.va; }
+// the ping-pong key buffer that does NOT hold the sorted keys is free after the last pass: the normal grid keeps the list
+// of its voxel heads (first sorted position of every occupied voxel) there
+__device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return (B.sort_passes & 1) ? B.ka : B.kb; }
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass) {
     const M3dBuild& B = builds[blockIdx.y];
@@ -191,27 +194,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
 // ---- a4: bucket heads -> exact-sized hash table, sorted float4 points -----------------------------
 // dyn[0] = occupied voxels, dyn[1] = hmask, dyn[2] = hshift, dyn[3] = occupied buckets, dyn[4] = big buckets
 // (table geometry is derived on the device: no host round trip between the sort and the table build)
+// (occupied voxels and buckets are counted per 256-position block, without atomics: contended returning atomics on one
+// address retire at ~5 per microsecond on this chip — 1500 of them were the whole cost of every variant that used them)
 __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
-    const uint32_t* skey = sorted_keys(B);
     const int n = B.n;
-    uint32_t c = 0, b = 0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const uint32_t* skey = sorted_keys(B);
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    bool vh = false, bh = false;
+    if (j < n) {
         const uint32_t k = skey[j];
-        if (k == M3D_INVALID_KEY) continue;
-        const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
-        if (j == 0 || kp != k) c++;
-        if (j == 0 || (kp >> 3) != (k >> 3)) b++;
+        if (k != M3D_INVALID_KEY) {
+            const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
+            vh = (j == 0) || (kp != k);
+            bh = (j == 0) || ((kp >> 3) != (k >> 3));
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) { c += __shfl_down((int)c, o); b += __shfl_down((int)b, o); }
     __shared__ uint32_t red[4][2];
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = c; red[threadIdx.x >> 6][1] = b; }
+    const unsigned long long bv = __ballot(vh), bb = __ballot(bh);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = (uint32_t)__popcll(bv); red[threadIdx.x >> 6][1] = (uint32_t)__popcll(bb); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        c = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-        if (c) atomicAdd(&B.dyn[0], c);
-        if (b) atomicAdd(&B.dyn[3], b);
+    if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block
+        B.hist[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        B.hist[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
 }
 
@@ -221,13 +227,35 @@ __host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap
     hmask = hs - 1; hshift = 32 - hb;
 }
 
-__global__ void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_builds) return;
-    const M3dBuild& B = builds[i];
-    uint32_t hmask; int hshift;
-    m3d_table_size(B.dyn[3], B.hcap, hmask, hshift);
-    B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
+// one workgroup per build: totals of the per-block counts (dyn[0] voxels, dyn[3] buckets), exclusive prefix of the voxel
+// heads in place (where each block of k_finalize_level appends its heads), table geometry
+__global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
+    const M3dBuild& B = builds[blockIdx.x];
+    const int nblk = (B.n + 255) / 256;
+    __shared__ uint32_t sh[2][256];
+    uint32_t carryV = 0, carryB = 0;
+    const int t = threadIdx.x;
+    for (int base = 0; base < nblk; base += 256) {
+        const int b = base + t;
+        const uint32_t vV = b < nblk ? B.hist[2 * b] : 0u, vB = b < nblk ? B.hist[2 * b + 1] : 0u;
+        sh[0][t] = vV; sh[1][t] = vB;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t aV = t >= o ? sh[0][t - o] : 0u, aB = t >= o ? sh[1][t - o] : 0u;
+            __syncthreads();
+            sh[0][t] += aV; sh[1][t] += aB;
+            __syncthreads();
+        }
+        if (b < nblk) B.hist[2 * b] = carryV + sh[0][t] - vV;
+        carryV += sh[0][255]; carryB += sh[1][255];
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint32_t hmask; int hshift;
+        m3d_table_size(carryB, B.hcap, hmask, hshift);
+        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV;
+        B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds) {
@@ -250,16 +278,31 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = B.n;
-    if (j >= n) return;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;   // block-uniform
+    const bool inb = j < n;
     const uint32_t* skey = sorted_keys(B);
     const uint32_t* sval = sorted_vals(B);
     const uint32_t hmask = B.dyn[1];
     const int hshift = (int)B.dyn[2];
-    const uint32_t k = skey[j];
-    const uint32_t oi = sval[j];
-    B.skey_out[j] = k; B.perm_out[j] = oi;             // kept for the introspection API
+    const uint32_t k = inb ? skey[j] : M3D_INVALID_KEY;
+    const uint32_t oi = inb ? sval[j] : 0u;
     const bool valid = k != M3D_INVALID_KEY;
-    const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
+    const uint32_t kp = (inb && j) ? skey[j - 1] : M3D_INVALID_KEY;
+    if (B.mom) {   // normal grid: k_normals runs once per occupied voxel, over the dense list of voxel heads: this block
+        // appends its heads at the prefix k_table_params left in hist[2 blk] (ranks: wave64 ballots + LDS; no atomics)
+        __shared__ uint32_t s_wc[4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const bool vhead = valid && (j == 0 || kp != k);
+        const unsigned long long bh = __ballot(vhead);
+        if (lane == 0) s_wc[wave] = (uint32_t)__popcll(bh);
+        __syncthreads();
+        uint32_t off = B.hist[2 * blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; w++) if (w < wave) off += s_wc[w];
+        if (vhead) voxel_head_list(B)[off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
+    }
+    if (!inb) return;
+    B.skey_out[j] = k; B.perm_out[j] = oi;             // kept for the introspection API
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
     float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
@@ -391,24 +434,8 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
         v[0] = 1; v[1] = qx; v[2] = qy; v[3] = qz;
         v[4] = qx * qx; v[5] = qx * qy; v[6] = qx * qz; v[7] = qy * qy; v[8] = qy * qz; v[9] = qz * qz;
     }
-    uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
+    const uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
     const bool head = (lane == 0) || (kprev != key);
-    {   // list of the first sorted position of every occupied voxel (k_normals runs once per VOXEL): ranks by wave64 ballot
-        // + LDS, one atomic per block reserves the block's segment; the order of the list is irrelevant
-        if (lane == 0 && ok && j > 0) kprev = B.skey_out[j - 1];
-        const bool ghead = ok && (j == 0 || kprev != key);
-        __shared__ uint32_t s_hc[4], s_hbase;
-        const int wave = threadIdx.x >> 6;
-        const unsigned long long bh = __ballot(ghead);
-        if (lane == 0) s_hc[wave] = (uint32_t)__popcll(bh);
-        __syncthreads();
-        uint32_t off = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { if (w < wave) off += s_hc[w]; tot += s_hc[w]; }
-        if (threadIdx.x == 0) s_hbase = tot ? atomicAdd(&B.dyn[5], tot) : 0u;
-        __syncthreads();
-        if (ghead) B.ka[s_hbase + off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
-    }
     const unsigned long long heads = __ballot(head);
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const int seg_start = 63 - __clzll((long long)(heads & le));
@@ -441,7 +468,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     if (!B.mom) return;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= B.dyn[5]) return;
-    const int j = (int)B.ka[v];   // first sorted position of the voxel (a finite point)
+    const int j = (int)voxel_head_list(B)[v];   // first sorted position of the voxel (a finite point)
     const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const long long* mom = B.mom;
@@ -590,10 +617,9 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int 
         M3D_DBG(s, "k_rs_scatter");
     }
     HIP_TRY(hipGetLastError());
-    const int cc = blocks > 32 ? 32 : blocks;   // k_count_cells ends in two atomics per block on the build's counters: few, fat blocks
-    hipLaunchKernelGGL(k_count_cells, dim3(cc, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_count_cells, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_count_cells");
-    hipLaunchKernelGGL(k_table_params, dim3((n_builds + 63) / 64), dim3(64), 0, s, d_builds, n_builds);
+    hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
     hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_clear_table");
