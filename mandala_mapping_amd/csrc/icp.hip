@@ -982,6 +982,7 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
 // only costs a few empty launches, never correctness). The two counters live in pair 0's state, agent-scope atomics only.
 __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ jobs, int n_pairs, bool still_active, unsigned int seq,
                                                     unsigned long long* __restrict__ progress) {
+    if (!progress) return;   // nobody listens (fixed iteration counts): skip the device-scope atomics
     M3dPairState* g0 = jobs[0].st;
     if (still_active) {
         __hip_atomic_fetch_add(&g0->gsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -997,10 +998,11 @@ __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ j
     }
 }
 
+__host__ __device__ inline int m3d_ticket_group(int bpp);
 template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
-                                                                    long long* __restrict__ partials,
+                                                                    long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk);
@@ -1060,13 +1062,27 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     // L2 — including the megabytes of match/state lines the search kernel left dirty (measured: +50 us per iteration).
     // (The blocks of a pair sit on one XCD only when the batch is a multiple of 8 pairs; the L2s of different XCDs are
     // not coherent for plain accesses.)
+    // "Last block": a device-scope returning atomic is performed at the memory side and same-address ones retire one after
+    // the other at ~5 per microsecond — 49 arrivals on one ticket were the 10 us this tail cost. Two levels instead: a block
+    // arrives at its GROUP's counter (~sqrt(bpp) blocks each, every counter on its own 128-B line), the last of a group at
+    // the pair's counter: at most ~7 + 7 serialised arrivals instead of 49.
     __shared__ int s_last;
     __shared__ long long s_part[8][M3D_PARTIAL_STRIDE];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned int)bpp - 1u) ? 1 : 0;
+        const int gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs, grp = blk / gs;
+        unsigned int* tk = tickets + (size_t)pair * (size_t)(ng + 1) * 32u;
+        const unsigned int members = (unsigned int)min(gs, bpp - grp * gs);
+        int last = 0;
+        if (__hip_atomic_fetch_add(&tk[32 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            __hip_atomic_store(&tk[32 * (1 + grp)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&tk[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)ng - 1u) {
+                __hip_atomic_store(&tk[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -1074,8 +1090,16 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
         const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
         long long v = 0;
         if (slot < M3D_NSUMS)
-            for (int b = seg; b < bpp; b += 8)
-                v += __hip_atomic_load(&partials[((size_t)pair * bpp + b) * M3D_PARTIAL_STRIDE + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int b0 = seg; b0 < bpp; b0 += 64) {   // eight loads in flight per thread (a `v += load` loop waits for every one)
+                long long t[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int b = b0 + 8 * k;
+                    t[k] = (b < bpp) ? __hip_atomic_load(&partials[((size_t)pair * bpp + b) * M3D_PARTIAL_STRIDE + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) v += t[k];
+            }
         s_part[seg][slot] = v;
         __syncthreads();
         if (threadIdx.x < M3D_NSUMS) {
@@ -1087,7 +1111,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    st->ticket = 0u;
     m3d_solve_pair(J, first_of_level, s_part[0]);
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
 }
@@ -1151,6 +1174,13 @@ static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
     return b < 1 ? 1 : b;
 }
 
+// blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
+__host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }
+int m3d_ticket_words(int n_pairs, int max_n_src) {
+    const int bpp = m3d_acc_blocks(max_n_src), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
+    return n_pairs * (ng + 1) * 32;
+}
+
 // workgroups per pair of the reduction pass: ~8 queries per thread, so the 29-term block reduction is amortised
 int m3d_acc_blocks(int max_n_src) {
     static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
@@ -1170,8 +1200,8 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
         M3D_DBG(s, "k_nn_iter");
         if (k1) (void)hipEventRecord(k1, s);
         const int bpp_a = m3d_acc_blocks(max_n_src);
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, seq, progress, fuse_solve);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, seq, progress, fuse_solve);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, seq, progress, fuse_solve);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, seq, progress, fuse_solve);
         M3D_DBG(s, "k_accumulate_matches");
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);

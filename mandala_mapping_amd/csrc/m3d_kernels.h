@@ -78,6 +78,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int lane_min;                // a 256-query block with >= lane_min queries to search walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
     long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
+    unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
 };
@@ -87,6 +88,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
                                     hipEvent_t k1);
+int m3d_ticket_words(int n_pairs, int max_n_src);
 int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
                                       const M3dNnWork& w);

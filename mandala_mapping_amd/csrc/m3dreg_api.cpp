@@ -100,6 +100,8 @@ struct m3dreg_handle {
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
+    unsigned int* d_tickets = nullptr; // arrival counters of the reduction pass
+    size_t tickets_cap = 0;
     size_t partials_cap = 0;
     size_t match_cap = 0;
     size_t match_pairs_cap = 0;
@@ -505,6 +507,15 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         HIPCHK(h, hipMalloc((void**)&h->d_partials, sizeof(long long) * (n_part + n_part / 4)));
         h->partials_cap = n_part + n_part / 4;
     }
+    const size_t n_tk = size_t(m3d_ticket_words(int(n_pairs), max_n_src));
+    if (n_tk > h->tickets_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_tickets) hipFree(h->d_tickets);
+        h->d_tickets = nullptr; h->tickets_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_tickets, sizeof(unsigned int) * (n_tk + n_tk / 4)));
+        h->tickets_cap = n_tk + n_tk / 4;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned int) * n_tk, h->stream));   // (the kernels leave them at zero as well)
     h->match_stride = int(stride);
     h->match_pairs = n_pairs;
     return M3DREG_OK;
@@ -512,7 +523,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
 
 M3dNnWork nn_work(const m3dreg_handle* h) {
     M3dNnWork w;
-    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials;
+    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
     w.certify = h->certify;
@@ -657,7 +668,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials }) if (p) hipFree(p);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -739,7 +750,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                 prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
                 if (prev_sampled) { k0 = next_event(h); h->ev_kind.push_back(0); k1 = next_event(h); h->ev_kind.push_back(1); }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), h->seq, h->d_progress, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             h->launched_iters++;
         }
     }
