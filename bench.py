@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=2,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
     ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
+    ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -114,10 +115,15 @@ def main():
             last["all"] = (allT, allst)
         last["T"], last["st"], last["clouds"] = T, st, clouds
 
+    host_log = []
+
     def enqueue(i):
         r = regs[i % D]
+        ta = time.perf_counter()
         clouds = make_clouds(r)
+        tb = time.perf_counter()
         r.align_batch_async(r._pairs([(s_, t_, None) for s_, t_ in clouds]), B)
+        host_log.append(("enq", i, 1e3 * (tb - ta), 1e3 * (time.perf_counter() - tb)))
         return clouds
 
     def run_steps(k):
@@ -129,7 +135,9 @@ def main():
         clouds = None
         for i in range(k):
             idx, clouds = pending.pop(0)
+            ta = time.perf_counter()
             T, st = regs[idx % D].batch_wait(B)
+            host_log.append(("wait", idx, 1e3 * (time.perf_counter() - ta), 0.0))
             finish(T, st, clouds)
             if nxt < k:
                 pending.append((nxt, enqueue(nxt))); nxt += 1
@@ -162,10 +170,14 @@ def main():
         r.profile_read(0, reset=True)
         r.profile_read(1, reset=True)
     barrier()
+    host_log.clear()
     t0 = time.perf_counter()
     run_steps(K)
     barrier()
     t1 = time.perf_counter()
+    if args.trace_host and rank == 0:
+        for what, i, a, b in host_log:
+            print(f"[host] {what} step {i}: {a:.3f} ms" + (f" bucketing, {b:.3f} ms enqueue of the iterations" if what == "enq" else ""), file=sys.stderr)
     launches = kern_ms = iters_timed = iter_ms = 0
     for r in regs:
         a, b = r.profile_read(1, reset=True)       # k_nn_iter alone
