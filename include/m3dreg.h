@@ -175,6 +175,34 @@ int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out);
 int m3dagg_restart(m3dagg* a);                       /* requestCallback (:224-229) */
 int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
 
+/* ---- calibration cost on the device ------------------------------------------
+ * The cost function the reference's two calibration nodes minimise (`testData`,
+ * m3d/m3d_calibration/src/m3d_calibration_twiddle.cpp:199-308 = m3d_calibration_sa.cpp:199-277): every scan
+ * segment of a calibration sweep (scanSegment: points in the laser frame + the tf of its message, :33-38, :56-69) is
+ * moved by original_Transform * laserOffsetMatrix (:229-230), the points are split on the sign of their RAW
+ * coordinate along `laser_up_axis` (:234-266), both halves are voxel-grid filtered at 0.1 m (:279-286) and the
+ * cost is the number of second-half voxel centroids with no first-half centroid within 0.05 m (:288-304).
+ * The library evaluates many candidates per launch; the two optimiser loops are host code with the reference's
+ * control flow and constants. */
+typedef struct m3dcal m3dcal;
+int m3dcal_create(m3dreg_handle* h, int laser_up_axis, m3dcal** out);       /* laserUpAxis param (:176), 0 / 1 / 2 */
+int m3dcal_destroy(m3dcal* c);
+/* addPoints (:56-69): one scan segment = n points (FLOAT32 x/y/z inside point_step, host buffer) + its
+ * original_Transform as column-major float[16] (Eigen::Affine3f::data()) */
+int m3dcal_add_segment(m3dcal* c, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                       const float original_T[16]);
+/* testData for k candidates at once: params = k x {x, y, z, yaw, pitch, roll}; counts[k] receives `c`;
+ * voxels (optional) k x {voxels of firstPcFilter, voxels of secondPcFilter} */
+int m3dcal_evaluate(m3dcal* c, const float* params, size_t k, int64_t* counts, int64_t* voxels);
+/* publishPointcloud of the twiddle node (:330-396): p = 0, dp = 0.01, x1.1 on improvement, x0.9 on failure, stops when
+ * the LAST dp falls to 1e-6 (:376-380, :348) or after max_sweeps (0 = no limit). p_out[5] = (y, z, yaw, pitch, roll) as
+ * the node maps them (:345: testData(0, p0, p1, p2, p3, p4)); returns the number of sweeps through *sweeps. */
+int m3dcal_twiddle(m3dcal* c, int max_sweeps, float p_out[5], float* best_error, int* sweeps, int* evaluations);
+/* publishPointcloud of the annealing node (m3d_calibration_sa.cpp:284-356): T0 = 1, alpha = 0.99, until T <= 0.001
+ * (688 evaluations), proposal p + 0.001 * U(-1, 1) per coordinate, Metropolis acceptance, rand()/RAND_MAX after
+ * srand(seed) (the reference seeds with time(0), :289). p_io: start on entry ((0, 0.12, 0, 0, 0) in the node, :303-308). */
+int m3dcal_anneal(m3dcal* c, unsigned int seed, float p_io[5], float* best_error, int* evaluations);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration of the handle is bracketed by three hipEvents on
  * its stream: before and after the dominant kernel (`k_nn_iter`: certificate check + exact 27-voxel NN search of

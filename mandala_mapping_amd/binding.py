@@ -29,6 +29,7 @@ EXPORTS = [
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
+    "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
 ]
 
 
@@ -81,6 +82,12 @@ def lib():
     L.m3dagg_take_cloud.argtypes = [vp, C.POINTER(vp)]
     L.m3dagg_restart.argtypes = [vp]
     L.m3dagg_download.argtypes = [vp, f32p, sz, C.POINTER(sz)]
+    L.m3dcal_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.m3dcal_destroy.argtypes = [vp]
+    L.m3dcal_add_segment.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p]
+    L.m3dcal_evaluate.argtypes = [vp, f32p, sz, i64p, i64p]
+    L.m3dcal_twiddle.argtypes = [vp, C.c_int, f32p, f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.m3dcal_anneal.argtypes = [vp, C.c_uint, f32p, f32p, C.POINTER(C.c_int)]
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
@@ -366,6 +373,56 @@ class Aggregator:
 
     def restart(self):
         self._reg._check(lib().m3dagg_restart(self._a), "m3dagg_restart")
+
+
+class Calibrator:
+    """Device-side mirror of the cost function and the two optimiser loops of the reference's calibration nodes
+    (m3d_calibration_twiddle.cpp:199-396, m3d_calibration_sa.cpp:199-356): scan segments in, outlier counts /
+    the calibrated mounting offset out. Many parameter candidates are evaluated per launch."""
+
+    def __init__(self, reg: Registrar, laser_up_axis=1):
+        self._reg = reg
+        self._c = C.c_void_p()
+        reg._check(lib().m3dcal_create(reg._h, laser_up_axis, C.byref(self._c)), "m3dcal_create")
+
+    def close(self):
+        if self._c:
+            lib().m3dcal_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            if self._reg._h:
+                self.close()
+        except Exception:
+            pass
+
+    def add_segment(self, xyz, original_T):
+        """xyz: float32 [n,3] points of one scan in the laser frame; original_T: 4x4 transform of that scan (:56-69)"""
+        a = np.ascontiguousarray(xyz, np.float32)
+        t = np.ascontiguousarray(np.asarray(original_T, np.float32).T.reshape(16))   # column-major, as Eigen::Affine3f::data()
+        self._reg._check(lib().m3dcal_add_segment(self._c, a.ctypes.data_as(C.c_void_p), len(a), 12, 0, 4, 8, _ptr(t, C.c_float)), "m3dcal_add_segment")
+
+    def evaluate(self, params, with_voxels=False):
+        """params: [k,6] (x, y, z, yaw, pitch, roll) -> int64 [k] costs (and [k,2] voxel counts of the two halves)"""
+        p = np.ascontiguousarray(np.atleast_2d(params), np.float32)
+        k = len(p)
+        out = np.zeros(k, np.int64)
+        vox = np.zeros((k, 2), np.int64)
+        self._reg._check(lib().m3dcal_evaluate(self._c, _ptr(p, C.c_float), k, _ptr(out, C.c_int64), _ptr(vox, C.c_int64)), "m3dcal_evaluate")
+        return (out, vox) if with_voxels else out
+
+    def twiddle(self, max_sweeps=0):
+        p = np.zeros(5, np.float32)
+        err, sw, ev = C.c_float(), C.c_int(), C.c_int()
+        self._reg._check(lib().m3dcal_twiddle(self._c, max_sweeps, _ptr(p, C.c_float), C.byref(err), C.byref(sw), C.byref(ev)), "m3dcal_twiddle")
+        return p, err.value, sw.value, ev.value
+
+    def anneal(self, seed, p0=(0.0, 0.12, 0.0, 0.0, 0.0)):
+        p = np.asarray(p0, np.float32).copy()
+        err, ev = C.c_float(), C.c_int()
+        self._reg._check(lib().m3dcal_anneal(self._c, seed, _ptr(p, C.c_float), C.byref(err), C.byref(ev)), "m3dcal_anneal")
+        return p, err.value, ev.value
 
 
 class Gpu6dSlamNode:

@@ -67,6 +67,20 @@ struct M3dAggArgs {
 };
 hipError_t m3d_launch_aggregate(hipStream_t s, const M3dAggArgs& A);
 
+// calibrate.hip
+struct M3dCalArgs {
+    const float4* pts;           // [n] raw points of every segment {x, y, z, bits(segment index)}
+    int n, n_seg, axis;          // axis = laserUpAxis (the RAW coordinate whose sign splits the sweep)
+    const float* mm;             // [candidates][n_seg][12]: original_Transform * laserOffsetMatrix, row-major linear (9) + translation (3)
+    unsigned long long* keys;    // [candidates][tsize] (half << 63 | voxel) or all-ones = empty
+    uint32_t* cnt;               // [candidates][tsize] points per voxel
+    long long* sums;             // [candidates][tsize][3] 2^-16 m fixed-point coordinate sums
+    uint32_t tsize; int tshift;  // table size (power of two >= 2 n), 64 - log2(tsize)
+    unsigned int* result;        // [candidates][3]: {cost, voxels of the first half, voxels of the second half}
+    int* status;                 // [candidates]: 1 = a voxel coordinate left the +-2^20 range
+};
+hipError_t m3d_launch_calibration(hipStream_t s, const M3dCalArgs& A, int n_candidates);
+
 // icp.hip
 // variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
 //          2 = split (default): k_nn_iter (classify + search, one int32 result per query), then k_accumulate_matches,

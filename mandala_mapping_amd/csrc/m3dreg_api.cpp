@@ -1005,6 +1005,229 @@ int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out) {
     return M3DREG_OK;
 }
 
+// ---- calibration cost on the device --------------------------------------------------
+}  // extern "C"
+
+struct m3dcal {
+    m3dreg_handle* h = nullptr;
+    int axis = 1;
+    std::vector<float> pts;        // host copy {x, y, z, bits(segment)} per point
+    std::vector<float> seg_T;      // 12 floats per segment: row-major linear part + translation of original_Transform
+    bool dirty = true;
+    float4* d_pts = nullptr; size_t pts_cap = 0;
+    float* d_mm = nullptr; size_t mm_cap = 0;
+    unsigned long long* d_keys = nullptr; size_t keys_cap = 0;
+    uint32_t* d_cnt = nullptr; size_t cnt_cap = 0;
+    long long* d_sums = nullptr; size_t sums_cap = 0;
+    unsigned int* d_result = nullptr; size_t res_cap = 0;
+    int* d_status = nullptr; size_t st_cap = 0;
+    float* h_mm = nullptr; size_t hmm_cap = 0;                 // pinned staging
+    unsigned int* h_result = nullptr; size_t hres_cap = 0;
+    int* h_status = nullptr; size_t hst_cap = 0;
+};
+
+namespace {
+// m3d_calibration_twiddle.cpp:202-220 — Eigen's scalar code paths restated in float, left to right, no fused multiply-add
+// (this file is built with -ffp-contract=off); cosf/sinf stay on the host so both sides of the parity test share one libm.
+void cal_offset_matrix(const float p[6], float ol[9], float ot[3]) {
+    const float ha0 = 0.5f * p[3], ha1 = 0.5f * p[4], ha2 = 0.5f * p[5];
+    const float aw = std::cos(ha0), ax = std::sin(ha0) * 1.0f, ay = std::sin(ha0) * 0.0f, az = std::sin(ha0) * 0.0f;
+    const float bw = std::cos(ha1), bx = std::sin(ha1) * 0.0f, by = std::sin(ha1) * 1.0f, bz = std::sin(ha1) * 0.0f;
+    const float cw = std::cos(ha2), cx = std::sin(ha2) * 0.0f, cy = std::sin(ha2) * 0.0f, cz = std::sin(ha2) * 1.0f;
+    const float dw = aw * bw - ax * bx - ay * by - az * bz;
+    const float dx = aw * bx + ax * bw + ay * bz - az * by;
+    const float dy = aw * by + ay * bw + az * bx - ax * bz;
+    const float dz = aw * bz + az * bw + ax * by - ay * bx;
+    const float w = dw * cw - dx * cx - dy * cy - dz * cz;
+    const float x = dw * cx + dx * cw + dy * cz - dz * cy;
+    const float y = dw * cy + dy * cw + dz * cx - dx * cz;
+    const float z = dw * cz + dz * cw + dx * cy - dy * cx;
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    ol[0] = 1.0f - (tyy + tzz); ol[1] = txy - twz; ol[2] = txz + twy;
+    ol[3] = txy + twz; ol[4] = 1.0f - (txx + tzz); ol[5] = tyz - twx;
+    ol[6] = txz - twy; ol[7] = tyz + twx; ol[8] = 1.0f - (txx + tyy);
+    for (int r = 0; r < 3; r++) ot[r] = 0.0f + ((ol[3 * r] * p[0] + ol[3 * r + 1] * p[1]) + ol[3 * r + 2] * p[2]);
+}
+// :229 mm = original_Transform * laserOffsetMatrix
+void cal_compose(const float* a, const float bl[9], const float bt[3], float* o) {
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) o[3 * r + c] = (a[3 * r] * bl[c] + a[3 * r + 1] * bl[3 + c]) + a[3 * r + 2] * bl[6 + c];
+        o[9 + r] = ((a[3 * r] * bt[0] + a[3 * r + 1] * bt[1]) + a[3 * r + 2] * bt[2]) + a[9 + r];
+    }
+}
+template <typename T> int cal_grow(m3dreg_handle* h, T*& p, size_t& cap, size_t need, bool pinned = false) {
+    if (need <= cap) return M3DREG_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (p) { if (pinned) hipHostFree(p); else hipFree(p); }
+    p = nullptr; cap = 0;
+    const size_t c = need + need / 4 + 16;
+    if (pinned) HIPCHK(h, hipHostMalloc((void**)&p, sizeof(T) * c, hipHostMallocDefault));
+    else HIPCHK(h, hipMalloc((void**)&p, sizeof(T) * c));
+    cap = c;
+    return M3DREG_OK;
+}
+int cal_eval1(m3dcal* c, const float p6[6], float* err) {
+    int64_t v = 0;
+    int rc = m3dcal_evaluate(c, p6, 1, &v, nullptr);
+    if (rc) return rc;
+    *err = float(v);
+    return M3DREG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int m3dcal_create(m3dreg_handle* h, int laser_up_axis, m3dcal** out) {
+    if (!h || !out || laser_up_axis < 0 || laser_up_axis > 2) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dcal_create: bad argument");
+    m3dcal* c = new m3dcal();
+    c->h = h; c->axis = laser_up_axis;
+    *out = c;
+    return M3DREG_OK;
+}
+
+int m3dcal_destroy(m3dcal* c) {
+    if (!c) return M3DREG_ERR_INVALID_ARG;
+    hipSetDevice(c->h->device);
+    hipStreamSynchronize(c->h->stream);
+    for (void* p : { (void*)c->d_pts, (void*)c->d_mm, (void*)c->d_keys, (void*)c->d_cnt, (void*)c->d_sums, (void*)c->d_result, (void*)c->d_status }) if (p) hipFree(p);
+    for (void* p : { (void*)c->h_mm, (void*)c->h_result, (void*)c->h_status }) if (p) hipHostFree(p);
+    delete c;
+    return M3DREG_OK;
+}
+
+int m3dcal_add_segment(m3dcal* c, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z, const float T[16]) {
+    if (!c || !T || (n && !data)) return M3DREG_ERR_INVALID_ARG;
+    if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step) return fail(c->h, M3DREG_ERR_INVALID_ARG, "m3dcal_add_segment: field offsets outside point_step");
+    if (c->pts.size() / 4 + n >= 0x3FFFFFFFull) return fail(c->h, M3DREG_ERR_INVALID_ARG, "m3dcal_add_segment: too many points");
+    const uint32_t seg = uint32_t(c->seg_T.size() / 12);
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c->seg_T.push_back(T[4 * k + r]);   // column-major in, row-major kept
+    for (int r = 0; r < 3; r++) c->seg_T.push_back(T[12 + r]);
+    const uint8_t* b = static_cast<const uint8_t*>(data);
+    for (size_t j = 0; j < n; j++) {
+        float v[4];
+        memcpy(&v[0], b + j * point_step + off_x, 4); memcpy(&v[1], b + j * point_step + off_y, 4); memcpy(&v[2], b + j * point_step + off_z, 4);
+        memcpy(&v[3], &seg, 4);
+        c->pts.insert(c->pts.end(), v, v + 4);
+    }
+    c->dirty = true;
+    return M3DREG_OK;
+}
+
+int m3dcal_evaluate(m3dcal* c, const float* params, size_t k, int64_t* counts, int64_t* voxels) {
+    if (!c || !params || !counts || k == 0 || k > 4096) return M3DREG_ERR_INVALID_ARG;
+    m3dreg_handle* h = c->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = c->pts.size() / 4, S = c->seg_T.size() / 12;
+    if (n == 0) return fail(h, M3DREG_ERR_EMPTY_CLOUD, "m3dcal_evaluate: no segments");
+    int rc;
+    if ((rc = cal_grow(h, c->d_pts, c->pts_cap, n))) return rc;
+    if (c->dirty) { HIPCHK(h, hipMemcpyAsync(c->d_pts, c->pts.data(), sizeof(float) * 4 * n, hipMemcpyHostToDevice, h->stream)); c->dirty = false; }
+    uint32_t tsize = 1024; int tbits = 10;
+    while (tsize < 2u * uint32_t(n)) { tsize <<= 1; tbits++; }
+    // candidates per launch: bounded by a table budget of ~2 GiB
+    size_t per = (size_t(2) << 30) / (size_t(tsize) * 36u);
+    if (per < 1) per = 1;
+    if (per > k) per = k;
+    if ((rc = cal_grow(h, c->d_keys, c->keys_cap, per * tsize))) return rc;
+    if ((rc = cal_grow(h, c->d_cnt, c->cnt_cap, per * tsize))) return rc;
+    if ((rc = cal_grow(h, c->d_sums, c->sums_cap, per * tsize * 3))) return rc;
+    if ((rc = cal_grow(h, c->d_result, c->res_cap, per * 3))) return rc;
+    if ((rc = cal_grow(h, c->d_status, c->st_cap, per))) return rc;
+    if ((rc = cal_grow(h, c->h_result, c->hres_cap, per * 3, true))) return rc;
+    if ((rc = cal_grow(h, c->h_status, c->hst_cap, per, true))) return rc;
+    if ((rc = cal_grow(h, c->d_mm, c->mm_cap, per * S * 12))) return rc;
+    if ((rc = cal_grow(h, c->h_mm, c->hmm_cap, per * S * 12, true))) return rc;
+    for (size_t k0 = 0; k0 < k; k0 += per) {
+        const size_t kk = std::min(per, k - k0);
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // the pinned staging of the previous chunk has been consumed
+        for (size_t q = 0; q < kk; q++) {
+            float ol[9], ot[3];
+            cal_offset_matrix(params + 6 * (k0 + q), ol, ot);
+            for (size_t s = 0; s < S; s++) cal_compose(&c->seg_T[12 * s], ol, ot, c->h_mm + (q * S + s) * 12);
+        }
+        HIPCHK(h, hipMemcpyAsync(c->d_mm, c->h_mm, sizeof(float) * kk * S * 12, hipMemcpyHostToDevice, h->stream));
+        M3dCalArgs A{};
+        A.pts = c->d_pts; A.n = int(n); A.n_seg = int(S); A.axis = c->axis; A.mm = c->d_mm;
+        A.keys = c->d_keys; A.cnt = c->d_cnt; A.sums = c->d_sums; A.tsize = tsize; A.tshift = 64 - tbits;
+        A.result = c->d_result; A.status = c->d_status;
+        HIPCHK(h, m3d_launch_calibration(h->stream, A, int(kk)));
+        HIPCHK(h, hipMemcpyAsync(c->h_result, c->d_result, sizeof(unsigned int) * 3 * kk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int) * kk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (size_t q = 0; q < kk; q++) {
+            if (c->h_status[q]) return fail(h, M3DREG_ERR_GRID_TOO_LARGE, "m3dcal_evaluate: a transformed point lies beyond +-104 km");
+            counts[k0 + q] = int64_t(c->h_result[3 * q]);
+            if (voxels) { voxels[2 * (k0 + q)] = int64_t(c->h_result[3 * q + 1]); voxels[2 * (k0 + q) + 1] = int64_t(c->h_result[3 * q + 2]); }
+        }
+    }
+    return M3DREG_OK;
+}
+
+// m3d_calibration_twiddle.cpp:330-396. p and dp are std::vector<float> (:514); `p[i] - 2.0 * dp[i]` and `dp[i] * 1.1` are
+// double expressions rounded back to float on assignment, exactly as written here.
+int m3dcal_twiddle(m3dcal* c, int max_sweeps, float p_out[5], float* best_error_out, int* sweeps, int* evaluations) {
+    if (!c || !p_out) return M3DREG_ERR_INVALID_ARG;
+    float p[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, dp[5] = { 0.01f, 0.01f, 0.01f, 0.01f, 0.01f };
+    int evals = 0, rc;
+    auto test = [&](float* err) { const float q[6] = { 0.0f, p[0], p[1], p[2], p[3], p[4] }; evals++; return cal_eval1(c, q, err); };   // :345
+    float best_error;
+    if ((rc = test(&best_error))) return rc;
+    int n = 0;
+    float incr = 100.0f;
+    while (incr > 0.000001) {                                     // :348
+        if (max_sweeps > 0 && n >= max_sweeps) break;
+        for (int i = 0; i < 5; i++) {
+            p[i] = p[i] + dp[i];
+            float err;
+            if ((rc = test(&err))) return rc;
+            if (err < best_error) { best_error = err; dp[i] = float(dp[i] * 1.1); }
+            else {
+                p[i] = float(p[i] - 2.0 * dp[i]);
+                if ((rc = test(&err))) return rc;
+                if (err < best_error) { best_error = err; dp[i] = float(dp[i] * 1.1); }
+                else { p[i] = p[i] + dp[i]; dp[i] = float(dp[i] * 0.9); }
+            }
+        }
+        incr = 0.0f;
+        for (int i = 0; i < 5; i++) incr = dp[i];                 // :376-380: only the LAST dp survives
+        n++;
+    }
+    for (int i = 0; i < 5; i++) p_out[i] = p[i];
+    if (best_error_out) *best_error_out = best_error;
+    if (sweeps) *sweeps = n;
+    if (evaluations) *evaluations = evals;
+    return M3DREG_OK;
+}
+
+// m3d_calibration_sa.cpp:280-356
+int m3dcal_anneal(m3dcal* c, unsigned int seed, float p[5], float* best_error_out, int* evaluations) {
+    if (!c || !p) return M3DREG_ERR_INVALID_ARG;
+    srand(seed);                                                  // :289 (time(0) there)
+    auto m_rand = []() { return -1.0f + 2 * ((float)rand()) / ((float)RAND_MAX); };   // :280-283
+    int evals = 0, rc;
+    float best_error;
+    { const float q[6] = { 0.0f, p[0], p[1], p[2], p[3], p[4] }; evals++; if ((rc = cal_eval1(c, q, &best_error))) return rc; }   // :311
+    float temperature = 1.0f;
+    const float alpha = 0.99;
+    while (temperature > 0.001f) {                                // :316
+        float c_p[5];
+        for (int i = 0; i < 5; i++) c_p[i] = float(p[i] + 0.001 * m_rand());   // :319-323
+        float c_error;
+        { const float q[6] = { 0.0f, c_p[0], c_p[1], c_p[2], c_p[3], c_p[4] }; evals++; if ((rc = cal_eval1(c, q, &c_error))) return rc; }
+        const float ac_p = float(std::exp((best_error - c_error) / temperature));   // :328 exp(float) -> std::exp overload on float
+        if (ac_p > ((float)rand()) / ((float)RAND_MAX)) {         // :329
+            best_error = c_error;
+            for (int i = 0; i < 5; i++) p[i] = c_p[i];
+        }
+        temperature = alpha * temperature;                        // :340
+    }
+    if (best_error_out) *best_error_out = best_error;
+    if (evaluations) *evaluations = evals;
+    return M3DREG_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------
 int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     if (!h) return M3DREG_ERR_INVALID_ARG;

@@ -210,3 +210,49 @@ def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
 def perturb(T, rng, deg, trans):
     """A noisy initial guess around T (odometry prior)."""
     return T @ random_T(rng, deg, trans)
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY §8 row f2: a calibration sweep of the rotating 2-D laser unit (m3d_calibration nodes)
+# ------------------------------------------------------------------------------------------------
+def offset_matrix(params):
+    """laserOffsetMatrix of m3d_calibration_twiddle.cpp:202-220 in float64: rotate(Rx(yaw) Ry(pitch) Rz(roll)) then
+    translate((x, y, z)) in the rotated frame. params = (x, y, z, yaw, pitch, roll)."""
+    x, y, z, yaw, pitch, roll = [float(v) for v in params]
+    R = rot_x(yaw) @ rot_y(pitch) @ rot_z(roll)
+    return make_T(R, R @ np.array([x, y, z]))
+
+
+CAL_ROOM = (np.array([-3.2, -2.6, 0.0]), np.array([3.0, 2.8, 3.0]))   # a lab-sized room: ranges of 1.3 - 4 m
+CAL_OBSTACLES = [
+    (np.array([1.6, 1.2, 0.0]), np.array([2.4, 2.0, 1.1])),
+    (np.array([-2.6, -2.0, 0.0]), np.array([-1.9, -0.8, 1.7])),
+]
+
+
+def calibration_sweep(n_seg=480, n_rays=480, true_params=(0.0, 0.03, -0.02, 0.03, 0.0, 0.02), seed=7, sigma=0.003, turns=1.0):
+    """Segments of one calibration sweep: a planar laser (rays in its own XY plane) on a head that turns about the
+    head's X axis — the axis lies in the scan plane, so over a full turn every surface is seen twice, once by the
+    rays with y > 0 and once by those with y <= 0 (laserUpAxis = 1). The laser sits on the head with the mounting
+    offset `true_params`; the tf of every message (`original_Transform`) only knows the head angle. The room is small
+    enough for neighbouring scan planes to land closer than the 0.05 m radius of the cost function.
+    Returns [(points float32 [k,3] in the laser frame, original_T float32 4x4)]."""
+    rng = np.random.default_rng(seed)
+    E = offset_matrix(true_params)
+    base = make_T(np.eye(3), np.array([0.1, -0.15, 1.45]))
+    a = (2.0 * np.pi / n_rays) * (np.arange(n_rays) + 0.5)
+    d_l = np.stack([np.cos(a), np.sin(a), np.zeros_like(a)], axis=-1)
+    segs = []
+    for i in range(n_seg):
+        th = 2.0 * np.pi * turns * i / n_seg
+        head = base @ make_T(rot_x(th), np.zeros(3))
+        W = head @ E
+        d_w = d_l @ W[:3, :3].T
+        o_w = np.broadcast_to(W[:3, 3], d_w.shape)
+        t = _ray_box_exit(o_w, d_w, *CAL_ROOM)
+        for bmin, bmax in CAL_OBSTACLES:
+            t = np.minimum(t, _ray_box_enter(o_w, d_w, bmin, bmax))
+        r = t + rng.normal(0.0, sigma, size=t.shape)
+        keep = (r > 1.0) & np.isfinite(r)            # the calibration node drops r <= 1 (m3d_calibration_twiddle.cpp:479)
+        segs.append(((d_l[keep] * r[keep, None]).astype(np.float32), head.astype(np.float32)))
+    return segs

@@ -58,6 +58,12 @@ def _lib(omp=False):
             getattr(L, fn).argtypes = [vp]
             getattr(L, fn).restype = C.c_double
         L.orc_agg_ready.argtypes = [vp]
+        L.orc_cal_test_data.argtypes = [f32p, i32p, f32p, C.c_int32, C.c_int32, f32p, i64p]
+        L.orc_cal_test_data.restype = C.c_int64
+        L.orc_cal_test_data_bruteforce.argtypes = [f32p, i32p, f32p, C.c_int32, C.c_int32, f32p]
+        L.orc_cal_test_data_bruteforce.restype = C.c_int64
+        L.orc_cal_offset_matrix.argtypes = [f32p, f32p, f32p]
+        L.orc_cal_offset_matrix.restype = None
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -199,3 +205,41 @@ class Aggregator:
 
     def restart(self):
         self._L.orc_agg_restart(self._a)
+
+
+class Calibration:
+    """oracle/m3d_cal_oracle.c: the reference's `testData` restated (m3d_calibration_twiddle.cpp:199-308)."""
+
+    def __init__(self, laser_up_axis=1):
+        self._L = _lib()
+        self.axis = laser_up_axis
+        self._xyz, self._n, self._T = [], [], []
+
+    def add_segment(self, xyz, original_T):
+        a = np.ascontiguousarray(xyz, np.float32)
+        T = np.asarray(original_T, np.float32)
+        self._xyz.append(a)
+        self._n.append(len(a))
+        self._T.append(np.concatenate([T[:3, :3].reshape(9), T[:3, 3]]).astype(np.float32))
+
+    def _pack(self):
+        xyz = np.ascontiguousarray(np.concatenate(self._xyz), np.float32) if self._xyz else np.zeros((0, 3), np.float32)
+        return xyz, np.asarray(self._n, np.int32), np.ascontiguousarray(np.stack(self._T), np.float32)
+
+    def test_data(self, params, brute=False):
+        """params: (x, y, z, yaw, pitch, roll) -> (cost, sizes[4]) or cost (brute force variant)"""
+        xyz, n, T = self._pack()
+        p = np.asarray(params, np.float32)
+        if brute:
+            return int(self._L.orc_cal_test_data_bruteforce(_ptr(xyz, C.c_float), _ptr(n, C.c_int32), _ptr(T, C.c_float), len(n), self.axis, _ptr(p, C.c_float)))
+        sizes = np.zeros(4, np.int64)
+        c = int(self._L.orc_cal_test_data(_ptr(xyz, C.c_float), _ptr(n, C.c_int32), _ptr(T, C.c_float), len(n), self.axis, _ptr(p, C.c_float), _ptr(sizes, C.c_int64)))
+        return c, sizes
+
+    def offset_matrix(self, params):
+        p = np.asarray(params, np.float32)
+        l, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        self._L.orc_cal_offset_matrix(_ptr(p, C.c_float), _ptr(l, C.c_float), _ptr(t, C.c_float))
+        M = np.eye(4, dtype=np.float32)
+        M[:3, :3] = l.reshape(3, 3); M[:3, 3] = t
+        return M
