@@ -26,8 +26,13 @@ __device__ __forceinline__ void m3d_stat(int it, int what, unsigned int v = 1u) 
     if (v == 1u) { if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_m3d_stats[it & 63][what], (unsigned long long)__popcll(m)); }
     else atomicAdd(&g_m3d_stats[it & 63][what], (unsigned long long)v);
 }
+__device__ __forceinline__ void m3d_stat_wave(int it, int what) {   // one count per WAVE that executes this point (SIMT trip counts)
+    const unsigned long long m = __ballot(1);
+    if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_m3d_stats[it & 63][what], 1ull);
+}
 #define M3D_STAT(it, what) m3d_stat(it, what)
 #define M3D_STATV(it, what, v) m3d_stat(it, what, v)
+#define M3D_STATW(it, what) m3d_stat_wave(it, what)
 extern "C" hipError_t m3d_debug_read_stats(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_stats), sizeof(unsigned long long) * 64 * 16);
     if (e == hipSuccess && reset) { static unsigned long long z[64 * 16]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_stats), z, sizeof(z)); }
@@ -36,6 +41,7 @@ extern "C" hipError_t m3d_debug_read_stats(unsigned long long* out, int reset) {
 #else
 #define M3D_STAT(it, what) ((void)0)
 #define M3D_STATV(it, what, v) ((void)0)
+#define M3D_STATW(it, what) ((void)0)
 #endif
 
 #define ICP_THREADS 256
@@ -558,6 +564,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
         for (uint32_t t = base + c0; t < t1; t += 4) {
             M3D_STAT(sit, 12);
+            M3D_STATW(sit, 14);
             // four independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
             const uint32_t last = t1 - 1u - t;   // >= 0
             uint32_t idx[4]; float4 c4[4];
@@ -580,16 +587,13 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
 }
 
 // Start of a seeded walk: the previous match is known to lie inside the neighbourhood (closer than one voxel edge), so its
-// distance bounds the search and shrinks the neighbourhood before any probe. It is NOT entered as a candidate: its own row
+// distance (measured by the query's owner while classifying) bounds the search and shrinks the neighbourhood before any probe. It is NOT entered as a candidate: its own row
 // can only be discarded after a strictly closer point was found (box distance of its row <= its distance <= bound), so the
 // walk meets it again as an ordinary candidate whenever it can still win — and `sec` never sees the winner twice.
-__device__ __forceinline__ void m3d_walk_seed(M3dQuery& Q, m3d_gf4 pts, int m_prev, float ux, float uy, float uz, M3dWalk& W) {
-    const float4 c4 = m3d_ld(pts, (size_t)m_prev);
-    const float ex = ux - c4.x, ey = uy - c4.y, ez = uz - c4.z;
-    const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+__device__ __forceinline__ void m3d_walk_seed_dd(M3dQuery& Q, float dd, M3dWalk& W) {
     W.bound = fminf(W.bound, dd * 1.0001f);
 #pragma unroll
-    for (int a = 0; a < 3; a++) {   // drop the sides of the neighbourhood that cannot hold a closer point
+    for (int a = 0; a < 3; a++) {
         if (Q.gl[a] * Q.gl[a] > W.bound) { Q.lo[a] = max(Q.lo[a], Q.ic[a]); W.sec = min(W.sec, __float_as_uint(Q.gl[a] * Q.gl[a])); }
         if (Q.gh[a] * Q.gh[a] > W.bound) { Q.hi[a] = min(Q.hi[a], Q.ic[a]); W.sec = min(W.sec, __float_as_uint(Q.gh[a] * Q.gh[a])); }
     }
@@ -602,12 +606,12 @@ __device__ __forceinline__ int m3d_walk_result(const M3dWalk& W, float dmax2, bo
 
 // ONE QUERY PER LANE (long worklists, first iteration of a level): throughput-shaped
 __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz, float dmax2,
-                                             bool seeded, int m_prev, long long& code_out, float& sec, int sit = 0) {
+                                             bool seeded, float dseed, long long& code_out, float& sec, int sit = 0) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
     code_out = m3d_voxel_code(Q);
     M3dWalk W; m3d_walk_init(W, dmax2);
-    if (seeded) m3d_walk_seed(Q, pts, m_prev, ux, uy, uz, W);
+    if (seeded) m3d_walk_seed_dd(Q, dseed, W);
     if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
         const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
         const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
@@ -688,7 +692,9 @@ struct M3dNnArgs {
 __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
     __shared__ int s_cnt[4];
-    __shared__ int s_list[256];
+    __shared__ int s_list[256];          // worklist of the cooperative walk: owner thread | seeded << 8 ...
+    __shared__ float s_wu[3][256];       // ... its transformed query ...
+    __shared__ float s_wd[256];          // ... and the squared distance to its seed (the previous match), all known to the owner
     const int tid = (int)threadIdx.x;
     const int i = blk * 256 + tid;
 #ifdef M3D_STATS
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 #endif
     (void)sit;
     int cls = 0;   // 0 = done, 1 = seeded search, 2 = full search
-    float ux = 0.f, uy = 0.f, uz = 0.f;
+    float ux = 0.f, uy = 0.f, uz = 0.f, dseed = 0.f;
     int mp = -1;
     if (i < n) {
         const float4 p = m3d_ld(src, i);
@@ -742,6 +748,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
                                            (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
                     cls = certified ? 0 : (seedable ? 1 : 2);
+                    dseed = dd1;
                     if (certified) M3D_STAT(sit, 1);
                 }
             }
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
             long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, mp, code, sec, sit);
+            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
             out[i] = m;
             if (m == M3D_NN_NONE_CACHED) cache[i] = code;
             if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
@@ -770,7 +777,12 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         return;
     }
     // ---- few queries: LDS worklist, 8 lanes per query ------------------------------------------------------------
-    if (cls != 0) s_list[offW + (int)__popcll(bW & ((1ull << lane) - 1ull))] = tid | (cls == 1 ? 256 : 0);
+    if (cls != 0) {   // the group that walks this query starts from what its owner already knows: no reload of the source point,
+        // of the previous match index or of the seed point — three dependent round trips less per pass
+        const int w = offW + (int)__popcll(bW & ((1ull << lane) - 1ull));
+        s_list[w] = tid | (cls == 1 ? 256 : 0);
+        s_wu[0][w] = ux; s_wu[1][w] = uy; s_wu[2][w] = uz; s_wd[w] = dseed;
+    }
     __syncthreads();
     const int sub = tid & 7;
     for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles below need every lane
@@ -787,14 +799,11 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
         int vx0 = 0, vy0 = 0, vz0 = 0;
         if (act) {
-            const float4 p = m3d_ld(src, qi);
-            vx = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-            vy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-            vz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+            vx = s_wu[0][q]; vy = s_wu[1][q]; vz = s_wu[2][q];
             ok = m3d_query_setup(g, vx, vy, vz, Q);   // finite by classification
             if (ok) {
                 code = m3d_voxel_code(Q);
-                if (seeded) m3d_walk_seed(Q, pts, out[qi], vx, vy, vz, W);   // every lane of the group starts from the seed
+                if (seeded) m3d_walk_seed_dd(Q, s_wd[q], W);   // every lane of the group starts from the seed's bound
                 if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
                     const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
                     const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
@@ -804,11 +813,13 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                         const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
                         const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
                         uint32_t slot = m3d_hash_slot(key, g.hshift);
-                        lo = m3d_ld(tab, 2 * (size_t)slot);
-                        while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
+                        lo = m3d_ld(tab, 2 * (size_t)slot); hi = m3d_ld(tab, 2 * (size_t)slot + 1);   // both halves in one round trip
+                        if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+                            do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
+                            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
+                        }
                         if (lo.x == key) {
                             found = true;
-                            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
                             vx0 = 2 * (b0x + ox); vy0 = 2 * (b0y + oy); vz0 = 2 * (b0z + oz);
                         }
                     }

@@ -23,10 +23,11 @@ L.m3d_debug_read_stats(buf, 1)
 reg.align_batch(pairs)
 L.m3d_debug_read_stats(buf, 1)
 a = np.array(buf[:], dtype=np.uint64).reshape(64, 16).astype(np.float64)
-names = ["queries", "certified", "none-cached", "seeded", "full", "blk lane", "blk coop", "probes", "found", "rows", "rows>0", "pruned>0", "batches", "cands", "-", "coop passes"]
+names = ["queries", "certified", "none-cached", "seeded", "full", "blk lane", "blk coop", "probes", "found", "rows", "rows>0", "pruned>0", "batches", "cands", "wave trips", "coop passes"]
 print(" it " + " ".join(f"{n:>11s}" for n in names))
 for it in range(20):
     print(f"{it:3d} " + " ".join(f"{a[it, k]:11.0f}" for k in range(16)))
 s = a[:20].sum(0)
 srch = s[3] + s[4]
+print(f"gather-loop trips per WAVE-slot vs per lane: {s[14]:.0f} wave trips x 64 lanes = {64*s[14]:.0f} lane slots for {s[12]:.0f} lane batches ({100*s[12]/max(1,64*s[14]):.1f} % of the slots useful)")
 print(f"per searched query: probes {s[7]/srch:.2f} found {s[8]/srch:.2f} rows {s[9]/srch:.2f} nonempty {s[10]/srch:.2f} pruned-nonempty {s[11]/srch:.2f} batches {s[12]/srch:.2f} candidates {s[13]/srch:.2f}")
