@@ -652,6 +652,7 @@ struct M3dNnArgs {
                                        //           lower bound of every non-best candidate seen there (NN certificate)
     int certify;                       // 1 = use the NN certificates (default); 0 = always search (A/B, M3DREG_CERTIFY)
     float seed_reach;                  // seeds farther than this many voxel edges are not used (<= 0.99)
+    M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
 };
 
@@ -659,7 +660,7 @@ struct M3dNnArgs {
     int pair, blk;                                                                                          \
     m3d_map_block(n_pairs, bpp, pair, blk);                                                                 \
     const M3dJob& J = jobs[pair];                                                                           \
-    const M3dPairState* st = J.st;                                                                          \
+    const M3dPairState* st = A.states + pair;   /* == J.st, without waiting for the job descriptor */      \
     if (st->done || (!first_of_level && st->level_done)) return;                                            \
     float R[9], tt[3];                                                                                      \
     m3d_load_pose(st, R, tt);                                                                               \
@@ -1014,11 +1015,11 @@ template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                                                    unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
+                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk);
     const M3dJob& J = jobs[pair];
-    M3dPairState* st = J.st;
+    M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
 
     if (st->done || (!first_of_level && st->level_done)) {
         // a finished pair still reports to the batch-wide progress word (one thread per pair)
@@ -1205,14 +1206,14 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     if (variant == 2) {
         // search: one block per 256 queries; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min;
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states;
         if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
         hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");
         if (k1) (void)hipEventRecord(k1, s);
         const int bpp_a = m3d_acc_blocks(max_n_src);
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, seq, progress, fuse_solve);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, seq, progress, fuse_solve);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve);
         M3D_DBG(s, "k_accumulate_matches");
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);

@@ -92,6 +92,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int lane_min;                // a 256-query block with >= lane_min queries to search walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
     long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
+    M3dPairState* states;        // [n_pairs] the batch's pair states (== jobs[pair].st)
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)

@@ -523,7 +523,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
 
 M3dNnWork nn_work(const m3dreg_handle* h) {
     M3dNnWork w;
-    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets;
+    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
     w.certify = h->certify;
