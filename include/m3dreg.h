@@ -137,6 +137,19 @@ typedef struct m3dreg_cloud_desc {
     int32_t data_is_device;
 } m3dreg_cloud_desc;
 int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);
+/* The whole sensor_msgs/PointCloud2 layout contract, decoded on the device: x / y / z are found by
+ * NAME in the field table, the way pcl::fromPCLPointCloud2 resolves them in the consumer idiom of
+ * m3d_aggregator.cpp:243-246; any offsets (aligned or not), FLOAT32 or FLOAT64 (rounded to nearest float; PCL itself
+ * refuses to map a FLOAT64 x onto pcl::PointXYZ), either byte order, organised clouds with padded rows
+ * (point i at (i / width) * row_step + (i % width) * point_step). Other fields (intensity, ring, rgb) are skipped.
+ * M3DREG_ERR_INVALID_ARG names what is wrong through m3dreg_last_error (missing field, unsupported datatype, sizes that do
+ * not fit data_bytes). The aggregator's own layout (16 / 0 / 4 / 8, little-endian) takes the coalesced fast path. */
+#define M3DREG_FLOAT32 7   /* sensor_msgs/PointField.FLOAT32 */
+#define M3DREG_FLOAT64 8   /* sensor_msgs/PointField.FLOAT64 */
+typedef struct m3dreg_point_field { const char* name; uint32_t offset; uint8_t datatype; uint32_t count; } m3dreg_point_field;
+int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_bytes, uint32_t width, uint32_t height, uint32_t point_step,
+                            uint32_t row_step, const m3dreg_point_field* fields, size_t n_fields, int is_bigendian, int data_is_device,
+                            m3dreg_cloud** out);
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c);
 int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
                         const float init_T[16], float out_T[16], m3dreg_stats* stats);

@@ -119,6 +119,10 @@ class CloudDesc(C.Structure):
                 ("off_z", C.c_size_t), ("data_is_device", C.c_int32)]
 
 
+class PointField(C.Structure):   # m3dreg_point_field
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint32), ("datatype", C.c_uint8), ("count", C.c_uint32)]
+
+
 class Pair(C.Structure):
     _fields_ = [("source", C.c_void_p), ("target", C.c_void_p), ("init_T", C.c_float * 16)]
 

@@ -27,6 +27,7 @@ EXPORTS = [
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
+    "m3dreg_cloud_create_pc2",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
@@ -60,6 +61,7 @@ def lib():
     L.m3dreg_align.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_cloud_create.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
     L.m3dreg_cloud_create_batch.argtypes = [vp, C.POINTER(abi.CloudDesc), sz, C.POINTER(vp)]
+    L.m3dreg_cloud_create_pc2.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.PointField), sz, C.c_int, C.c_int, C.POINTER(vp)]
     L.m3dreg_cloud_destroy.argtypes = [vp, vp]
     L.m3dreg_align_clouds.argtypes = [vp, vp, vp, f32p, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_align_batch.argtypes = [vp, C.POINTER(abi.Pair), sz, f32p, C.POINTER(abi.Stats)]
@@ -213,6 +215,18 @@ class Registrar:
         p = C.c_void_p()
         self._check(lib().m3dreg_cloud_create(self._h, buf, n, point_step, offsets[0], offsets[1], offsets[2], 0, C.byref(p)), "cloud_create")
         return Cloud(self, p, n)
+
+    def cloud_pc2(self, msg: PointCloud2):
+        """The message as it is — field table, byte order, row padding — decoded on the device (m3dreg_cloud_create_pc2)."""
+        k = len(msg.fields)
+        ft = (abi.PointField * k)()
+        for i, f in enumerate(msg.fields):
+            ft[i].name, ft[i].offset, ft[i].datatype, ft[i].count = f.name.encode(), f.offset, f.datatype, f.count
+        buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+        p = C.c_void_p()
+        self._check(lib().m3dreg_cloud_create_pc2(self._h, buf, len(msg.data), msg.width, msg.height, msg.point_step, msg.row_step, ft, k,
+                                                  1 if msg.is_bigendian else 0, 0, C.byref(p)), "cloud_create_pc2")
+        return Cloud(self, p, msg.n)
 
     def cloud_from_device(self, dev_ptr, n, point_step=16, offsets=(0, 4, 8)):
         """dev_ptr: integer device address of a PointCloud2-layout payload already in HBM."""

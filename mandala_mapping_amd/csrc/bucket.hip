@@ -27,6 +27,14 @@ __host__ __device__ inline float unord_f32(uint32_t u) {
 }
 float m3d_unord_f32(uint32_t u) { return unord_f32(u); }
 
+// one x/y/z field of a general PointCloud2 point: bytes -> (FLOAT32 | FLOAT64 rounded to nearest float), any alignment
+__device__ __forceinline__ float decode_field(const uint8_t* p, int is_f64, int bigendian) {
+    const int nb = is_f64 ? 8 : 4;
+    unsigned long long v = 0;
+    for (int b = 0; b < nb; b++) v |= (unsigned long long)p[b] << (8 * (bigendian ? (nb - 1 - b) : b));
+    return is_f64 ? (float)__longlong_as_double((long long)v) : __uint_as_float((uint32_t)v);
+}
+
 // aabb (zero-initialised): [0..2] = max of ~ordered (i.e. the minimum), [3..5] = max of ordered, [6] = finite points
 __global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict__ descs) {
     const M3dDecode D = descs[blockIdx.y];
@@ -34,10 +42,18 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict
     uint32_t mn[3] = { 0u, 0u, 0u }, mx[3] = { 0u, 0u, 0u };
     uint32_t cnt = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint8_t* p = D.raw + (size_t)i * D.step;
-        const float px = *reinterpret_cast<const float*>(p + D.ox);
-        const float py = *reinterpret_cast<const float*>(p + D.oy);
-        const float pz = *reinterpret_cast<const float*>(p + D.oz);
+        float px, py, pz;
+        if (!D.generic) {
+            const uint8_t* p = D.raw + (size_t)i * D.step;
+            px = *reinterpret_cast<const float*>(p + D.ox);
+            py = *reinterpret_cast<const float*>(p + D.oy);
+            pz = *reinterpret_cast<const float*>(p + D.oz);
+        } else {   // any field offset / FLOAT32 or FLOAT64 / either byte order / padded rows, on the device
+            const uint8_t* p = D.raw + (size_t)(i / D.width) * (size_t)D.row_step + (size_t)(i % D.width) * (size_t)D.step;
+            px = decode_field(p + D.ox, D.f64[0], D.bigendian);
+            py = decode_field(p + D.oy, D.f64[1], D.bigendian);
+            pz = decode_field(p + D.oz, D.f64[2], D.bigendian);
+        }
         D.xyz[i] = make_float4(px, py, pz, 0.f);
         if (m3d_finite3(px, py, pz)) {
             const uint32_t a = ord_f32(px), b = ord_f32(py), c = ord_f32(pz);

@@ -19,6 +19,11 @@ static inline bool m3d_dbg_on() { static const bool on = getenv("M3DREG_DEBUG_SY
 struct M3dDecode {               // one cloud of a decode batch (a2)
     const uint8_t* raw;          // PointCloud2 payload on the device
     int n, step, ox, oy, oz;
+    int generic;                 // 0: little-endian FLOAT32 fields at 4-byte aligned addresses, rows without padding (what m3d_aggregator sends);
+                                 // 1: the general sensor_msgs/PointCloud2 case below, assembled byte by byte
+    int width, row_step;         // generic: point i sits at (i / width) * row_step + (i % width) * step
+    int f64[3];                  // generic: field a is FLOAT64 (rounded to float) instead of FLOAT32
+    int bigendian;               // generic: fields are stored big-endian
     float4* xyz;                 // [n] out: coordinates in input order, one 16-B element per point (finalize gathers them by permutation)
     uint32_t* aabb;              // [8] out (zeroed): ~ordered min[3] (as max), ordered max[3], finite count
 };

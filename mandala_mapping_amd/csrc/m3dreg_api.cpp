@@ -288,7 +288,8 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     return (k.off + 255) & ~size_t(255);
 }
 
-struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned; };
+struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned;
+                    bool generic = false; size_t width = 0, row_step = 0, data_bytes = 0; bool f64[3] = { false, false, false }; bool bigendian = false; };
 
 // Bucket a batch of clouds: one decode launch, ONE host sync (grid geometry is host-derived from the exact
 // AABBs), one bucketing pipeline for every grid of every cloud, one final sync (table geometry read-back).
@@ -336,7 +337,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         // --- the rest ---
         for (size_t i = 0; i < k; i++) {
             const size_t n = in[i].n;
-            staged[i] = (!in[i].is_device) ? w.take<uint8_t>(in[i].aligned ? n * in[i].step : 12 * n) : nullptr;
+            staged[i] = (!in[i].is_device) ? w.take<uint8_t>(in[i].generic ? in[i].data_bytes : (in[i].aligned ? n * in[i].step : 12 * n)) : nullptr;
             for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
                 BuildWs& B = bw[i * size_t(grids_per_cloud) + size_t(gidx)];
                 B.ka = w.take<uint32_t>(n); B.va = w.take<uint32_t>(n); B.kb = w.take<uint32_t>(n); B.vb = w.take<uint32_t>(n);
@@ -371,8 +372,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         const uint8_t* raw = static_cast<const uint8_t*>(in[i].data);
         if (!in[i].is_device) {
             const void* src = in[i].data;
-            size_t bytes = in[i].n * in[i].step;
-            if (!in[i].aligned) {   // never produced by m3d_aggregator (16/0/4/8); repacked on the host
+            size_t bytes = in[i].generic ? in[i].data_bytes : in[i].n * in[i].step;
+            if (!in[i].generic && !in[i].aligned) {   // never produced by m3d_aggregator (16/0/4/8); repacked on the host
                 repack[i].resize(3 * in[i].n);
                 const uint8_t* b = static_cast<const uint8_t*>(in[i].data);
                 for (size_t j = 0; j < in[i].n; j++) {
@@ -386,6 +387,9 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             raw = staged[i];
         }
         D.raw = raw; D.n = int(in[i].n); D.step = int(step); D.ox = int(ox); D.oy = int(oy); D.oz = int(oz);
+        D.generic = in[i].generic ? 1 : 0; D.width = int(in[i].generic ? in[i].width : in[i].n); D.row_step = int(in[i].row_step);
+        for (int a = 0; a < 3; a++) D.f64[a] = in[i].f64[a] ? 1 : 0;
+        D.bigendian = in[i].bigendian ? 1 : 0;
         D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
     B_HIP(hipMemcpyAsync(d_dec, h_dec, sizeof(M3dDecode) * k, hipMemcpyHostToDevice, h->stream));
@@ -711,6 +715,44 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
     m3dreg_cloud_desc d;
     d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z; d.data_is_device = data_is_device;
     return m3dreg_cloud_create_batch(h, &d, 1, out);
+}
+
+// the whole sensor_msgs/PointCloud2 layout contract (what pcl::fromPCLPointCloud2 resolves by field name,
+// m3d_aggregator.cpp:243-246), decoded on the device
+int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_bytes, uint32_t width, uint32_t height, uint32_t point_step,
+                            uint32_t row_step, const m3dreg_point_field* fields, size_t n_fields, int is_bigendian, int data_is_device,
+                            m3dreg_cloud** out) {
+    if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: bad argument");
+    *out = nullptr;
+    if (!data || !fields || width == 0 || height == 0 || point_step == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: empty message");
+    const size_t n = size_t(width) * size_t(height);
+    if (n > 0x0FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: at most 2^28 - 1 points per cloud");
+    if (row_step == 0) row_step = width * point_step;   // some producers leave it unset on unorganised clouds
+    if (size_t(row_step) < size_t(width) * point_step || size_t(row_step) * height > data_bytes || size_t(row_step) * height > 0x7FFFFFFFull)
+        return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: width * point_step / row_step * height do not fit the data");
+    CloudInput ci{};
+    ci.data = data; ci.n = n; ci.step = point_step; ci.is_device = data_is_device != 0; ci.aligned = true;
+    ci.generic = true; ci.width = width; ci.row_step = row_step; ci.data_bytes = size_t(row_step) * height; ci.bigendian = is_bigendian != 0;
+    size_t* off[3] = { &ci.ox, &ci.oy, &ci.oz };
+    bool have[3] = { false, false, false };
+    for (size_t f = 0; f < n_fields; f++) {
+        if (!fields[f].name) continue;
+        const int a = !strcmp(fields[f].name, "x") ? 0 : (!strcmp(fields[f].name, "y") ? 1 : (!strcmp(fields[f].name, "z") ? 2 : -1));
+        if (a < 0) continue;   // intensity, ring, rgb ...: not read by the registration path
+        if (fields[f].datatype != M3DREG_FLOAT32 && fields[f].datatype != M3DREG_FLOAT64)
+            return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: x/y/z must be FLOAT32 or FLOAT64");
+        if (fields[f].count < 1) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: x/y/z field with count 0");
+        const size_t sz = fields[f].datatype == M3DREG_FLOAT64 ? 8 : 4;
+        if (size_t(fields[f].offset) + sz > point_step) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: field outside point_step");
+        *off[a] = fields[f].offset; ci.f64[a] = sz == 8; have[a] = true;
+    }
+    if (!have[0] || !have[1] || !have[2]) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: the message lacks an x, y or z field");
+    // the aggregator's own layout takes the fast path (one coalesced 16-B read per point)
+    if (!ci.bigendian && !ci.f64[0] && !ci.f64[1] && !ci.f64[2] && row_step == width * point_step && point_step % 4 == 0 && ci.ox % 4 == 0 &&
+        ci.oy % 4 == 0 && ci.oz % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 4 == 0)
+        ci.generic = false;
+    HIPCHK(h, hipSetDevice(h->device));
+    return create_clouds(h, &ci, 1, out);
 }
 
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {

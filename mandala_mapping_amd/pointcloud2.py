@@ -13,6 +13,7 @@ from typing import List, Tuple
 import numpy as np
 
 FLOAT32 = 7  # sensor_msgs/PointField.FLOAT32
+FLOAT64 = 8  # sensor_msgs/PointField.FLOAT64
 
 
 @dataclass
@@ -86,3 +87,29 @@ def to_little_endian(msg: PointCloud2) -> PointCloud2:
     xyz = decode_xyz(msg)
     out = encode_xyz(xyz, msg.point_step, msg.xyz_offsets(), msg.frame_id, big_endian=False)
     return out
+
+
+def encode_general(xyz: np.ndarray, fields, point_step: int, width: int = None, height: int = 1, row_pad: int = 0,
+                   big_endian: bool = False, frame_id="m3d_test/m3d_link", fill: int = 0xA5) -> PointCloud2:
+    """A PointCloud2 with an arbitrary field table (SURVEY §8 row f3 test inputs): `fields` = [PointField] that must
+    contain x, y, z as FLOAT32 or FLOAT64 at any offsets; other fields and all padding bytes are filled with `fill`;
+    organised clouds (height > 1) get `row_pad` extra bytes at the end of every row."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n = xyz.shape[0]
+    width = n if width is None else width
+    assert width * height == n
+    row_step = width * point_step + row_pad
+    buf = np.full((height, row_step), fill, dtype=np.uint8)
+    pts = buf[:, :width * point_step].reshape(n, point_step) if row_pad == 0 and height == 1 else None
+    col = {"x": 0, "y": 1, "z": 2}
+    for f in fields:
+        if f.name not in col:
+            continue
+        dt = (">" if big_endian else "<") + ("f8" if f.datatype == FLOAT64 else "f4")
+        sz = 8 if f.datatype == FLOAT64 else 4
+        vals = xyz[:, col[f.name]].astype(dt).view(np.uint8).reshape(n, sz)
+        for r in range(height):
+            rows = buf[r, :width * point_step].reshape(width, point_step)
+            rows[:, f.offset:f.offset + sz] = vals[r * width:(r + 1) * width]
+    return PointCloud2(data=buf.tobytes(), width=width, height=height, point_step=point_step, row_step=row_step,
+                       is_bigendian=big_endian, is_dense=bool(np.isfinite(xyz).all()), frame_id=frame_id, fields=list(fields))

@@ -243,3 +243,31 @@ class Calibration:
         M = np.eye(4, dtype=np.float32)
         M[:3, :3] = l.reshape(3, 3); M[:3, 3] = t
         return M
+
+
+def decode_pc2(msg):
+    """sensor_msgs/PointCloud2 -> float32 [n,3], field by field and point by point (SURVEY §8 row f3 oracle): x / y / z
+    found by name as pcl::fromPCLPointCloud2 does (m3d_aggregator.cpp:243-246), FLOAT32 or FLOAT64 (rounded to nearest
+    float), either byte order, point i at (i // width) * row_step + (i % width) * point_step."""
+    raw = memoryview(msg.data)
+    off, kind = {}, {}
+    for f in msg.fields:
+        if f.name in ("x", "y", "z"):
+            if f.datatype not in (7, 8):
+                raise ValueError("x/y/z must be FLOAT32 or FLOAT64")
+            off[f.name], kind[f.name] = f.offset, f.datatype
+    if len(off) != 3:
+        raise ValueError("PointCloud2 lacks x/y/z")
+    row_step = msg.row_step or msg.width * msg.point_step
+    n = msg.width * msg.height
+    i = np.arange(n)
+    base = (i // msg.width) * row_step + (i % msg.width) * msg.point_step
+    data = np.frombuffer(raw, dtype=np.uint8)
+    out = np.empty((n, 3), np.float32)
+    for a, name in enumerate(("x", "y", "z")):
+        sz = 8 if kind[name] == 8 else 4
+        idx = base[:, None] + off[name] + np.arange(sz)[None, :]
+        b = np.ascontiguousarray(data[idx])
+        dt = (">" if msg.is_bigendian else "<") + ("f8" if sz == 8 else "f4")
+        out[:, a] = b.view(dt).reshape(n).astype(np.float32)
+    return out

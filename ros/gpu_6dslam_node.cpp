@@ -22,6 +22,7 @@
 #include <string>
 
 #include <geometry_msgs/PoseStamped.h>
+#include <vector>
 #include <ros/ros.h>
 #include <sensor_msgs/PointCloud2.h>
 #include <tf/transform_broadcaster.h>
@@ -30,7 +31,7 @@
 
 class Gpu6dSlamNode {
 public:
-    Gpu6dSlamNode() : nh_("~"), have_target_(false) {
+    Gpu6dSlamNode() : nh_("~") {
         std::string cloud_topic;
         nh_.param<std::string>("cloud", cloud_topic, "/m3d_test/aggregator/cloud");
         nh_.param<std::string>("odom_frame", odom_frame_, "m3d_test/odom");
@@ -54,30 +55,30 @@ public:
         pose_pub_ = nh_.advertise<geometry_msgs::PoseStamped>("pose", 1);
         sub_ = nh_.subscribe(cloud_topic, 1, &Gpu6dSlamNode::onCloud, this);   // queue depth 1, like the producer
     }
-    ~Gpu6dSlamNode() { if (h_) m3dreg_destroy(h_); }
+    ~Gpu6dSlamNode() { if (h_) { if (prev_) m3dreg_cloud_destroy(h_, prev_); m3dreg_destroy(h_); } }
 
 private:
-    // byte offsets of the FLOAT32 x/y/z fields (the aggregator always sends 0/4/8 in a 16-byte point)
-    static bool xyzOffsets(const sensor_msgs::PointCloud2& m, size_t off[3]) {
-        int found = 0;
-        for (const auto& f : m.fields) {
-            int a = f.name == "x" ? 0 : f.name == "y" ? 1 : f.name == "z" ? 2 : -1;
-            if (a < 0) continue;
-            if (f.datatype != sensor_msgs::PointField::FLOAT32 || f.count != 1) return false;
-            off[a] = f.offset; found |= 1 << a;
-        }
-        return found == 7 && !m.is_bigendian;
+    // The message crosses the C ABI as it is — raw buffer + field table; x/y/z are resolved by name on the other side the
+    // way pcl::fromPCLPointCloud2 would (any offsets, FLOAT32/FLOAT64, either byte order, padded rows: SURVEY §8 row f3).
+    // Each sweep is bucketed ONCE: it is the source of this registration and the target of the next.
+    m3dreg_cloud* bucket(const sensor_msgs::PointCloud2& m) {
+        std::vector<m3dreg_point_field> ft(m.fields.size());
+        for (size_t i = 0; i < m.fields.size(); i++)
+            ft[i] = m3dreg_point_field{ m.fields[i].name.c_str(), m.fields[i].offset, m.fields[i].datatype, m.fields[i].count };
+        m3dreg_cloud* c = nullptr;
+        const int rc = m3dreg_cloud_create_pc2(h_, m.data.data(), m.data.size(), m.width, m.height, m.point_step, m.row_step, ft.data(), ft.size(),
+                                               m.is_bigendian ? 1 : 0, 0, &c);
+        if (rc != M3DREG_OK) ROS_WARN("m3dreg_cloud_create_pc2: %s", m3dreg_last_error(h_));   // logged and swallowed, m3d_aggregator.cpp:239-241
+        return rc == M3DREG_OK ? c : nullptr;
     }
 
     void onCloud(const sensor_msgs::PointCloud2ConstPtr& msg) {
-        size_t off[3];
-        const size_t n = size_t(msg->width) * msg->height;
-        if (n == 0 || !xyzOffsets(*msg, off)) { ROS_WARN("unsupported PointCloud2 layout"); return; }
-        if (have_target_) {
+        m3dreg_cloud* cur = bucket(*msg);
+        if (!cur) return;
+        if (prev_) {
             float T[16]; m3dreg_stats st;
-            // the raw message buffer crosses the C ABI as is: no PCL conversion, no copy on the host
-            int rc = m3dreg_align(h_, msg->data.data(), n, msg->point_step, off[0], off[1], off[2], delta_, T, &st);
-            if (rc != M3DREG_OK) { ROS_WARN("m3dreg_align: %s", m3dreg_last_error(h_)); }   // logged and swallowed, m3d_aggregator.cpp:239-241
+            const int rc = m3dreg_align_clouds(h_, cur, prev_, delta_, T, &st);
+            if (rc != M3DREG_OK) { ROS_WARN("m3dreg_align_clouds: %s", m3dreg_last_error(h_)); }
             else if (st.status == M3DREG_CONVERGED || st.status == M3DREG_MAX_ITERATIONS) {
                 std::memcpy(delta_, T, sizeof(T));   // constant-velocity prior for the next sweep
                 float P[16];                          // pose <- pose * T  (column-major 4x4, Eigen::Matrix4f layout)
@@ -92,11 +93,9 @@ private:
             } else {
                 ROS_WARN("registration rejected: status %d after %d iterations", st.status, st.iterations);
             }
+            m3dreg_cloud_destroy(h_, prev_);
         }
-        // the new sweep becomes the target of the next registration (scan-to-scan odometry)
-        int rc = m3dreg_set_target_xyz(h_, msg->data.data(), n, msg->point_step, off[0], off[1], off[2]);
-        have_target_ = (rc == M3DREG_OK);
-        if (!have_target_) ROS_WARN("m3dreg_set_target_xyz: %s", m3dreg_last_error(h_));
+        prev_ = cur;   // the new sweep becomes the target of the next registration (scan-to-scan odometry)
     }
 
     void publish(const std_msgs::Header& hdr) {
@@ -117,7 +116,7 @@ private:
     tf::TransformBroadcaster br_;
     std::string odom_frame_;
     m3dreg_handle* h_ = nullptr;
-    bool have_target_;
+    m3dreg_cloud* prev_ = nullptr;
     float pose_[16], delta_[16];
 };
 
