@@ -216,6 +216,23 @@ int m3dcal_twiddle(m3dcal* c, int max_sweeps, float p_out[5], float* best_error,
  * srand(seed) (the reference seeds with time(0), :289). p_io: start on entry ((0, 0.12, 0, 0, 0) in the node, :303-308). */
 int m3dcal_anneal(m3dcal* c, unsigned int seed, float p_io[5], float* best_error, int* evaluations);
 
+/* ---- persistent map in HBM ---------------------------------------------------
+ * The dense aggregated reference of BASELINE config 5, maintained on the device: every registered scan is inserted with
+ * its pose, only points whose dedup voxel (floor(u / dedup_leaf)) is still empty are kept (lowest input index of the scan
+ * wins, kept points are appended in input order — deterministic), and m3dmap_as_cloud buckets the point buffer in place
+ * as a registration target. Nothing of the map ever crosses PCIe. No reference source exists for this step (the
+ * reference's gpu_6dslam is an empty submodule); the behaviour is specified in DESIGN.md §8 and restated by
+ * oracle/m3d_map_oracle.c. */
+typedef struct m3dmap m3dmap;
+int m3dmap_create(m3dreg_handle* h, float dedup_leaf, size_t capacity_points, m3dmap** out);
+int m3dmap_destroy(m3dmap* m);
+/* T: pose of the scan in the map frame, column-major float[16] (what m3dreg_align returned, chained) */
+int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t* n_added);
+int m3dmap_size(m3dmap* m, size_t* n_points);
+int m3dmap_as_cloud(m3dmap* m, m3dreg_cloud** out);          /* the map as a bucketed target (the map itself keeps growing) */
+int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
+int m3dmap_clear(m3dmap* m);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration of the handle is bracketed by three hipEvents on
  * its stream: before and after the dominant kernel (`k_nn_iter`: certificate check + exact 27-voxel NN search of

@@ -30,6 +30,7 @@ EXPORTS = [
     "m3dreg_cloud_create_pc2",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
+    "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
 ]
 
@@ -84,6 +85,13 @@ def lib():
     L.m3dagg_take_cloud.argtypes = [vp, C.POINTER(vp)]
     L.m3dagg_restart.argtypes = [vp]
     L.m3dagg_download.argtypes = [vp, f32p, sz, C.POINTER(sz)]
+    L.m3dmap_create.argtypes = [vp, C.c_float, sz, C.POINTER(vp)]
+    L.m3dmap_destroy.argtypes = [vp]
+    L.m3dmap_insert.argtypes = [vp, vp, f32p, C.POINTER(sz)]
+    L.m3dmap_size.argtypes = [vp, C.POINTER(sz)]
+    L.m3dmap_as_cloud.argtypes = [vp, C.POINTER(vp)]
+    L.m3dmap_download.argtypes = [vp, f32p, sz, C.POINTER(sz)]
+    L.m3dmap_clear.argtypes = [vp]
     L.m3dcal_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.m3dcal_destroy.argtypes = [vp]
     L.m3dcal_add_segment.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p]
@@ -389,6 +397,53 @@ class Aggregator:
         self._reg._check(lib().m3dagg_restart(self._a), "m3dagg_restart")
 
 
+class Map:
+    """The persistent voxel-deduplicated map in HBM: registered scans in, a bucketed target out."""
+
+    def __init__(self, reg: Registrar, dedup_leaf=0.02, capacity=1 << 22):
+        self._reg = reg
+        self._m = C.c_void_p()
+        reg._check(lib().m3dmap_create(reg._h, dedup_leaf, capacity, C.byref(self._m)), "m3dmap_create")
+
+    def close(self):
+        if self._m:
+            lib().m3dmap_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            if self._reg._h:
+                self.close()
+        except Exception:
+            pass
+
+    def insert(self, scan: Cloud, T):
+        t = T_to_colmajor16(T)
+        k = C.c_size_t()
+        self._reg._check(lib().m3dmap_insert(self._m, scan._p, _ptr(t, C.c_float), C.byref(k)), "m3dmap_insert")
+        return k.value
+
+    def __len__(self):
+        n = C.c_size_t()
+        self._reg._check(lib().m3dmap_size(self._m, C.byref(n)), "m3dmap_size")
+        return n.value
+
+    def as_cloud(self):
+        p = C.c_void_p()
+        self._reg._check(lib().m3dmap_as_cloud(self._m, C.byref(p)), "m3dmap_as_cloud")
+        return Cloud(self._reg, p, len(self))
+
+    def points(self):
+        n = len(self)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        k = C.c_size_t()
+        self._reg._check(lib().m3dmap_download(self._m, _ptr(out, C.c_float), n, C.byref(k)), "m3dmap_download")
+        return out[:n, :3]
+
+    def clear(self):
+        self._reg._check(lib().m3dmap_clear(self._m), "m3dmap_clear")
+
+
 class Calibrator:
     """Device-side mirror of the cost function and the two optimiser loops of the reference's calibration nodes
     (m3d_calibration_twiddle.cpp:199-396, m3d_calibration_sa.cpp:199-356): scan segments in, outlier counts /
@@ -450,20 +505,21 @@ class Gpu6dSlamNode:
         self.reg = Registrar(params, device)
         self.pose = np.eye(4)          # pose of the latest cloud in the frame of the first
         self.last_delta = np.eye(4)    # constant-velocity prior for the next registration
-        self._have_target = False
+        self._prev = None              # the previous sweep, already bucketed: target of the next registration
         self.history = []
 
     def on_cloud(self, msg: PointCloud2):
-        """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None)."""
-        if not self._have_target:
-            self.reg.set_target(msg)
-            self._have_target = True
+        """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None). Like the shim, the message
+        crosses the ABI with its own field table and every sweep is bucketed once (source now, target next)."""
+        cur = self.reg.cloud_pc2(msg)
+        if self._prev is None:
+            self._prev = cur
             self.history.append((self.pose.copy(), None))
             return self.pose.copy(), None
-        T, st = self.reg.align_msg(msg, self.last_delta)
+        T, st = self.reg.align(cur, self._prev, self.last_delta)
         if st.status in (abi.CONVERGED, abi.MAX_ITERATIONS):
             self.last_delta = T
             self.pose = self.pose @ T
-        self.reg.set_target(msg)
+        self._prev = cur
         self.history.append((self.pose.copy(), st))
         return self.pose.copy(), st

@@ -86,6 +86,26 @@ struct M3dCalArgs {
 };
 hipError_t m3d_launch_calibration(hipStream_t s, const M3dCalArgs& A, int n_candidates);
 
+// map.hip
+struct M3dMapArgs {
+    const float4* src;           // [n] the scan's points in input order (m3dreg_cloud::xyz)
+    int n;
+    float R[9], t[3];            // pose of the scan in the map frame, rounded to float (row-major R)
+    float inv_leaf;              // 1.0f / dedup leaf
+    unsigned long long* keys;    // [tsize] occupancy table: voxel key or all-ones
+    uint32_t* epoch;             // [tsize] insert that created the slot
+    uint32_t* owner;             // [tsize] lowest input index of the creating insert that fell into the voxel (~0 initially)
+    uint32_t tsize; int tshift;
+    uint32_t cur_epoch;
+    uint32_t* slot_of;           // [n] workspace: table slot of every point of this insert (~0 = dropped)
+    uint32_t* block_counts;      // [blocks] workspace
+    float4* out;                 // map points, pcl::PointXYZ layout
+    uint32_t* count;             // [1] points in the map
+    uint32_t capacity;
+    uint32_t* flags;             // [4]: {table full, voxel out of range, -, point buffer full}
+};
+hipError_t m3d_launch_map_insert(hipStream_t s, const M3dMapArgs& A);
+
 // icp.hip
 // variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
 //          2 = split (default): k_nn_iter (classify + search, one int32 result per query), then k_accumulate_matches,

@@ -1270,6 +1270,133 @@ int m3dcal_anneal(m3dcal* c, unsigned int seed, float p[5], float* best_error_ou
     return M3DREG_OK;
 }
 
+// ---- persistent map in HBM -----------------------------------------------------------
+}  // extern "C"
+
+struct m3dmap {
+    m3dreg_handle* h = nullptr;
+    float leaf = 0.02f;
+    size_t capacity = 0;
+    float4* d_pts = nullptr;
+    uint32_t* d_count = nullptr;          // {points}
+    uint32_t* d_flags = nullptr;          // [4]
+    unsigned long long* d_keys = nullptr; uint32_t* d_epoch = nullptr; uint32_t* d_owner = nullptr;
+    uint32_t tsize = 0; int tbits = 0;
+    uint32_t* d_slot_of = nullptr; size_t slot_cap = 0;
+    uint32_t* d_blocks = nullptr; size_t blocks_cap = 0;
+    uint32_t epoch = 0;
+    size_t n_host = 0;                    // points in the map as of the last insert
+};
+
+namespace {
+int map_clear_device(m3dmap* m) {
+    m3dreg_handle* h = m->h;
+    HIPCHK(h, hipMemsetAsync(m->d_keys, 0xFF, sizeof(unsigned long long) * m->tsize, h->stream));
+    HIPCHK(h, hipMemsetAsync(m->d_epoch, 0, sizeof(uint32_t) * m->tsize, h->stream));
+    HIPCHK(h, hipMemsetAsync(m->d_owner, 0xFF, sizeof(uint32_t) * m->tsize, h->stream));
+    HIPCHK(h, hipMemsetAsync(m->d_count, 0, sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(m->d_flags, 0, sizeof(uint32_t) * 4, h->stream));
+    m->epoch = 0; m->n_host = 0;
+    return M3DREG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int m3dmap_create(m3dreg_handle* h, float dedup_leaf, size_t capacity, m3dmap** out) {
+    if (!h || !out || !(dedup_leaf > 0.f) || !std::isfinite(dedup_leaf) || capacity == 0 || capacity > 0x0FFFFFFFull)
+        return fail(h, M3DREG_ERR_INVALID_ARG, "m3dmap_create: bad argument (at most 2^28 - 1 points)");
+    HIPCHK(h, hipSetDevice(h->device));
+    m3dmap* m = new m3dmap();
+    m->h = h; m->leaf = dedup_leaf; m->capacity = capacity;
+    m->tsize = 1024; m->tbits = 10;
+    while (m->tsize < 2u * uint32_t(capacity)) { m->tsize <<= 1; m->tbits++; }   // one voxel per kept point: load factor <= 1/2
+    hipError_t e = hipMalloc((void**)&m->d_pts, sizeof(float4) * capacity);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_count, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_flags, sizeof(uint32_t) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_keys, sizeof(unsigned long long) * m->tsize);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_epoch, sizeof(uint32_t) * m->tsize);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_owner, sizeof(uint32_t) * m->tsize);
+    if (e != hipSuccess) { m3dmap_destroy(m); return fail(h, M3DREG_ERR_HIP, "m3dmap_create", e); }
+    int rc = map_clear_device(m);
+    if (rc) { m3dmap_destroy(m); return rc; }
+    *out = m;
+    return M3DREG_OK;
+}
+
+int m3dmap_destroy(m3dmap* m) {
+    if (!m) return M3DREG_ERR_INVALID_ARG;
+    hipSetDevice(m->h->device);
+    hipStreamSynchronize(m->h->stream);
+    for (void* p : { (void*)m->d_pts, (void*)m->d_count, (void*)m->d_flags, (void*)m->d_keys, (void*)m->d_epoch, (void*)m->d_owner, (void*)m->d_slot_of, (void*)m->d_blocks }) if (p) hipFree(p);
+    delete m;
+    return M3DREG_OK;
+}
+
+int m3dmap_clear(m3dmap* m) { return m ? map_clear_device(m) : M3DREG_ERR_INVALID_ARG; }
+
+int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t* n_added) {
+    if (!m || !scan || !T) return M3DREG_ERR_INVALID_ARG;
+    m3dreg_handle* h = m->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = size_t(scan->n), nblocks = (n + 255) / 256;
+    if (n > m->slot_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m->d_slot_of) hipFree(m->d_slot_of);
+        m->d_slot_of = nullptr; m->slot_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&m->d_slot_of, sizeof(uint32_t) * (n + n / 4 + 16)));
+        m->slot_cap = n + n / 4 + 16;
+    }
+    if (nblocks > m->blocks_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (m->d_blocks) hipFree(m->d_blocks);
+        m->d_blocks = nullptr; m->blocks_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&m->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 4 + 16)));
+        m->blocks_cap = nblocks + nblocks / 4 + 16;
+    }
+    M3dMapArgs A{};
+    A.src = scan->xyz; A.n = int(n);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A.R[3 * r + c] = T[c * 4 + r]; A.t[r] = T[12 + r]; }
+    A.inv_leaf = 1.0f / m->leaf;
+    A.keys = m->d_keys; A.epoch = m->d_epoch; A.owner = m->d_owner; A.tsize = m->tsize; A.tshift = 64 - m->tbits;
+    A.cur_epoch = ++m->epoch;
+    A.slot_of = m->d_slot_of; A.block_counts = m->d_blocks; A.out = m->d_pts; A.count = m->d_count; A.capacity = uint32_t(m->capacity); A.flags = m->d_flags;
+    HIPCHK(h, hipMemsetAsync(m->d_flags, 0, sizeof(uint32_t) * 4, h->stream));
+    HIPCHK(h, m3d_launch_map_insert(h->stream, A));
+    uint32_t host[5];
+    HIPCHK(h, hipMemcpyAsync(host, m->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(host + 1, m->d_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_added) *n_added = size_t(host[0]) - m->n_host;
+    m->n_host = host[0];
+    if (host[1] || host[4]) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dmap_insert: map capacity exceeded (points beyond it were dropped)");
+    if (host[2]) return fail(h, M3DREG_ERR_GRID_TOO_LARGE, "m3dmap_insert: points beyond +-2^20 dedup voxels were dropped");
+    return M3DREG_OK;
+}
+
+int m3dmap_size(m3dmap* m, size_t* n) {
+    if (!m || !n) return M3DREG_ERR_INVALID_ARG;
+    *n = m->n_host;
+    return M3DREG_OK;
+}
+
+int m3dmap_as_cloud(m3dmap* m, m3dreg_cloud** out) {
+    if (!m || !out) return M3DREG_ERR_INVALID_ARG;
+    if (m->n_host == 0) return fail(m->h, M3DREG_ERR_EMPTY_CLOUD, "m3dmap_as_cloud: the map is empty");
+    return m3dreg_cloud_create(m->h, m->d_pts, m->n_host, 16, 0, 4, 8, 1, out);   // bucketed in place: no PCIe transfer of the map
+}
+
+int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out) {
+    if (!m || !n_out) return M3DREG_ERR_INVALID_ARG;
+    *n_out = m->n_host;
+    const size_t k = m->n_host < cap_points ? m->n_host : cap_points;
+    if (xyzw && k) {
+        HIPCHK(m->h, hipMemcpyAsync(xyzw, m->d_pts, 16 * k, hipMemcpyDeviceToHost, m->h->stream));
+        HIPCHK(m->h, hipStreamSynchronize(m->h->stream));
+    }
+    return M3DREG_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------
 int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     if (!h) return M3DREG_ERR_INVALID_ARG;

@@ -64,6 +64,16 @@ def _lib(omp=False):
         L.orc_cal_test_data_bruteforce.restype = C.c_int64
         L.orc_cal_offset_matrix.argtypes = [f32p, f32p, f32p]
         L.orc_cal_offset_matrix.restype = None
+        L.orc_map_create.argtypes = [C.c_float, C.c_size_t]
+        L.orc_map_create.restype = vp
+        L.orc_map_destroy.argtypes = [vp]
+        L.orc_map_destroy.restype = None
+        L.orc_map_size.argtypes = [vp]
+        L.orc_map_size.restype = C.c_size_t
+        L.orc_map_points.argtypes = [vp, f32p]
+        L.orc_map_points.restype = None
+        L.orc_map_insert.argtypes = [vp, f32p, C.c_size_t, f32p]
+        L.orc_map_insert.restype = C.c_size_t
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -271,3 +281,28 @@ def decode_pc2(msg):
         dt = (">" if msg.is_bigendian else "<") + ("f8" if sz == 8 else "f4")
         out[:, a] = b.view(dt).reshape(n).astype(np.float32)
     return out
+
+
+class Map:
+    """oracle/m3d_map_oracle.c: the persistent voxel-deduplicated map of SURVEY §8 row f4."""
+
+    def __init__(self, leaf, capacity):
+        self._L = _lib()
+        self._m = C.c_void_p(self._L.orc_map_create(leaf, capacity))
+
+    def __del__(self):
+        try:
+            self._L.orc_map_destroy(self._m)
+        except Exception:
+            pass
+
+    def insert(self, xyz, T):
+        a = np.ascontiguousarray(xyz, np.float32)
+        t = np.ascontiguousarray(np.asarray(T, np.float64).T.reshape(16).astype(np.float32))   # column-major float[16]
+        return int(self._L.orc_map_insert(self._m, _ptr(a, C.c_float), len(a), _ptr(t, C.c_float)))
+
+    def points(self):
+        n = int(self._L.orc_map_size(self._m))
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self._L.orc_map_points(self._m, _ptr(out, C.c_float))
+        return out[:n]

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, "include", "m3dreg.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(m3d(?:reg|agg|cal)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(m3d(?:reg|agg|cal|map)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,69 @@
+"""SURVEY.md §8 row f4 — the persistent voxel-deduplicated map in HBM.
+CPU: the oracle's insert rule on hand-made cases. GPU: m3dmap_* through the C ABI must hold exactly the oracle's points
+(same points, same order, same bits) after several inserts, and registering a scan against the device map must equal
+registering it against the oracle's map."""
+import numpy as np
+import pytest
+
+from mandala_mapping_amd import abi, synth
+
+
+def test_oracle_insert_rule(orc):
+    m = orc.Map(0.5, 100)
+    a = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [0.6, 0.1, 0.1], [np.nan, 0, 0], [-0.1, 0.1, 0.1]], np.float32)
+    assert m.insert(a, np.eye(4)) == 3                      # second point shares the first one's voxel, NaN is skipped
+    assert np.array_equal(m.points(), a[[0, 2, 4]])
+    assert m.insert(a, np.eye(4)) == 0                      # nothing new the second time
+    T = synth.make_T(np.eye(3), np.array([0.5, 0.0, 0.0]))
+    assert m.insert(a[:1], T) == 0                          # lands in the voxel of a[2]
+    assert m.insert(a[:1], synth.make_T(np.eye(3), np.array([0.0, 1.0, 0.0]))) == 1
+
+
+def test_oracle_capacity_is_respected(orc):
+    m = orc.Map(0.1, 5)
+    a = np.stack([np.arange(20) * 0.25, np.zeros(20), np.zeros(20)], axis=1).astype(np.float32)
+    assert m.insert(a, np.eye(4)) == 5 and len(m.points()) == 5
+
+
+@pytest.mark.gpu
+def test_gpu_map_equals_oracle_map_and_registers_like_it(reg, orc):
+    p = abi.Params.make(leaf=(0.4, 0.2), iterations=(8, 10), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    gm = reg.Map(R, dedup_leaf=0.05, capacity=200000)
+    om = orc.Map(0.05, 200000)
+    poses, scans = [], []
+    for k in range(4):
+        pose = synth.sensor_pose(0.4 * k, 0.1 * k, 2.0 * k)
+        xyz = synth.hdl32_scan(pose, 400, 50 + k)
+        if k == 2:
+            xyz = xyz.copy(); xyz[::97] = np.nan
+        scans.append(xyz); poses.append(pose)
+    for k in range(3):
+        c = R.cloud(scans[k])
+        added = gm.insert(c, poses[k])
+        assert added == om.insert(scans[k], poses[k])
+        assert len(gm) == len(om.points())
+    assert np.array_equal(gm.points().view(np.uint32), om.points().view(np.uint32))
+    # the fourth scan against the map: the device map bucketed in place == the oracle's map points bucketed by the oracle
+    tgt = gm.as_cloud()
+    src = R.cloud(scans[3])
+    T0 = synth.perturb(poses[3], np.random.default_rng(3), 0.8, 0.08)
+    T, st = R.align(src, tgt, T0)
+    To, sto, _ = orc.align(p, orc.Cloud(p, scans[3]), orc.Cloud(p, om.points()), T0)
+    assert np.array_equal(T, To) and (st.status, st.iterations, st.n_corr) == (sto.status, sto.iterations, sto.n_corr)
+    rot, tra = synth.pose_error(T, poses[3])
+    assert rot < 0.1 and tra < 0.02, (rot, tra)
+    # the map keeps growing after it has been used as a target, and clear() empties it
+    assert gm.insert(src, T) == om.insert(scans[3], T)
+    gm.clear()
+    assert len(gm) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_map_reports_overflow(reg):
+    R = reg.Registrar()
+    gm = reg.Map(R, dedup_leaf=0.05, capacity=1000)
+    c = R.cloud(synth.hdl32_scan(synth.sensor_pose(0, 0, 0), 200, 1))
+    with pytest.raises(abi.M3dregError):
+        gm.insert(c, np.eye(4))
+    assert len(gm) == 1000
