@@ -16,7 +16,7 @@
 #define RS_TILE (RS_THREADS * RS_ROUNDS)
 #define RS_WAVES (RS_THREADS / 64)
 
-// ---- a2: PointCloud2 payload -> SoA + exact AABB ------------------------------------------------
+// ---- a2: PointCloud2 payload -> one float4 per point (input order) + exact AABB -------------------
 __device__ __forceinline__ uint32_t ord_f32(float f) {   // order-preserving float -> uint map
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);

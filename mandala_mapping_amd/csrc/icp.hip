@@ -6,10 +6,12 @@
 // The normative arithmetic is DESIGN.md §Spec; oracle/m3d_oracle.c restates it on the CPU and the
 // parity tests compare every output bit for bit.
 //
-// Hardware mapping: source points stream coalesced from SoA arrays; candidates are 16-B gathers from
-// the cell-sorted float4 array (L2/MALL-resident); the 29 sums are int64 fixed point, reduced with
-// wave64 shuffles, then LDS across the 4 waves, then one 64-bit integer atomic per term and block —
-// associative, so the result does not depend on launch geometry. No MFMA: there is no contraction.
+// Hardware mapping: source points stream coalesced as 16-B elements of the source cloud's own sorted array (a wave's
+// queries are neighbours in space); candidates are 16-B gathers from the target's voxel-sorted float4 array
+// (L2/MALL-resident); the 29 sums are int64 fixed point, reduced with a transposed wave64 butterfly, then LDS across
+// the 4 waves, then one block partial that the pair's last block adds up — integer addition is associative, so the
+// result does not depend on launch geometry. Two launches per Gauss-Newton iteration (k_nn_iter,
+// k_accumulate_matches). No MFMA: there is no contraction.
 #include "m3d_kernels.h"
 
 // -DM3D_STATS: instrumented build (scripts/walk_stats.py): counts, per Gauss-Newton iteration of pair 0's clock, what the

@@ -491,9 +491,9 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
 }
 
 int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
-    // per-pair stride of the per-query arrays: a whole number of 256-query blocks — k_nn_light's block b owns worklist
-    // slots [256 b, 256 b + 256) of its pair, so a shorter stride lets a pair's last block spill into the next pair's
-    // first slots (a cross-pair race: found with 64 identical pairs giving different results)
+    // per-pair stride of the per-query arrays: a whole number of 256-query blocks, so that no block of one pair can ever touch
+    // slots of the next (an earlier worklist layout raced across pairs with a 64-rounded stride: found with 64 identical
+    // pairs giving different results; tests/test_gpu_parity.py::test_identical_pairs_in_one_batch_give_identical_results)
     const size_t stride = (size_t(max_n_src) + 255) & ~size_t(255);
     if (n_pairs * stride > h->match_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
