@@ -687,6 +687,132 @@ struct M3dNnArgs {
 //      other rows — so the block's latency is a handful of dependent waits however sparse its list is.
 // No global worklists, no atomics, no scan: what the earlier three-kernel chain (classify / scan / search) exchanged through
 // HBM stays inside the block.
+// Classification of ONE query (no search). mp = its result of the previous iteration.
+// Returns 0 = answered (certified, cached "none", or outside the grid: `out` is corrected when it has to change),
+// 1 = needs a seeded search, 2 = needs a full search; dseed = squared distance to the previous match (cls 1, certified);
+// certified = the previous match stands (q1 = that point, for the caller's residual).
+// (s0 = state[i] and q1 = pts[mp] are passed in: callers that handle several queries per thread load them for all of them first)
+__device__ __forceinline__ int m3d_classify_loaded(const M3dGrid& g, M3D_GLOBAL int* out, const M3D_GLOBAL long long* cache, int i, int mp, float ux,
+                                                   float uy, float uz, float dmax2, int certify, float seed_reach, const m3d_f32x4& s0,
+                                                   const float4& q1, float& dseed, bool& certified, int sit) {
+    certified = false;
+    if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; return 0; }
+    const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
+    const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
+                          (f1z >= -1.0f && f1z <= (float)g.dims[2]);
+    if (!in_range) { if (mp != -1) out[i] = -1; return 0; }
+    if (mp == M3D_NN_NONE_CACHED) {
+        const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
+        const int cls = (code == cache[i]) ? 0 : 2;
+        if (cls == 0) M3D_STAT(sit, 2);
+        return cls;
+    }
+    if (mp < 0) return 2;
+    // NN certificate: at its last real search (position u0) every candidate other than the match was at
+    // least sqrt(sec) away [inside the 27 voxels] / dout away [outside them]. The query has moved by
+    // delta since, so those are still farther than (bound - delta); if the match's CURRENT distance is
+    // below that, with margins far above float rounding, it is provably still the exact argmin.
+    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    const float mx = ux - s0.x, my = uy - s0.y, mz = uz - s0.z;
+    const float delta = sqrtf(mx * mx + my * my + mz * mz);
+    const float f0x = m3d_cell_f(s0.x, g.mn[0], g.inv_leaf), f0y = m3d_cell_f(s0.y, g.mn[1], g.inv_leaf), f0z = m3d_cell_f(s0.z, g.mn[2], g.inv_leaf);
+    const bool same_voxel = (f0x == f1x) && (f0y == f1y) && (f0z == f1z);
+    const float r0x = (s0.x - g.mn[0]) - f0x * g.leaf, r0y = (s0.y - g.mn[1]) - f0y * g.leaf, r0z = (s0.z - g.mn[2]) - f0z * g.leaf;
+    const float gm = fmaxf(fminf(fminf(fminf(r0x, g.leaf - r0x), fminf(r0y, g.leaf - r0y)), fminf(r0z, g.leaf - r0z)) - g.prune_slack, 0.f);
+    const float dout = 0.999f * g.leaf + gm;
+    const float reach = seed_reach * g.leaf;
+    const bool seedable = dd1 < reach * reach;   // closer than one voxel edge => inside the (new) neighbourhood
+    const float others = same_voxel ? sqrtf(s0.w) : fminf(sqrtf(s0.w), dout);   // same voxel => same 27 voxels => only `sec` matters
+    certified = certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
+                (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
+    dseed = dd1;
+    if (certified) M3D_STAT(sit, 1);
+    return certified ? 0 : (seedable ? 1 : 2);
+}
+// one query per thread: load what the certificate needs, then classify
+__device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_GLOBAL int* out, const M3D_GLOBAL long long* cache,
+                                            const M3D_GLOBAL m3d_f32x4* state, int i, int mp, float ux, float uy, float uz, float dmax2,
+                                            int certify, float seed_reach, float& dseed, bool& certified, float4& q1, int sit) {
+    m3d_f32x4 s0 = (m3d_f32x4){ 0.f, 0.f, 0.f, 0.f };
+    q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mp >= 0) { s0 = state[i]; q1 = m3d_ld(pts, (size_t)mp); }
+    return m3d_classify_loaded(g, out, cache, i, mp, ux, uy, uz, dmax2, certify, seed_reach, s0, q1, dseed, certified, sit);
+}
+
+// One query walked by the 8 lanes of a group (sub = lane & 7 holds one bucket of the 2x2x2): nearest row of every bucket,
+// bound exchange, the other rows, shuffle merge. Every lane of the wave must call it (act = this group has a query);
+// returns the match (>= 0), -1 or M3D_NN_NONE_CACHED on every lane of the group; sec / code for the state arrays.
+__device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float dmax2, bool act, bool seeded,
+                                              float vx, float vy, float vz, float dseed, int sub, long long& code, float& sec, int sit) {
+    M3dQuery Q;
+    M3dWalk W; m3d_walk_init(W, dmax2);
+    bool ok = false, found = false;
+    code = 0;
+    uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
+    int vx0 = 0, vy0 = 0, vz0 = 0;
+    if (act) {
+        ok = m3d_query_setup(g, vx, vy, vz, Q);   // finite by classification
+        if (ok) {
+            code = m3d_voxel_code(Q);
+            if (seeded) m3d_walk_seed_dd(Q, dseed, W);   // every lane of the group starts from the seed's bound
+            if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
+                const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+                const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
+                const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
+                if (sub < nb) {   // this lane's bucket
+                    const int shy = nbx, shz = nbx + nby;
+                    const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
+                    const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+                    uint32_t slot = m3d_hash_slot(key, g.hshift);
+                    lo = m3d_ld(tab, 2 * (size_t)slot); hi = m3d_ld(tab, 2 * (size_t)slot + 1);   // both halves in one round trip
+                    if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
+                        do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
+                        hi = m3d_ld(tab, 2 * (size_t)slot + 1);
+                    }
+                    if (lo.x == key) {
+                        found = true;
+                        vx0 = 2 * (b0x + ox); vy0 = 2 * (b0y + oy); vz0 = 2 * (b0z + oz);
+                    }
+                }
+            }
+        }
+    }
+    // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
+    if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
+    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
+    {
+        float bnd = W.bound;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
+        W.bound = bnd;
+    }
+    // ... and the other rows are mostly discarded by their box distance
+    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
+    // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
+    // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
+    unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned long long ok2 = __shfl_xor(bkey, o);
+        const int ob = __shfl_xor(best, o);
+        const uint32_t os = (uint32_t)__shfl_xor((int)secb, o);
+        const bool oa = __shfl_xor((int)any_point, o) != 0;
+        const bool better = ok2 < bkey;
+        secb = min(min(secb, os), (uint32_t)((better ? bkey : ok2) >> 32));
+        bkey = better ? ok2 : bkey;
+        best = better ? ob : best;
+        any_point = any_point || oa;
+    }
+    sec = __uint_as_float(secb);
+    int m = -1;
+    if (ok) {
+        if (best >= 0 && m3d_key_d2(bkey) <= dmax2) m = best;
+        else m = (seeded || any_point) ? -1 : M3D_NN_NONE_CACHED;
+    }
+    return m;
+}
+
 #ifdef M3D_NN_WAVES   // A/B builds: force the occupancy of the search kernel (make CXXFLAGS+=-DM3D_NN_WAVES=6)
 #define M3D_NN_OCC __attribute__((amdgpu_waves_per_eu(M3D_NN_WAVES, M3D_NN_WAVES)))
 #else
@@ -718,43 +844,8 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i] = -1;
         } else {
             mp = out[i];
-            if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; }
-            else {
-                const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
-                const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
-                                      (f1z >= -1.0f && f1z <= (float)g.dims[2]);
-                if (!in_range) { if (mp != -1) out[i] = -1; }
-                else if (mp == M3D_NN_NONE_CACHED) {
-                    const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
-                    cls = (code == cache[i]) ? 0 : 2;
-                    if (cls == 0) M3D_STAT(sit, 2);
-                } else if (mp < 0) cls = 2;
-                else {
-                    // NN certificate: at its last real search (position u0) every candidate other than the match was at
-                    // least sqrt(sec) away [inside the 27 voxels] / dout away [outside them]. The query has moved by
-                    // delta since, so those are still farther than (bound - delta); if the match's CURRENT distance is
-                    // below that, with margins far above float rounding, it is provably still the exact argmin.
-                    const m3d_f32x4 s0 = state[i];
-                    const float4 q1 = m3d_ld(pts, (size_t)mp);
-                    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
-                    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                    const float mx = ux - s0.x, my = uy - s0.y, mz = uz - s0.z;
-                    const float delta = sqrtf(mx * mx + my * my + mz * mz);
-                    const float f0x = m3d_cell_f(s0.x, g.mn[0], g.inv_leaf), f0y = m3d_cell_f(s0.y, g.mn[1], g.inv_leaf), f0z = m3d_cell_f(s0.z, g.mn[2], g.inv_leaf);
-                    const bool same_voxel = (f0x == f1x) && (f0y == f1y) && (f0z == f1z);
-                    const float r0x = (s0.x - g.mn[0]) - f0x * g.leaf, r0y = (s0.y - g.mn[1]) - f0y * g.leaf, r0z = (s0.z - g.mn[2]) - f0z * g.leaf;
-                    const float gm = fmaxf(fminf(fminf(fminf(r0x, g.leaf - r0x), fminf(r0y, g.leaf - r0y)), fminf(r0z, g.leaf - r0z)) - g.prune_slack, 0.f);
-                    const float dout = 0.999f * g.leaf + gm;
-                    const float reach = A.seed_reach * g.leaf;
-                    const bool seedable = dd1 < reach * reach;   // closer than one voxel edge => inside the (new) neighbourhood
-                    const float others = same_voxel ? sqrtf(s0.w) : fminf(sqrtf(s0.w), dout);   // same voxel => same 27 voxels => only `sec` matters
-                    const bool certified = A.certify && (same_voxel || seedable) && (dd1 <= dmax2) &&
-                                           (others * 0.9999f > sqrtf(dd1) * 1.0001f + delta * 1.0001f + 1.0e-6f * g.leaf);
-                    cls = certified ? 0 : (seedable ? 1 : 2);
-                    dseed = dd1;
-                    if (certified) M3D_STAT(sit, 1);
-                }
-            }
+            bool certified; float4 q1;
+            cls = m3d_classify(g, pts, out, cache, state, i, mp, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, sit);
         }
     }
     // how many queries of this block need a search?
@@ -788,81 +879,16 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     }
     __syncthreads();
     const int sub = tid & 7;
-    for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles below need every lane
+    for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
         const int q = base + (tid >> 3);
         const bool act = q < nW;
         const int e = act ? s_list[q] : 0;
-        const bool seeded = (e & 256) != 0;
         const int qi = blk * 256 + (e & 255);
-        float vx = 0.f, vy = 0.f, vz = 0.f;
-        M3dQuery Q;
-        M3dWalk W; m3d_walk_init(W, dmax2);
-        bool ok = false, found = false;
-        long long code = 0;
-        uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
-        int vx0 = 0, vy0 = 0, vz0 = 0;
-        if (act) {
-            vx = s_wu[0][q]; vy = s_wu[1][q]; vz = s_wu[2][q];
-            ok = m3d_query_setup(g, vx, vy, vz, Q);   // finite by classification
-            if (ok) {
-                code = m3d_voxel_code(Q);
-                if (seeded) m3d_walk_seed_dd(Q, s_wd[q], W);   // every lane of the group starts from the seed's bound
-                if (Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
-                    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-                    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
-                    const int nb = (nbx + 1) * (nby + 1) * (nbz + 1);
-                    if (sub < nb) {   // this lane's bucket
-                        const int shy = nbx, shz = nbx + nby;
-                        const int ox = sub & nbx, oy = (sub >> shy) & nby, oz = (sub >> shz) & nbz;
-                        const uint32_t key = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
-                        uint32_t slot = m3d_hash_slot(key, g.hshift);
-                        lo = m3d_ld(tab, 2 * (size_t)slot); hi = m3d_ld(tab, 2 * (size_t)slot + 1);   // both halves in one round trip
-                        if (lo.x != key && lo.x != M3D_INVALID_KEY) {   // rare: linear probing past a collision
-                            do { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); } while (lo.x != key && lo.x != M3D_INVALID_KEY);
-                            hi = m3d_ld(tab, 2 * (size_t)slot + 1);
-                        }
-                        if (lo.x == key) {
-                            found = true;
-                            vx0 = 2 * (b0x + ox); vy0 = 2 * (b0y + oy); vz0 = 2 * (b0z + oz);
-                        }
-                    }
-                }
-            }
-        }
-        // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
+        const float vx = act ? s_wu[0][q] : 0.f, vy = act ? s_wu[1][q] : 0.f, vz = act ? s_wu[2][q] : 0.f;
+        long long code; float sec;
         if (tid == 0) M3D_STAT(sit, 15);
-        if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
-        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
-        {
-            float bnd = W.bound;
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
-            W.bound = bnd;
-        }
-        // ... and the other rows are mostly discarded by their box distance
-        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
-        // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
-        // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
-        unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            const unsigned long long ok2 = __shfl_xor(bkey, o);
-            const int ob = __shfl_xor(best, o);
-            const uint32_t os = (uint32_t)__shfl_xor((int)secb, o);
-            const bool oa = __shfl_xor((int)any_point, o) != 0;
-            const bool better = ok2 < bkey;
-            secb = min(min(secb, os), (uint32_t)((better ? bkey : ok2) >> 32));
-            bkey = better ? ok2 : bkey;
-            best = better ? ob : best;
-            any_point = any_point || oa;
-        }
-        const float sec = __uint_as_float(secb);
+        const int m = m3d_coop_query(g, tab, pts, bigcum, dmax2, act, (e & 256) != 0, vx, vy, vz, act ? s_wd[q] : 0.f, sub, code, sec, sit);
         if (act && sub == 0) {
-            int m = -1;
-            if (ok) {
-                if (best >= 0 && m3d_key_d2(bkey) <= dmax2) m = best;
-                else m = (seeded || any_point) ? -1 : M3D_NN_NONE_CACHED;
-            }
             out[qi] = m;
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
             if (m >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
@@ -1013,62 +1039,11 @@ __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ j
 }
 
 __host__ __device__ inline int m3d_ticket_group(int bpp);
-template <int METRIC>
-__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
-                                                                    const int* __restrict__ match, int match_stride,
-                                                                    long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
-    int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk);
-    const M3dJob& J = jobs[pair];
-    M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
-
-    if (st->done || (!first_of_level && st->level_done)) {
-        // a finished pair still reports to the batch-wide progress word (one thread per pair)
-        if (fuse_solve && blk == 0 && threadIdx.x == 0) m3d_report_progress(jobs, n_pairs, false, seq, progress);
-        return;
-    }
-    float R[9], tt[3];
-    m3d_load_pose(st, R, tt);
-    const M3dLevelDev& L = J.tgt;
-    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
-    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
-    constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
-    const int n = J.n_src;
-    const int* in = match + (size_t)pair * match_stride;
-    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
-    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
-    // dependent gathers (match -> point, normal), so its speed is the number of them in flight
-    constexpr int NB = 4;
-    const int stride = bpp * ICP_THREADS;
-    for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
-        int m[NB]; float4 p[NB], q[NB], nq[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
-#pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const size_t mm = (size_t)max(m[k], 0);
-            q[k] = m3d_ld(pts, mm);
-            nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
-        }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            if (m[k] < 0) continue;
-            const float ux = fmaf(R[0], p[k].x, fmaf(R[1], p[k].y, fmaf(R[2], p[k].z, tt[0])));
-            const float uy = fmaf(R[3], p[k].x, fmaf(R[4], p[k].y, fmaf(R[5], p[k].z, tt[1])));
-            const float uz = fmaf(R[6], p[k].x, fmaf(R[7], p[k].y, fmaf(R[8], p[k].z, tt[2])));
-            const float ex = ux - q[k].x, ey = uy - q[k].y, ez = uz - q[k].z;
-            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
-            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
-        }
-    }
-    block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
-    if (!fuse_solve || !partials) return;
+// The end of an iteration for one pair, reached by every thread of every block of the pair's reduction: the LAST block
+// to arrive adds up the pair's block partials, solves the 6x6 system and updates the pose (a8).
+__device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, const M3dJob& J, M3dPairState* st, int n_pairs, int pair, int blk, int bpp,
+                                              int first_of_level, const long long* __restrict__ partials, unsigned int* __restrict__ tickets,
+                                              unsigned int seq, unsigned long long* __restrict__ progress) {
     // ---- a8 in the same launch: the LAST block of the pair to finish adds up the pair's block partials and solves.
     // (A separate solve kernel cost its ~10 us plus a dependent-launch gap of ~5 us in every iteration.)
     // The partials are stored and loaded with agent-scope (write-through / coherent) accesses and the writers wait for
@@ -1127,6 +1102,65 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     if (threadIdx.x != 0) return;
     m3d_solve_pair(J, first_of_level, s_part[0]);
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
+                                                                    const int* __restrict__ match, int match_stride,
+                                                                    long long* __restrict__ partials, unsigned int* __restrict__ tickets,
+                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk);
+    const M3dJob& J = jobs[pair];
+    M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
+
+    if (st->done || (!first_of_level && st->level_done)) {
+        // a finished pair still reports to the batch-wide progress word (one thread per pair)
+        if (fuse_solve && blk == 0 && threadIdx.x == 0) m3d_report_progress(jobs, n_pairs, false, seq, progress);
+        return;
+    }
+    float R[9], tt[3];
+    m3d_load_pose(st, R, tt);
+    const M3dLevelDev& L = J.tgt;
+    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
+    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
+    constexpr int NACC = (METRIC == 1) ? 29 : 17;
+    long long acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    const int n = J.n_src;
+    const int* in = match + (size_t)pair * match_stride;
+    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
+    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
+    // dependent gathers (match -> point, normal), so its speed is the number of them in flight
+    constexpr int NB = 4;
+    const int stride = bpp * ICP_THREADS;
+    for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
+        int m[NB]; float4 p[NB], q[NB], nq[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const size_t mm = (size_t)max(m[k], 0);
+            q[k] = m3d_ld(pts, mm);
+            nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (m[k] < 0) continue;
+            const float ux = fmaf(R[0], p[k].x, fmaf(R[1], p[k].y, fmaf(R[2], p[k].z, tt[0])));
+            const float uy = fmaf(R[3], p[k].x, fmaf(R[4], p[k].y, fmaf(R[5], p[k].z, tt[1])));
+            const float uz = fmaf(R[6], p[k].x, fmaf(R[7], p[k].y, fmaf(R[8], p[k].z, tt[2])));
+            const float ex = ux - q[k].x, ey = uy - q[k].y, ez = uz - q[k].z;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));   // same chain as the search: same bits
+            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
+        }
+    }
+    block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
+    if (!fuse_solve || !partials) return;
+    m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, first_of_level, partials, tickets, seq, progress);
 }
 
 
