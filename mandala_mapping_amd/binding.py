@@ -259,11 +259,11 @@ class Registrar:
         """arrays: list of float32 [n,3] arrays / PointCloud2 messages -> list of Clouds, bucketed in ONE batch."""
         msgs = [to_little_endian(encode_xyz(a) if isinstance(a, np.ndarray) else a) for a in arrays]
         k = len(msgs)
-        bufs = [(C.c_char * len(m.data)).from_buffer_copy(m.data) for m in msgs]
+        bufs = [np.frombuffer(m.data, np.uint8) for m in msgs]   # views of the messages' own buffers: the payload is not copied on the host
         descs = (abi.CloudDesc * k)()
         for i, m in enumerate(msgs):
             ox, oy, oz = m.xyz_offsets()
-            descs[i].data, descs[i].n, descs[i].point_step = C.addressof(bufs[i]), m.n, m.point_step
+            descs[i].data, descs[i].n, descs[i].point_step = bufs[i].ctypes.data, m.n, m.point_step
             descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = ox, oy, oz, 0
         out = (C.c_void_p * k)()
         self._check(lib().m3dreg_cloud_create_batch(self._h, descs, k, out), "cloud_create_batch")
