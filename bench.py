@@ -11,8 +11,9 @@ over RCCL (one all_gather per step — the only collective; pairs never exchange
 Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (k_nn_iter: source transform, NN-certificate
 check and exact 27-voxel nearest-neighbour search of every query of every pair of the batch) by its algorithmic
 bytes (NN part: 12 N + 12 M + 8 C_occ per pair) over its average launch duration, taken from
-hipEvents the library records on its stream around launches of that kernel inside the timed region (every third
-launch: an event record is a barrier packet, bracketing all of them cost 4 % of the throughput being measured). `cpu_baseline` is the CPU oracle (OpenMP build)
+hipEvents the library records on its stream around launches of that kernel inside the timed region (every seventh
+launch: an event record is a barrier packet that costs ~6 us on the queue, bracketing all of them cost 4 % of the
+throughput being measured). `cpu_baseline` is the CPU oracle (OpenMP build)
 timed on a bounded sample of the same workload on this host's cores.
 """
 import argparse
@@ -45,6 +46,7 @@ def parse():
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
     ap.add_argument("--inflight", type=int, default=2,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
+    ap.add_argument("--event-every", type=int, default=7, help="bracket every n-th iteration with hipEvents (n should not divide --iters)")
     ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
     ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
@@ -166,7 +168,7 @@ def main():
         torch.cuda.synchronize()
 
     for r in regs:
-        r.profile_enable(not args.no_events, every=3)   # 3 does not divide the 20 iterations of a step: every iteration index is sampled
+        r.profile_enable(not args.no_events, every=args.event_every)   # 7 does not divide the 20 iterations of a step: every iteration index gets sampled
         r.profile_read(0, reset=True)
         r.profile_read(1, reset=True)
     barrier()
