@@ -459,19 +459,37 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const bool take = (lane - o) >= seg_start;
+        if (__ballot(take) == 0ull) break;   // wave-uniform: every run of this wave is already complete (runs average ~6 points)
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const long long t = __shfl_up(v[i], o);
             if (take) v[i] += t;
         }
     }
+    // does the wave's first run continue one that began in the previous wave / its last run continue into the next wave?
+    const int j0 = j - lane;   // sorted position of lane 0
+    uint32_t kb = M3D_INVALID_KEY, ka = M3D_INVALID_KEY;
+    if (lane == 0 && ok && j0 > 0) kb = B.skey_out[j0 - 1];
+    if (lane == 63 && ok && j + 1 < g.n_valid) ka = B.skey_out[j + 1];
+    const bool first_continues = __shfl((int)(lane == 0 && ok && kb == key), 0) != 0;
+    const bool last_continues = __shfl((int)(lane == 63 && ok && ka == key), 63) != 0;
     if (ok && tail) {
-        // first sorted position of this voxel (the moments of a voxel live at that index)
-        const float4 pj = L.pts[j];
-        const int hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
-                                           (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
+        // the moments of a voxel live at its first sorted position
+        const bool began_here = !(seg_start == 0 && first_continues);
+        const bool whole = began_here && !(lane == 63 && last_continues);
+        int hp = j0 + seg_start;
+        if (!began_here) {
+            const float4 pj = L.pts[j];
+            hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
+                                     (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
+        }
+        if (whole) {   // the run lies inside this wave (nearly all do): plain stores into the zeroed array, no probe, no atomics
 #pragma unroll
-        for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&B.mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
+            for (int i = 0; i < 10; i++) B.mom[10 * (size_t)hp + i] = v[i];
+        } else {       // a run cut by a wave boundary: its pieces are added with 64-bit integer atomics
+#pragma unroll
+            for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&B.mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
+        }
     }
 }
 
