@@ -108,9 +108,10 @@ __device__ __forceinline__ void sort_buffers(const M3dBuild& B, int pass, const 
                                              uint32_t*& vout) {
     if (pass & 1) { kin = B.kb; vin = B.vb; kout = B.ka; vout = B.va; }
     else { kin = B.ka; vin = B.va; kout = B.kb; vout = B.vb; }
+    if (pass == B.sort_passes - 1) { kout = B.skey_out; vout = B.perm_out; }   // the last pass scatters straight into the cloud's own arrays
 }
-__device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return (B.sort_passes & 1) ? B.kb : B.ka; }
-__device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { return (B.sort_passes & 1) ? B.vb : B.va; }
+__device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return B.skey_out; }
+__device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { return B.perm_out; }
 // the ping-pong key buffer that does NOT hold the sorted keys is free after the last pass: the normal grid keeps the list
 // of its voxel heads (first sorted position of every occupied voxel) there
 __device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return (B.sort_passes & 1) ? B.ka : B.kb; }
@@ -318,7 +319,6 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
         if (vhead) voxel_head_list(B)[off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
     }
     if (!inb) return;
-    B.skey_out[j] = k; B.perm_out[j] = oi;             // kept for the introspection API
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
     float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
