@@ -46,6 +46,9 @@ def parse():
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
     ap.add_argument("--inflight", type=int, default=2,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo + --share-gpu = rehearsal of the N > 1 flow on a single-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--event-every", type=int, default=7, help="bracket every n-th iteration with hipEvents (n should not divide --iters)")
     ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
     ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
@@ -65,11 +68,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else None   # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B, K, W = args.pairs_per_gpu, args.steps, args.warmup
     # fixed iteration count: eps = 0 never triggers, so every launch of the dominant kernel does full work
@@ -112,10 +121,17 @@ def main():
         return [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
 
     def finish(T, st, clouds):
-        if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI)
-            allT, allst = sharding.gather_results([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, dev)
-            last["all"] = (allT, allst)
+        if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI).
+            # It is enqueued here and read one step later (or at the end of the timed region): the ranks exchange every
+            # step's results without falling into lock-step at every step.
+            ticket = sharding.gather_results_start([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, cdev)
+            drain_gather()
+            last["pending_gather"] = ticket
         last["T"], last["st"], last["clouds"] = T, st, clouds
+
+    def drain_gather():
+        if last.get("pending_gather") is not None:
+            last["all"] = sharding.gather_results_finish(last.pop("pending_gather"))
 
     host_log = []
 
@@ -143,6 +159,7 @@ def main():
             finish(T, st, clouds)
             if nxt < k:
                 pending.append((nxt, enqueue(nxt))); nxt += 1
+        drain_gather()   # the last step's poses are on every rank before the timed region ends
         return clouds
 
     def step():
@@ -188,7 +205,7 @@ def main():
         r.profile_enable(False)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -34,6 +34,39 @@ def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = Non
     return [sorted(x) for x in out]
 
 
+def gather_results_start(local_idx: Sequence[int], local_T: np.ndarray, local_status: Sequence[int], n_total: int, dist, device=None):
+    """Enqueue the all-gather of this rank's poses / status words and return a ticket for gather_results_finish.
+    ONE host->device copy and ONE collective; nothing here waits for the other ranks, so a caller that pipelines its
+    batches (bench.py) is not forced into lock-step with the slowest rank at every batch."""
+    import torch
+    world = dist.get_world_size()
+    cap = n_total   # upper bound on a shard; a record is 144 bytes, so 64 pairs x 8 ranks is ~74 KB in total
+    # the record block is assembled on the host (element-wise writes into a device tensor cost a launch each)
+    rec_h = np.full((cap, 18), -1.0, dtype=np.float64)
+    for j, i in enumerate(local_idx):
+        rec_h[j, 0] = float(i)
+        rec_h[j, 1] = float(local_status[j])
+        rec_h[j, 2:] = np.asarray(local_T[j], np.float64).reshape(16)
+    rec = torch.from_numpy(rec_h).to(device) if device is not None else torch.from_numpy(rec_h)
+    out = torch.empty((world * cap, 18), dtype=torch.float64, device=rec.device)
+    work = dist.all_gather_into_tensor(out, rec, async_op=True)
+    return (work, out, rec, n_total)
+
+
+def gather_results_finish(ticket) -> Tuple[np.ndarray, np.ndarray]:
+    """Wait for the collective of gather_results_start and unpack it into pair order: ([n_total,4,4], [n_total])."""
+    work, out, _rec, n_total = ticket
+    work.wait()
+    a = out.cpu().numpy()   # ONE device->host copy
+    T = np.zeros((n_total, 4, 4))
+    st = np.full(n_total, -1, np.int64)
+    rows = a[a[:, 0] >= 0]
+    idx = rows[:, 0].astype(np.int64)
+    T[idx] = rows[:, 2:].reshape(-1, 4, 4)
+    st[idx] = rows[:, 1].astype(np.int64)
+    return T, st
+
+
 def gather_results(local_idx: Sequence[int], local_T: np.ndarray, local_status: Sequence[int], n_total: int,
                    dist=None, device=None) -> Tuple[np.ndarray, np.ndarray]:
     """All-gather the poses ([k,4,4]) and status words of every rank into pair order.
@@ -41,7 +74,6 @@ def gather_results(local_idx: Sequence[int], local_T: np.ndarray, local_status: 
     Each rank contributes a fixed-size record block (padded to the largest shard) of
     [pair index, status, 16 pose floats]; one `all_gather` moves everything. Returns ([n_total,4,4], [n_total]).
     """
-    import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         T = np.zeros((n_total, 4, 4))
         st = np.full(n_total, -1, np.int64)
@@ -49,25 +81,7 @@ def gather_results(local_idx: Sequence[int], local_T: np.ndarray, local_status: 
             T[i] = local_T[j]
             st[i] = local_status[j]
         return T, st
-    world = dist.get_world_size()
-    cap = n_total   # upper bound on a shard; a record is 144 bytes, so 64 pairs x 8 ranks is ~74 KB in total
-    rec = torch.full((cap, 18), -1.0, dtype=torch.float64, device=device)
-    for j, i in enumerate(local_idx):
-        rec[j, 0] = float(i)
-        rec[j, 1] = float(local_status[j])
-        rec[j, 2:] = torch.from_numpy(np.asarray(local_T[j], np.float64).reshape(16)).to(rec.device)
-    bufs = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(bufs, rec)
-    T = np.zeros((n_total, 4, 4))
-    st = np.full(n_total, -1, np.int64)
-    for b in bufs:
-        a = b.cpu().numpy()
-        for row in a:
-            if row[0] >= 0:
-                i = int(row[0])
-                T[i] = row[2:].reshape(4, 4)
-                st[i] = int(row[1])
-    return T, st
+    return gather_results_finish(gather_results_start(local_idx, local_T, local_status, n_total, dist, device))
 
 
 def register_sharded(pairs: Sequence, costs: Sequence[float], register_local: Callable[[List[int]], Tuple[np.ndarray, List[int]]],

@@ -59,6 +59,13 @@ def _worker(rank, world, port, q):
 
     T, st = sharding.register_sharded(pairs, costs, local, dist)
     mine = sharding.lpt_assign(costs, world)[rank]
+    # the pipelined form bench.py uses: two batches' gathers in flight, read one batch later
+    t1 = sharding.gather_results_start([rank], np.eye(4)[None] * (rank + 1), [rank], world, dist)
+    t2 = sharding.gather_results_start([rank], np.eye(4)[None] * (rank + 10), [rank + 5], world, dist)
+    Ta, sa = sharding.gather_results_finish(t1)
+    Tb, sb = sharding.gather_results_finish(t2)
+    assert [Ta[r, 0, 0] for r in range(world)] == [r + 1 for r in range(world)] and list(sa) == list(range(world))
+    assert [Tb[r, 0, 0] for r in range(world)] == [r + 10 for r in range(world)] and list(sb) == [r + 5 for r in range(world)]
     q.put((rank, T, st, mine))
     dist.barrier()
     dist.destroy_process_group()
