@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
     if (t == 0) {
         uint32_t hmask; int hshift;
         m3d_table_size(carryB, B.hcap, hmask, hshift);
-        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV;
+        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u;   // every word this pipeline reads is written here: no memset needed
         B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
     }
 }

@@ -1265,6 +1265,21 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     }
 }
 
+// Table geometry of every job's target level, straight from the bucketing pipeline's device-side words: the host enqueues a
+// registration right behind the bucketing of its clouds without waiting to read them back.
+__global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pairs, int n_levels) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs * n_levels) return;
+    M3dJob& J = jobs[(size_t)(t / n_pairs) * cap_pairs + (t % n_pairs)];
+    J.tgt.g.hmask = J.tgt.dyn[1];
+    J.tgt.g.hshift = (int32_t)J.tgt.dyn[2];
+}
+hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels) {
+    hipLaunchKernelGGL(k_patch_jobs, dim3((n_pairs * n_levels + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, cap_pairs, n_levels);
+    M3D_DBG(s, "k_patch_jobs");
+    return hipGetLastError();
+}
+
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
                                       const M3dNnWork& w) {
     launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, 1, variant, w);

@@ -49,6 +49,8 @@ struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* nrm_in;      // the same normals by INPUT index (fused kernel variants 0/1 only)
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
+    const uint32_t* dyn;      // [8] in the cloud's block: {occupied voxels, hmask, hshift, occupied buckets, big buckets, voxel heads}: derived on the
+                              // device by the bucketing pipeline; k_patch_jobs copies hmask / hshift into g (the host never waits for them)
     M3dGrid g;
 };
 

@@ -128,6 +128,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
                                     int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
                                     hipEvent_t k1);
+hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels);
 int m3d_ticket_words(int n_pairs, int max_n_src);
 int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,

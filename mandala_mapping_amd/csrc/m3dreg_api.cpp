@@ -33,7 +33,8 @@ struct DevLevel {
     uint32_t* skey = nullptr;
     uint32_t* perm = nullptr;
     float4* nrm = nullptr;         // normals in this level's sorted order (point-to-plane)
-    uint32_t n_cells_host = 0;
+    uint32_t n_cells_host = 0;     // valid once the cloud's meta data was fetched (fetch_meta)
+    uint32_t* dyn = nullptr;       // [8] device words of the bucketing pipeline (occupied voxels, table geometry ...), in the cloud's block
 };
 
 struct Block { void* p = nullptr; size_t bytes = 0; };
@@ -52,6 +53,7 @@ struct Carver {
 
 }  // namespace
 
+struct BatchReady;
 struct m3dreg_cloud {
     int32_t n = 0;
     int32_t n_valid = 0;
@@ -63,7 +65,11 @@ struct m3dreg_cloud {
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
     Block block;                   // ONE device allocation holds every array of the cloud
+    m3dreg_handle* owner = nullptr;    // the handle whose stream bucketed it
+    struct BatchReady* ready = nullptr;   // event recorded behind the bucketing of the batch this cloud came from (shared, ref-counted)
+    bool meta_ready = false;           // table geometry / voxel counts read back to the host (lazily: grid_info, export, debug_nn)
 };
+struct BatchReady { hipEvent_t ev = nullptr; int refs = 0; };
 
 struct m3dreg_handle {
     int device = 0;
@@ -257,6 +263,7 @@ int ensure_ws(m3dreg_handle* h, size_t dev_bytes, size_t host_bytes) {
 
 void free_cloud(m3dreg_handle* h, m3dreg_cloud* c) {
     if (!c) return;
+    if (c->ready && --c->ready->refs == 0) { hipEventDestroy(c->ready->ev); delete c->ready; }
     pool_put(h, c->block);
     delete c;
 }
@@ -284,6 +291,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
         L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
+        L.dyn = k.take<uint32_t>(8);
     }
     return (k.off + 255) & ~size_t(255);
 }
@@ -361,7 +369,6 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     M3dDecode* h_dec = hw.take<M3dDecode>(k);
     M3dBuild* h_builds = hw.take<M3dBuild>(n_builds);
     uint32_t* h_aabb = hw.take<uint32_t>(8 * k);
-    uint32_t* h_dyn = hw.take<uint32_t>(8 * n_builds);
 #define B_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
     B_HIP(hipMemsetAsync(zero_lo, 0, size_t(zero_hi - zero_lo), h->stream));
     // ---- a2: stage + decode ----------------------------------------------------------------------------------
@@ -420,7 +427,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.xyz = c->xyz; B.grid = L.grid;
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
             B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
-            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = W.dyn;
+            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's words live in its cloud (read by the jobs later)
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
             B.nrm_in = c->nrm_in;
             B.nrm_sorted = is_ng ? nullptr : L.nrm;
@@ -429,25 +436,41 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
     B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(n_builds), int(max_n), max_passes, want_normals, P.plane_ratio, P.normal_min_pts,
                                   P.normal_min_spread));
-    B_HIP(hipMemcpyAsync(h_dyn, bw[0].dyn, sizeof(uint32_t) * 8 * n_builds, hipMemcpyDeviceToHost, h->stream));
-    B_HIP(hipStreamSynchronize(h->stream));   // sync 2 of 2: device-derived table geometry of every level
+    // NO second synchronisation: the table geometry stays on the device (k_patch_jobs hands it to the registrations, fetch_meta
+    // reads it back when somebody asks). One event behind the pipeline lets OTHER handles order their streams after it.
+    BatchReady* br = new BatchReady();
+    if (hipEventCreateWithFlags(&br->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(br->ev, h->stream) != hipSuccess) {
+        if (br->ev) hipEventDestroy(br->ev);
+        delete br; cleanup(); return fail(h, M3DREG_ERR_HIP, "hipEventRecord(batch ready)");
+    }
 #undef B_HIP
     for (size_t i = 0; i < k; i++) {
-        for (int l = 0; l < P.n_levels; l++) {
-            const uint32_t* dyn = h_dyn + 8 * (i * size_t(grids_per_cloud) + size_t(l + (want_normals ? 1 : 0)));
-            DevLevel& L = cl[i]->lv[l];
-            L.n_cells_host = dyn[0];
-            L.grid.hmask = dyn[1];
-            L.grid.hshift = int32_t(dyn[2]);
-        }
+        cl[i]->owner = h; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false;
         out[i] = cl[i];
     }
     return M3DREG_OK;
 }
 
+// table geometry / voxel counts of a cloud on the host (waits for its bucketing)
+int fetch_meta(m3dreg_handle* h, m3dreg_cloud* c) {
+    if (c->meta_ready) return M3DREG_OK;
+    m3dreg_handle* o = c->owner ? c->owner : h;
+    HIPCHK(h, hipSetDevice(o->device));
+    HIPCHK(h, hipStreamSynchronize(o->stream));
+    for (int l = 0; l < c->n_levels; l++) {
+        uint32_t dyn[8];
+        HIPCHK(h, hipMemcpy(dyn, c->lv[l].dyn, sizeof(dyn), hipMemcpyDeviceToHost));
+        c->lv[l].n_cells_host = dyn[0];
+        c->lv[l].grid.hmask = dyn[1];
+        c->lv[l].grid.hshift = int32_t(dyn[2]);
+    }
+    c->meta_ready = true;
+    return M3DREG_OK;
+}
+
 M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
     M3dLevelDev d{};
-    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.g = L.grid;
+    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.dyn = L.dyn; d.g = L.grid;
     return d;
 }
 
@@ -558,6 +581,8 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         int rc = check_levels(h, t);
         if (rc) return rc;
         if (P.metric == M3DREG_POINT_TO_PLANE && !t->has_normals) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "target cloud has no normals");
+        for (const m3dreg_cloud* c : { s, t })   // a cloud bucketed on ANOTHER handle's stream: this stream waits for that pipeline
+            if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
         if (s->n_valid > max_n_src) max_n_src = s->n_valid;
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
@@ -772,6 +797,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     if ((rc = ensure_match(h, n_pairs, max_n_src))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * size_t(P.n_levels), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
     const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
     bool prev_sampled = false;
     for (int l = 0; l < P.n_levels; l++) {
@@ -1354,6 +1380,7 @@ int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t
         HIPCHK(h, hipMalloc((void**)&m->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 4 + 16)));
         m->blocks_cap = nblocks + nblocks / 4 + 16;
     }
+    if (scan->owner && scan->owner != h && scan->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, scan->ready->ev, 0));
     M3dMapArgs A{};
     A.src = scan->xyz; A.n = int(n);
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A.R[3 * r + c] = T[c * 4 + r]; A.t[r] = T[12 + r]; }
@@ -1420,6 +1447,7 @@ int m3dreg_cloud_levels(const m3dreg_cloud* c) { return c ? c->n_levels : M3DREG
 
 int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m3dreg_grid_info* out) {
     if (!h || !c || !out || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "grid_info: bad argument");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
     const DevLevel& L = c->lv[level];
     memset(out, 0, sizeof(*out));
     out->n = c->n; out->n_valid = c->n_valid;
@@ -1435,6 +1463,7 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
                         float* sorted_xyz, float* normals) {
     if (!h || !c || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: bad argument");
     if (normals && !c->has_normals) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: cloud has no normals");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
     const DevLevel& L = c->lv[level];
     const size_t n = size_t(c->n);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1461,6 +1490,7 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
                     int32_t* out_idx, float* out_d2) {
     if (!h || !target || !queries_xyz || !out_idx || !out_d2 || level < 0 || level >= target->n_levels || nq == 0 || nq >= 0x7FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "debug_nn: bad argument");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     float* dq = nullptr; int32_t* di = nullptr; float* dd = nullptr;
     HIPCHK(h, hipMalloc((void**)&dq, 12 * nq));
@@ -1493,6 +1523,7 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     const M3dJob* hj = &h->h_jobs[size_t(level) * h->cap_pairs];
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, hj, sizeof(M3dJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, 1, int(h->cap_pairs), 1));
     HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, h->icp_variant, nn_work(h)));
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
