@@ -347,3 +347,18 @@ def test_identical_pairs_in_one_batch_give_identical_results(reg, orc, copies):
     for k in range(copies):
         assert np.array_equal(Tb[k], To), k
         _same_stats(stb[k], sto)
+
+
+def test_clouds_bucketed_on_one_handle_register_on_another(reg, orc):
+    """Bucketing no longer ends with a host synchronisation: a registration enqueued on ANOTHER handle's stream must order
+    itself behind the bucketing of its clouds on the device (one event per bucketed batch)."""
+    p = _params(leaf=0.2, iterations=8, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    A, B = reg.Registrar(p), reg.Registrar(p)
+    for seed in range(4):
+        src, tgt, Tgt = synth.hdl32_pair(600, 10 + seed, 20 + seed, dx=0.2, dy=0.1, dyaw_deg=2.0)
+        cs, ct = A.clouds([src, tgt])          # returns while the bucketing is still in flight on A's stream
+        T, st = B.align(cs, ct)                # B's stream waits for it on the device
+        To, sto, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
+        assert np.array_equal(T, To), seed
+        _same_stats(st, sto)
+        assert ct.grid_info().n_cells == orc.Cloud(p, tgt).grid_info().n_cells   # lazily fetched meta data
