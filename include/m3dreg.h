@@ -130,7 +130,10 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
                         size_t off_x, size_t off_y, size_t off_z, int data_is_device,
                         m3dreg_cloud** out);
 /* Buckets many clouds at once: one decode launch and one bucketing pipeline serve the whole batch
- * (a single 100k-point cloud cannot fill 256 CUs), with two host synchronisations per BATCH. */
+ * (a single 100k-point cloud cannot fill 256 CUs), with ONE host synchronisation per BATCH (the exact AABB, from which
+ * the host derives the grid geometry). The call returns with the rest of the pipeline still in flight on the handle's
+ * stream: a registration on the same handle follows it in stream order, one on another handle is ordered behind it on
+ * the device (an event per batch), and m3dreg_cloud_grid_info / _export wait for it when they are called. */
 typedef struct m3dreg_cloud_desc {
     const void* data;     /* PointCloud2 payload (host, or device when data_is_device != 0) */
     size_t n, point_step, off_x, off_y, off_z;
