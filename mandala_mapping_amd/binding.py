@@ -501,17 +501,34 @@ class Gpu6dSlamNode:
     into an odometry estimate. The ROS wiring itself (subscriber, tf broadcaster) is the source-only
     shim in ros/gpu_6dslam_node.cpp; this class is what tests and bench drive."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, mode="scan_to_scan", map_leaf=0.05, map_capacity=1 << 22):
+        """mode: "scan_to_scan" (every sweep against the previous one, poses chained) or "scan_to_map" (every sweep against the
+        voxel-deduplicated map of all earlier sweeps, kept in HBM: SURVEY §8 row f4)."""
         self.reg = Registrar(params, device)
+        self.mode = mode
         self.pose = np.eye(4)          # pose of the latest cloud in the frame of the first
         self.last_delta = np.eye(4)    # constant-velocity prior for the next registration
-        self._prev = None              # the previous sweep, already bucketed: target of the next registration
+        self._prev = None              # scan_to_scan: the previous sweep, already bucketed: target of the next registration
+        self._map = Map(self.reg, map_leaf, map_capacity) if mode == "scan_to_map" else None
         self.history = []
 
     def on_cloud(self, msg: PointCloud2):
         """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None). Like the shim, the message
-        crosses the ABI with its own field table and every sweep is bucketed once (source now, target next)."""
+        crosses the ABI with its own field table and every sweep is bucketed once."""
         cur = self.reg.cloud_pc2(msg)
+        if self._map is not None:
+            if len(self._map) == 0:
+                self._map.insert(cur, self.pose)
+                self.history.append((self.pose.copy(), None))
+                return self.pose.copy(), None
+            tgt = self._map.as_cloud()                       # the map so far, bucketed in place
+            T, st = self.reg.align(cur, tgt, self.pose @ self.last_delta)   # prior: constant velocity in the map frame
+            if st.status in (abi.CONVERGED, abi.MAX_ITERATIONS):
+                self.last_delta = np.linalg.inv(self.pose) @ T
+                self.pose = T
+                self._map.insert(cur, T)                     # only points in still-empty voxels are kept
+            self.history.append((self.pose.copy(), st))
+            return self.pose.copy(), st
         if self._prev is None:
             self._prev = cur
             self.history.append((self.pose.copy(), None))

@@ -44,6 +44,9 @@ public:
         nh_.param("normal_leaf", normal_leaf, normal_leaf);
         nh_.param("iterations", iters, iters);
         nh_.param("device", device, device);
+        nh_.param<std::string>("mode", mode_, "scan_to_scan");   // or "scan_to_map": register against the HBM map of all earlier sweeps
+        nh_.param("map_leaf", map_leaf_, 0.05);
+        nh_.param("map_capacity", map_capacity_, 1 << 22);
         p.leaf[0] = float(leaf); p.max_corr_dist[0] = float(dmax); p.normal_leaf = float(normal_leaf); p.iterations[0] = iters;
         int rc = m3dreg_create(&p, device, nullptr, &h_);
         if (rc != M3DREG_OK) {   // same policy as the reference's drivers: fatal + exit (encoder_node_li.cpp:60-80)
@@ -51,11 +54,16 @@ public:
             ros::shutdown();
             return;
         }
+        if (mode_ == "scan_to_map" && m3dmap_create(h_, float(map_leaf_), size_t(map_capacity_), &map_) != M3DREG_OK) {
+            ROS_FATAL("m3dmap_create: %s", m3dreg_last_error(h_));
+            ros::shutdown();
+            return;
+        }
         for (int i = 0; i < 16; i++) { pose_[i] = (i % 5 == 0) ? 1.f : 0.f; delta_[i] = pose_[i]; }
         pose_pub_ = nh_.advertise<geometry_msgs::PoseStamped>("pose", 1);
         sub_ = nh_.subscribe(cloud_topic, 1, &Gpu6dSlamNode::onCloud, this);   // queue depth 1, like the producer
     }
-    ~Gpu6dSlamNode() { if (h_) { if (prev_) m3dreg_cloud_destroy(h_, prev_); m3dreg_destroy(h_); } }
+    ~Gpu6dSlamNode() { if (h_) { if (prev_) m3dreg_cloud_destroy(h_, prev_); if (map_) m3dmap_destroy(map_); m3dreg_destroy(h_); } }
 
 private:
     // The message crosses the C ABI as it is — raw buffer + field table; x/y/z are resolved by name on the other side the
@@ -75,6 +83,7 @@ private:
     void onCloud(const sensor_msgs::PointCloud2ConstPtr& msg) {
         m3dreg_cloud* cur = bucket(*msg);
         if (!cur) return;
+        if (map_) { onCloudMap(cur, msg->header); return; }
         if (prev_) {
             float T[16]; m3dreg_stats st;
             const int rc = m3dreg_align_clouds(h_, cur, prev_, delta_, T, &st);
@@ -98,6 +107,51 @@ private:
         prev_ = cur;   // the new sweep becomes the target of the next registration (scan-to-scan odometry)
     }
 
+    static void mul4(const float* A, const float* B, float* out) {   // out = A * B, column-major 4x4 (Eigen::Matrix4f layout)
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) {
+                float s = 0.f;
+                for (int k = 0; k < 4; k++) s += A[k * 4 + r] * B[c * 4 + k];
+                out[c * 4 + r] = s;
+            }
+    }
+    static void inv_rigid(const float* T, float* out) {   // [R t]^-1 = [R^T  -R^T t]
+        for (int i = 0; i < 16; i++) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) out[c * 4 + r] = T[r * 4 + c];
+        for (int r = 0; r < 3; r++) out[12 + r] = -(out[r] * T[12] + out[4 + r] * T[13] + out[8 + r] * T[14]);
+    }
+
+    // scan-to-map: the sweep is registered against the voxel-deduplicated map of all earlier sweeps, which
+    // never leaves HBM, then inserted with its pose. Prior: constant velocity in the map frame.
+    void onCloudMap(m3dreg_cloud* cur, const std_msgs::Header& hdr) {
+        size_t n_map = 0, added = 0;
+        m3dmap_size(map_, &n_map);
+        if (n_map == 0) {
+            if (m3dmap_insert(map_, cur, pose_, &added) != M3DREG_OK) ROS_WARN("m3dmap_insert: %s", m3dreg_last_error(h_));
+            m3dreg_cloud_destroy(h_, cur);
+            return;
+        }
+        m3dreg_cloud* tgt = nullptr;
+        if (m3dmap_as_cloud(map_, &tgt) != M3DREG_OK) { ROS_WARN("m3dmap_as_cloud: %s", m3dreg_last_error(h_)); m3dreg_cloud_destroy(h_, cur); return; }
+        float prior[16], T[16]; m3dreg_stats st;
+        mul4(pose_, delta_, prior);
+        const int rc = m3dreg_align_clouds(h_, cur, tgt, prior, T, &st);
+        if (rc != M3DREG_OK) { ROS_WARN("m3dreg_align_clouds: %s", m3dreg_last_error(h_)); }
+        else if (st.status == M3DREG_CONVERGED || st.status == M3DREG_MAX_ITERATIONS) {
+            float inv[16];
+            inv_rigid(pose_, inv);
+            mul4(inv, T, delta_);
+            std::memcpy(pose_, T, sizeof(T));
+            if (m3dmap_insert(map_, cur, T, &added) != M3DREG_OK) ROS_WARN("m3dmap_insert: %s", m3dreg_last_error(h_));   // map full: keep localising
+            publish(hdr);
+        } else {
+            ROS_WARN("registration rejected: status %d after %d iterations", st.status, st.iterations);
+        }
+        m3dreg_cloud_destroy(h_, tgt);
+        m3dreg_cloud_destroy(h_, cur);
+    }
+
     void publish(const std_msgs::Header& hdr) {
         tf::Matrix3x3 R(pose_[0], pose_[4], pose_[8], pose_[1], pose_[5], pose_[9], pose_[2], pose_[6], pose_[10]);
         tf::Transform t(R, tf::Vector3(pose_[12], pose_[13], pose_[14]));
@@ -117,6 +171,10 @@ private:
     std::string odom_frame_;
     m3dreg_handle* h_ = nullptr;
     m3dreg_cloud* prev_ = nullptr;
+    m3dmap* map_ = nullptr;
+    std::string mode_;
+    double map_leaf_ = 0.05;
+    int map_capacity_ = 1 << 22;
     float pose_[16], delta_[16];
 };
 

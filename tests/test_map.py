@@ -67,3 +67,29 @@ def test_gpu_map_reports_overflow(reg):
     with pytest.raises(abi.M3dregError):
         gm.insert(c, np.eye(4))
     assert len(gm) == 1000
+
+
+@pytest.mark.gpu
+def test_node_scan_to_map_mode_equals_the_oracle_chain(reg, orc):
+    """Gpu6dSlamNode(mode="scan_to_map"): every sweep registered against the device map of all earlier sweeps, then inserted
+    with its pose. The same loop over the oracle's map and the oracle's align must give the same poses, bit for bit."""
+    from mandala_mapping_amd import pointcloud2 as pc2
+    p = abi.Params.make(leaf=(0.4, 0.2), iterations=(8, 10), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    node = reg.Gpu6dSlamNode(p, mode="scan_to_map", map_leaf=0.05, map_capacity=200000)
+    om, pose, delta = orc.Map(0.05, 200000), np.eye(4), np.eye(4)
+    truth = [synth.sensor_pose(0.3 * k, 0.05 * k, 1.5 * k) for k in range(4)]
+    for k in range(4):
+        xyz = synth.hdl32_scan(truth[k], 400, 70 + k)
+        got, st = node.on_cloud(pc2.encode_xyz(xyz))
+        if k == 0:
+            om.insert(xyz, pose)
+            assert st is None and np.array_equal(got, np.eye(4))
+            continue
+        T, sto, _ = orc.align(p, orc.Cloud(p, xyz), orc.Cloud(p, om.points()), pose @ delta)
+        assert sto.status in (abi.CONVERGED, abi.MAX_ITERATIONS)
+        delta, pose = np.linalg.inv(pose) @ T, T
+        om.insert(xyz, T)
+        assert np.array_equal(got, pose) and (st.status, st.iterations, st.n_corr) == (sto.status, sto.iterations, sto.n_corr)
+        rot, tra = synth.pose_error(got, synth.inv_T(truth[0]) @ truth[k])
+        assert rot < 0.1 and tra < 0.03, (k, rot, tra)
+    assert len(node._map) == len(om.points())
