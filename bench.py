@@ -46,6 +46,9 @@ def parse():
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
     ap.add_argument("--inflight", type=int, default=2,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
+    ap.add_argument("--queue-depth", type=int, default=2,
+                    help="steps QUEUED per stream (the first of them runs, the others wait behind it on the same stream): with 2 a stream never "
+                         "drains while the host collects a finished step and enqueues the next one")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --share-gpu = rehearsal of the N > 1 flow on a single-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -89,8 +92,13 @@ def main():
     # every iteration kernel is latency-bound, a second chain fills the idle CUs. Every step still
     # does all of its own work inside the timed region; steps merely overlap in time.
     D = max(1, args.inflight)
+    Q = max(1, args.queue_depth)
     streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
-    regs = [binding.Registrar(params, device=local_rank, stream=C.c_void_p(st_.cuda_stream)) for st_ in streams]
+    # D * Q handles: handle j runs on stream j % D, so up to Q steps queue up behind each other on a stream (a handle holds the
+    # state of one batch). Nothing in a step's chain — bucketing (m3dreg_cloud_create_batch_async) or iterations — waits for the
+    # host, so a queued step starts the moment the one ahead of it on its stream ends.
+    regs = [binding.Registrar(params, device=local_rank, stream=C.c_void_p(streams[j % D].cuda_stream)) for j in range(D * Q)]
+    bregs = regs
     reg = regs[0]
 
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
@@ -117,7 +125,7 @@ def main():
             items = []
             for ds, ns, dt, nt in payloads:
                 items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
-            cl = r.clouds_from_device(items)
+            cl = r.clouds_from_device(items, wait=False)   # no host synchronisation anywhere in a step's chain
         return [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
 
     def finish(T, st, clouds):
@@ -136,9 +144,9 @@ def main():
     host_log = []
 
     def enqueue(i):
-        r = regs[i % D]
+        r = regs[i % len(regs)]
         ta = time.perf_counter()
-        clouds = make_clouds(r)
+        clouds = make_clouds(bregs[i % len(bregs)])
         tb = time.perf_counter()
         r.align_batch_async(r._pairs([(s_, t_, None) for s_, t_ in clouds]), B)
         host_log.append(("enq", i, 1e3 * (tb - ta), 1e3 * (time.perf_counter() - tb)))
@@ -148,13 +156,13 @@ def main():
         """k steps, at most D in flight: step i+D-1 is enqueued (its bucketing runs, its iterations queue up on its own
         stream) before the host waits for step i"""
         pending, nxt = [], 0
-        while nxt < min(D, k):
+        while nxt < min(len(regs), k):
             pending.append((nxt, enqueue(nxt))); nxt += 1
         clouds = None
         for i in range(k):
             idx, clouds = pending.pop(0)
             ta = time.perf_counter()
-            T, st = regs[idx % D].batch_wait(B)
+            T, st = regs[idx % len(regs)].batch_wait(B)
             host_log.append(("wait", idx, 1e3 * (time.perf_counter() - ta), 0.0))
             finish(T, st, clouds)
             if nxt < k:
@@ -176,7 +184,7 @@ def main():
     n_pts = int(np.mean([s.n for s, _ in clouds0]))
     del clouds0
     last.clear()
-    run_steps(max(W - 1, D if W > 0 else 0))   # untimed; at least one step per handle so that every pool is allocated
+    run_steps(max(W - 1, len(regs) if W > 0 else 0))   # untimed; at least one step per handle so that every pool is allocated
     last.clear()
 
     def barrier():
@@ -235,7 +243,8 @@ def main():
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step",
-                       "overlap": "none (serial steps)" if D == 1 else f"{D} steps in flight, one HIP stream each"},
+                       "overlap": ("none (serial steps)" if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
+                                  (f"; {Q} steps queued per stream" if Q > 1 else "")},
             "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
             "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
             "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,

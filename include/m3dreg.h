@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 1
+#define M3DREG_ABI_VERSION 2
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -61,7 +61,9 @@ typedef enum m3dreg_status {
     M3DREG_MAX_ITERATIONS = 1,  /* ran all iterations (normal for fixed-iteration runs) */
     M3DREG_TOO_FEW_CORR = 2,    /* fewer than min_correspondences matches: pose left at last good value */
     M3DREG_RANK_DEFICIENT = 3,  /* 6x6 normal matrix had a pivot <= pivot_rel_tol * max diagonal */
-    M3DREG_DIVERGED = 4         /* update rotation > 2 rad or non-finite */
+    M3DREG_DIVERGED = 4,        /* update rotation > 2 rad or non-finite */
+    M3DREG_BAD_CLOUD = 5        /* a cloud of the pair came out of m3dreg_cloud_create_batch_async in error (no finite point, grid too
+                                   large: m3dreg_cloud_status says which); the pose is the initial guess, no iteration ran */
 } m3dreg_status;
 
 /*
@@ -130,16 +132,25 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
                         size_t off_x, size_t off_y, size_t off_z, int data_is_device,
                         m3dreg_cloud** out);
 /* Buckets many clouds at once: one decode launch and one bucketing pipeline serve the whole batch
- * (a single 100k-point cloud cannot fill 256 CUs), with ONE host synchronisation per BATCH (the exact AABB, from which
- * the host derives the grid geometry). The call returns with the rest of the pipeline still in flight on the handle's
- * stream: a registration on the same handle follows it in stream order, one on another handle is ordered behind it on
- * the device (an event per batch), and m3dreg_cloud_grid_info / _export wait for it when they are called. */
+ * (a single 100k-point cloud cannot fill 256 CUs). The grid geometry (from the exact AABB), the hash-table geometry and the
+ * error state of every cloud are derived ON THE DEVICE and stay there, next to the cloud.
+ *   m3dreg_cloud_create_batch        waits for the pipeline and reports M3DREG_ERR_EMPTY_CLOUD / M3DREG_ERR_GRID_TOO_LARGE like
+ *                                    the single-cloud calls (no cloud is returned on failure);
+ *   m3dreg_cloud_create_batch_async  enqueues only — NO host synchronisation: a registration on the same handle follows in
+ *                                    stream order, one on another handle is ordered behind it on the device (an event per
+ *                                    batch). Host payloads must stay valid until the pipeline has consumed them
+ *                                    (m3dreg_synchronize, m3dreg_cloud_status, or the wait of a registration that uses the
+ *                                    cloud). A cloud that turns out empty or too large ends every registration that names it
+ *                                    with status M3DREG_BAD_CLOUD; m3dreg_cloud_status (waits) returns its error code, and so
+ *                                    do m3dreg_cloud_grid_info / _export. */
 typedef struct m3dreg_cloud_desc {
     const void* data;     /* PointCloud2 payload (host, or device when data_is_device != 0) */
     size_t n, point_step, off_x, off_y, off_z;
     int32_t data_is_device;
 } m3dreg_cloud_desc;
 int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);
+int m3dreg_cloud_create_batch_async(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);
+int m3dreg_cloud_status(m3dreg_handle* h, const m3dreg_cloud* c);   /* M3DREG_OK or the error the device found; waits for the bucketing */
 /* The whole sensor_msgs/PointCloud2 layout contract, decoded on the device: x / y / z are found by
  * NAME in the field table, the way pcl::fromPCLPointCloud2 resolves them in the consumer idiom of
  * m3d_aggregator.cpp:243-246; any offsets (aligned or not), FLOAT32 or FLOAT64 (rounded to nearest float; PCL itself

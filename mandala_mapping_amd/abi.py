@@ -5,7 +5,7 @@ HIP library and to the CPU oracle in the parity tests.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LEVELS = 4
 NSUMS = 29
 
@@ -35,6 +35,7 @@ MAX_ITERATIONS = 1
 TOO_FEW_CORR = 2
 RANK_DEFICIENT = 3
 DIVERGED = 4
+BAD_CLOUD = 5   # a cloud of the pair came out of the asynchronous bucketing in error (Cloud.status() says which)
 STATUS_NAMES = {0: "converged", 1: "max_iterations", 2: "too_few_corr", 3: "rank_deficient", 4: "diverged"}
 
 

@@ -27,6 +27,7 @@ EXPORTS = [
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
+    "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
     "m3dreg_cloud_create_pc2",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
@@ -62,6 +63,8 @@ def lib():
     L.m3dreg_align.argtypes = [vp, vp, sz, sz, sz, sz, sz, f32p, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_cloud_create.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_int, C.POINTER(vp)]
     L.m3dreg_cloud_create_batch.argtypes = [vp, C.POINTER(abi.CloudDesc), sz, C.POINTER(vp)]
+    L.m3dreg_cloud_create_batch_async.argtypes = [vp, C.POINTER(abi.CloudDesc), sz, C.POINTER(vp)]
+    L.m3dreg_cloud_status.argtypes = [vp, vp]
     L.m3dreg_cloud_create_pc2.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.PointField), sz, C.c_int, C.c_int, C.POINTER(vp)]
     L.m3dreg_cloud_destroy.argtypes = [vp, vp]
     L.m3dreg_align_clouds.argtypes = [vp, vp, vp, f32p, f32p, C.POINTER(abi.Stats)]
@@ -142,6 +145,10 @@ class Cloud:
                 self.free()
         except Exception:
             pass
+
+    def status(self):
+        """0, or the (negative) m3dreg_error the device found while bucketing this cloud; waits for the bucketing."""
+        return lib().m3dreg_cloud_status(self._reg._h, self._p)
 
     def grid_info(self, level=0):
         g = abi.GridInfo()
@@ -242,8 +249,10 @@ class Registrar:
         self._check(lib().m3dreg_cloud_create(self._h, C.c_void_p(dev_ptr), n, point_step, offsets[0], offsets[1], offsets[2], 1, C.byref(p)), "cloud_create(device)")
         return Cloud(self, p, n)
 
-    def clouds_from_device(self, items):
-        """items: list of (device address, n[, point_step, (ox, oy, oz)]) -> list of Clouds, bucketed in ONE batch."""
+    def clouds_from_device(self, items, wait=True):
+        """items: list of (device address, n[, point_step, (ox, oy, oz)]) -> list of Clouds, bucketed in ONE batch.
+        wait=False: m3dreg_cloud_create_batch_async — enqueue only, no host synchronisation; a cloud in error (no finite point,
+        grid too large) then ends its registrations with status BAD_CLOUD and Cloud.status() names the error."""
         k = len(items)
         descs = (abi.CloudDesc * k)()
         for i, it in enumerate(items):
@@ -252,11 +261,13 @@ class Registrar:
             descs[i].data, descs[i].n, descs[i].point_step = it[0], it[1], step
             descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = off[0], off[1], off[2], 1
         out = (C.c_void_p * k)()
-        self._check(lib().m3dreg_cloud_create_batch(self._h, descs, k, out), "cloud_create_batch")
+        fn = lib().m3dreg_cloud_create_batch if wait else lib().m3dreg_cloud_create_batch_async
+        self._check(fn(self._h, descs, k, out), "cloud_create_batch")
         return [Cloud(self, C.c_void_p(out[i]), items[i][1]) for i in range(k)]
 
-    def clouds(self, arrays):
-        """arrays: list of float32 [n,3] arrays / PointCloud2 messages -> list of Clouds, bucketed in ONE batch."""
+    def clouds(self, arrays, wait=True):
+        """arrays: list of float32 [n,3] arrays / PointCloud2 messages -> list of Clouds, bucketed in ONE batch (wait: see
+        clouds_from_device; the host buffers must stay alive until the copies have run when wait=False)."""
         msgs = [to_little_endian(encode_xyz(a) if isinstance(a, np.ndarray) else a) for a in arrays]
         k = len(msgs)
         bufs = [np.frombuffer(m.data, np.uint8) for m in msgs]   # views of the messages' own buffers: the payload is not copied on the host
@@ -266,8 +277,13 @@ class Registrar:
             descs[i].data, descs[i].n, descs[i].point_step = bufs[i].ctypes.data, m.n, m.point_step
             descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = ox, oy, oz, 0
         out = (C.c_void_p * k)()
-        self._check(lib().m3dreg_cloud_create_batch(self._h, descs, k, out), "cloud_create_batch")
-        return [Cloud(self, C.c_void_p(out[i]), msgs[i].n) for i in range(k)]
+        fn = lib().m3dreg_cloud_create_batch if wait else lib().m3dreg_cloud_create_batch_async
+        self._check(fn(self._h, descs, k, out), "cloud_create_batch")
+        cl = [Cloud(self, C.c_void_p(out[i]), msgs[i].n) for i in range(k)]
+        if not wait:
+            for c, b in zip(cl, bufs):
+                c._keep = b
+        return cl
 
     # ---- registration -------------------------------------------------------------------------
     def align(self, source: Cloud, target: Cloud, init_T=None):

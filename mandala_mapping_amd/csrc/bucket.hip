@@ -84,6 +84,43 @@ __global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict
     }
 }
 
+// ---- Spec §Grid on the device: one thread per CLOUD derives the geometry of all of its grids from the exact AABB -----------
+// (k_decode_aabb's words), the number of radix passes each needs and the cloud's error state — what the host used to do behind
+// a stream synchronisation. A cloud in error (no finite point, or a grid that needs more than 31 key bits) gets n = 0 in
+// every build: the pipeline below does nothing for it, and k_patch_jobs ends any registration that names it.
+__global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int gpc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clouds) return;
+    M3dBuild* B0 = builds + (size_t)c * gpc;
+    const uint32_t* ab = B0->aabb;
+    const int32_t n_valid = (int32_t)ab[6];
+    float mn[3], mx[3];
+    int err = n_valid == 0 ? M3D_ERR_EMPTY_CLOUD : 0;
+    for (int a = 0; a < 3; a++) {   // unord_f32, spelled with XOR masks: the select-then-pun form crashes the gfx950 instruction selector of ROCm 7.2 here
+        const uint32_t lo = ~ab[a], hi = ab[3 + a];
+        mn[a] = __uint_as_float(lo ^ (((lo >> 31) - 1u) | 0x80000000u));
+        mx[a] = __uint_as_float(hi ^ (((hi >> 31) - 1u) | 0x80000000u));
+    }
+    for (int gi = 0; gi < gpc && !err; gi++) {
+        M3dBuild& B = B0[gi];
+        M3dLevelMeta* M = reinterpret_cast<M3dLevelMeta*>(B.dyn);
+        M3dGrid g; int32_t bits[3]; float lbound;
+        err = m3d_make_grid(mn, mx, B.grid.leaf, n_valid, g, bits, lbound);
+        if (err) break;
+        B.grid = g;
+        const int kb = bits[0] + bits[1] + bits[2] + 3;
+        B.sort_passes = (n_valid != B.n) ? 4 : (kb + 7) / 8;   // the 0xFFFFFFFF keys of non-finite points must end up last
+        M->g = g; M->lbound = lbound;
+        for (int a = 0; a < 3; a++) { M->mx[a] = mx[a]; M->bits[a] = bits[a]; }
+    }
+    for (int gi = 0; gi < gpc; gi++) {
+        M3dBuild& B = B0[gi];
+        M3dLevelMeta* M = reinterpret_cast<M3dLevelMeta*>(B.dyn);
+        M->err = err;
+        if (err) { B.n = 0; B.ntiles = 0; B.sort_passes = 0; B.grid.n_valid = 0; M->g.n_valid = 0; }
+    }
+}
+
 // ---- a3: voxel key per point ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
@@ -635,8 +672,12 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 }
 
 // the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
-hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int n_builds, int max_n, int max_passes, bool any_normals,
+hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
                                    float plane_ratio, int min_pts, float min_spread) {
+    const int n_builds = n_clouds * grids_per_cloud;
+    const int max_passes = 4;   // a build whose keys need fewer skips the later ones on the device
+    hipLaunchKernelGGL(k_grid_params, dim3((n_clouds + 63) / 64), dim3(64), 0, s, d_builds, n_clouds, grids_per_cloud);
+    M3D_DBG(s, "k_grid_params");
     const int blocks = (max_n + 255) / 256;
     const int ntiles = m3d_sort_tiles(max_n);
     const int cb = blocks > 256 ? 256 : blocks;

@@ -1265,14 +1265,28 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     }
 }
 
-// Table geometry of every job's target level, straight from the bucketing pipeline's device-side words: the host enqueues a
-// registration right behind the bucketing of its clouds without waiting to read them back.
+// Everything a job needs from the bucketing of its clouds, straight from the pipeline's device-side words (M3dLevelMeta): the
+// target level's grid geometry, the fixed-point exponents (from its lbound), the source's finite-point count, and the error
+// state of either cloud — the host enqueues a registration right behind the bucketing of its clouds and never reads any of it.
+#define M3D_STATUS_BAD_CLOUD 5   // == M3DREG_BAD_CLOUD
 __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pairs, int n_levels) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_pairs * n_levels) return;
     M3dJob& J = jobs[(size_t)(t / n_pairs) * cap_pairs + (t % n_pairs)];
-    J.tgt.g.hmask = J.tgt.dyn[1];
-    J.tgt.g.hshift = (int32_t)J.tgt.dyn[2];
+    const M3dLevelMeta* M = reinterpret_cast<const M3dLevelMeta*>(J.tgt.dyn);
+    const M3dLevelMeta* MS = reinterpret_cast<const M3dLevelMeta*>(J.src_dyn);
+    M3dGrid g = M->g;
+    g.hmask = M->dyn[1];
+    g.hshift = (int32_t)M->dyn[2];
+    J.tgt.g = g;
+    J.n_src = MS->g.n_valid;
+    int32_t e[6]; float S[6];
+    m3d_fixed_exps(M->lbound, J.dmax, e, S);
+    for (int k = 0; k < 6; k++) { J.exps[k] = e[k]; J.S[k] = S[k]; }
+    if (t < n_pairs && (M->err || MS->err)) {   // a cloud that could not be bucketed: the registration ends before it starts
+        J.st->status = M3D_STATUS_BAD_CLOUD;
+        J.st->done = 1;
+    }
 }
 hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels) {
     hipLaunchKernelGGL(k_patch_jobs, dim3((n_pairs * n_levels + 63) / 64), dim3(64), 0, s, d_jobs, n_pairs, cap_pairs, n_levels);

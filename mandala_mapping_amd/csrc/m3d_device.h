@@ -35,6 +35,22 @@ struct M3dGrid {           // geometry of one voxel grid (host computes it from 
     float prune_slack;     // absolute slack [m] subtracted from voxel-box gaps before pruning
 };
 
+// What the bucketing pipeline derives ON THE DEVICE for one grid of a cloud (k_grid_params from the exact AABB, k_table_params
+// after the sort) — the host never waits for any of it: k_patch_jobs hands it to the registrations, the host reads it back
+// only when somebody asks (grid_info, export, the synchronous entry points' error check). 144 bytes, in the cloud's block.
+#define M3D_ERR_GRID_TOO_LARGE (-4)   // == M3DREG_ERR_GRID_TOO_LARGE
+#define M3D_ERR_EMPTY_CLOUD (-5)      // == M3DREG_ERR_EMPTY_CLOUD
+struct M3dLevelMeta {
+    uint32_t dyn[8];       // {occupied voxels, hmask, hshift, occupied buckets, big buckets, voxel heads, -, -}
+    M3dGrid g;             // hmask / hshift live in dyn[1], dyn[2] (written later in the pipeline than the rest)
+    float lbound;          // max half extent + 3 leaf: bound of |u - centre| that sizes the fixed-point exponents
+    float mx[3];
+    int32_t err;           // 0, or the m3dreg_error of the CLOUD (same value in every level's meta)
+    int32_t bits[3];
+    int32_t pad[2];
+};
+static_assert(sizeof(M3dLevelMeta) == 144, "M3dLevelMeta layout");
+
 struct M3dBucket {         // 32 bytes, 32-byte aligned
     uint32_t key;          // cx | cy << cb[0] | cz << (cb[0]+cb[1]); M3D_INVALID_KEY = empty slot
     uint32_t start;        // first sorted position of the bucket's points
@@ -49,8 +65,8 @@ struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* nrm_in;      // the same normals by INPUT index (fused kernel variants 0/1 only)
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
-    const uint32_t* dyn;      // [8] in the cloud's block: {occupied voxels, hmask, hshift, occupied buckets, big buckets, voxel heads}: derived on the
-                              // device by the bucketing pipeline; k_patch_jobs copies hmask / hshift into g (the host never waits for them)
+    const uint32_t* dyn;      // the level's M3dLevelMeta in the cloud's block (its first 8 words are the dyn counters): derived on the
+                              // device by the bucketing pipeline; k_patch_jobs copies the geometry into g (the host never waits for it)
     M3dGrid g;
 };
 
@@ -82,6 +98,8 @@ struct M3dJob {            // one pair at one level
     double eps_rot2, eps_trans2, pivot_rel_tol;
     M3dPairState* st;
     double* trace;         // [M3D_MAX_TRACE][16] or null
+    const uint32_t* src_dyn;   // M3dLevelMeta of the source's finest level (n_src, error state): read by k_patch_jobs
+    float dmax;                // max_corr_dist of this level (k_patch_jobs derives the fixed-point exponents from it and the target's lbound)
 };
 
 // ---- spec primitives shared by every kernel (operation order is normative) --------
@@ -111,6 +129,68 @@ __device__ __forceinline__ uint32_t m3d_bucket_key(const M3dGrid& g, int cx, int
 __device__ __forceinline__ uint32_t m3d_hash_slot(uint32_t key, int hshift) {
     return (key * 0x9E3779B1u) >> hshift;
 }
+// ---- Spec §Grid on either side of the bus: everything the kernels need, from the exact AABB. The bucketing pipeline runs it on
+// the device (k_grid_params); the arithmetic is float add / sub / mul / div / floor only (correctly rounded on both sides).
+__host__ __device__ inline int m3d_bits_for(int32_t d) {
+    int b = 1;
+    while (b < 31 && (1u << b) < (uint32_t)d) b++;   // d <= 2^30
+    return b;
+}
+__host__ __device__ inline float m3d_cell_hd(float v, float mn, float inv_leaf) {
+    const float d = v - mn;
+    const float s = d * inv_leaf;
+    return floorf(s);
+}
+// returns 0 or M3D_ERR_GRID_TOO_LARGE; hmask / hshift are left 0 (derived after the sort)
+__host__ __device__ inline int m3d_make_grid(const float mn[3], const float mx[3], float leaf, int32_t n_valid, M3dGrid& g, int32_t bits[3],
+                                             float& lbound) {
+    g.leaf = leaf;
+    g.inv_leaf = 1.0f / leaf;
+    g.n_valid = n_valid;
+    float half_max = 0.0f, amax = 0.0f, ext_max = 0.0f;
+    int total_bits = 0;
+    for (int a = 0; a < 3; a++) {
+        g.mn[a] = mn[a];
+        const float fc = m3d_cell_hd(mx[a], mn[a], g.inv_leaf);
+        if (!(fc < 1073741824.0f)) return M3D_ERR_GRID_TOO_LARGE;
+        g.dims[a] = (int32_t)fc + 1;
+        bits[a] = m3d_bits_for((g.dims[a] + 1) >> 1);   // bit width of the BUCKET coordinate
+        if (bits[a] > 11) return M3D_ERR_GRID_TOO_LARGE;
+        g.cb[a] = bits[a];
+        total_bits += bits[a];
+        const float ext = mx[a] - mn[a];
+        const float half = ext * 0.5f;
+        g.center[a] = mn[a] + half;
+        if (half > half_max) half_max = half;
+        amax = fmaxf(amax, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+        ext_max = fmaxf(ext_max, ext);
+    }
+    if (total_bits + 3 > 31) return M3D_ERR_GRID_TOO_LARGE;
+    lbound = half_max + 3.0f * leaf;
+    g.hmask = 0;
+    g.hshift = 0;
+    // pruning slack (not part of the results: only makes the box test conservative)
+    g.prune_slack = 1.0e-6f * (amax + ext_max) + 1.0e-3f * leaf;
+    return 0;
+}
+// ceil(log2(x)) of a positive normal double from its bits (what frexp would say, without libm)
+__host__ __device__ inline int m3d_ceil_log2_d(double x) {
+    union { double d; unsigned long long u; } c; c.d = x;
+    const int ex = (int)((c.u >> 52) & 0x7FFull) - 1022;           // x = m * 2^ex, m in [0.5, 1)
+    return ((c.u & 0xFFFFFFFFFFFFFull) == 0ull) ? ex - 1 : ex;     // m == 0.5: an exact power of two
+}
+// Spec §Linearisation: per-class fixed-point exponents e = 30 - ceil_log2(bound), and their scales 2^e
+__host__ __device__ inline void m3d_fixed_exps(float lbound, float max_corr_dist, int32_t e[6], float S[6]) {
+    const double lb = (double)lbound, D = (double)max_corr_dist * 1.001;
+    e[0] = 30 - m3d_ceil_log2_d(3.0 * lb * lb);
+    e[1] = 30 - m3d_ceil_log2_d(1.7320508075688772 * lb);
+    e[2] = 30;
+    e[3] = 30 - m3d_ceil_log2_d(1.7320508075688772 * lb * D);
+    e[4] = 30 - m3d_ceil_log2_d(D);
+    e[5] = 30 - m3d_ceil_log2_d(D * D);
+    for (int k = 0; k < 6; k++) { union { uint32_t u; float f; } c; c.u = (uint32_t)(e[k] + 127) << 23; S[k] = c.f; }   // 2^e, -126 <= e <= 127
+}
+
 // Pointers that arrive inside descriptors loaded from memory are "generic" to the compiler, which then
 // emits flat_load (slower, and every wait drains both counters). They all point to hipMalloc'ed HBM,
 // so the kernels re-type them as global (address space 1) before use.

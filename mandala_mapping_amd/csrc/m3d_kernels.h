@@ -33,7 +33,8 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     int sort_passes;             // 8-bit LSD passes needed to order this grid's keys
     int ntiles;
     const float4* xyz;           // input-order coordinates of the cloud
-    M3dGrid grid;                // hmask/hshift are filled on the device (dyn)
+    M3dGrid grid;                // in: grid.leaf; everything else is derived ON THE DEVICE from the cloud's exact AABB (k_grid_params), like sort_passes
+    const uint32_t* aabb;        // [8] the cloud's k_decode_aabb words
     uint32_t* keys;              // [n] out: key per input point
     uint32_t *ka, *va, *kb, *vb; // [n] sort ping-pong workspace
     uint32_t* hist;              // [256 * ntiles] workspace
@@ -44,7 +45,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t hcap;
     uint32_t* bigcum;            // [bigcap][8] out
     uint32_t bigcap;
-    uint32_t* dyn;               // [8] (zeroed) out: {occupied voxels, hmask, hshift, occupied buckets, big buckets, ...}
+    uint32_t* dyn;               // out: the grid's M3dLevelMeta (144 B; its first 8 words are the dyn counters {occupied voxels, hmask, hshift, ...})
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
     float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
     float4* nrm_sorted;          // [n] out: the same normals in this level's sorted order (level builds of point-to-plane clouds, else null)
@@ -53,7 +54,9 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
 float m3d_unord_f32(uint32_t u);
 int m3d_sort_tiles(int n);
 hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n_clouds, int max_n);
-hipError_t m3d_launch_bucket_batch(hipStream_t s, const M3dBuild* d_builds, int n_builds, int max_n, int max_passes, bool any_normals,
+// n_builds = n_clouds * grids_per_cloud, the builds of a cloud are consecutive. No host input beyond sizes: the grid geometry, the
+// number of sort passes and the error state of every cloud are derived on the device.
+hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
                                    float plane_ratio, int min_pts, float min_spread);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 

@@ -34,7 +34,8 @@ struct DevLevel {
     uint32_t* perm = nullptr;
     float4* nrm = nullptr;         // normals in this level's sorted order (point-to-plane)
     uint32_t n_cells_host = 0;     // valid once the cloud's meta data was fetched (fetch_meta)
-    uint32_t* dyn = nullptr;       // [8] device words of the bucketing pipeline (occupied voxels, table geometry ...), in the cloud's block
+    uint32_t* dyn = nullptr;       // the level's M3dLevelMeta (144 B) in the cloud's block: grid geometry, table geometry, counts, error state —
+                                   // all derived on the device; grid / bits / mx / lbound above are host COPIES, valid after fetch_meta
 };
 
 struct Block { void* p = nullptr; size_t bytes = 0; };
@@ -67,7 +68,8 @@ struct m3dreg_cloud {
     Block block;                   // ONE device allocation holds every array of the cloud
     m3dreg_handle* owner = nullptr;    // the handle whose stream bucketed it
     struct BatchReady* ready = nullptr;   // event recorded behind the bucketing of the batch this cloud came from (shared, ref-counted)
-    bool meta_ready = false;           // table geometry / voxel counts read back to the host (lazily: grid_info, export, debug_nn)
+    bool meta_ready = false;           // geometry / counts / error state read back to the host (lazily: grid_info, export, debug_nn, the synchronous entry points)
+    int err = 0;                       // valid once meta_ready: 0 or the m3dreg_error the device found (no finite point, grid too large)
 };
 struct BatchReady { hipEvent_t ev = nullptr; int refs = 0; };
 
@@ -81,7 +83,9 @@ struct m3dreg_handle {
     std::vector<Block> pool;
     size_t pool_bytes = 0;
     Block ws;                          // device workspace of the bucketing batch
-    void* h_ws = nullptr;              // pinned host staging (descriptors, aabb / dyn read-back)
+    void* h_ws = nullptr;              // pinned host staging (descriptors of a bucketing batch)
+    std::vector<std::vector<float>> repack;   // host-side repacked payloads of the batch in flight (unaligned layouts): alive until `staged` has fired
+    hipEvent_t staged = nullptr;       // recorded behind the copies out of h_ws: the next batch waits for it before it overwrites the staging area
     size_t h_ws_bytes = 0;
     // batch state
     size_t cap_pairs = 0;
@@ -141,72 +145,7 @@ int fail(m3dreg_handle* h, int code, const char* where, hipError_t e = hipSucces
         if (_e != hipSuccess) return fail((h), M3DREG_ERR_HIP, #call, _e); \
     } while (0)
 
-int bits_for(int32_t d) {
-    int b = 1;
-    while ((int64_t(1) << b) < int64_t(d)) b++;
-    return b;
-}
-
-int ceil_log2_d(double x) {
-    int ex;
-    double m = std::frexp(x, &ex);
-    return (m == 0.5) ? ex - 1 : ex;
-}
-
-float cell_f(float v, float mn, float inv_leaf) {
-    float d = v - mn;
-    float s = d * inv_leaf;
-    return std::floor(s);
-}
-
-// Spec §Grid: everything the kernels need, from the exact AABB. Returns an m3dreg_error.
-int make_grid(const float mn[3], const float mx[3], float leaf, int32_t n, int32_t n_valid, DevLevel& L) {
-    M3dGrid& g = L.grid;
-    g.leaf = leaf;
-    g.inv_leaf = 1.0f / leaf;
-    g.n_valid = n_valid;
-    float half_max = 0.0f, amax = 0.0f, ext_max = 0.0f;
-    int total_bits = 0;
-    for (int a = 0; a < 3; a++) {
-        g.mn[a] = mn[a];
-        L.mx[a] = mx[a];
-        float fc = cell_f(mx[a], mn[a], g.inv_leaf);
-        if (!(fc < 1073741824.0f)) return M3DREG_ERR_GRID_TOO_LARGE;
-        g.dims[a] = int32_t(fc) + 1;
-        L.bits[a] = bits_for((g.dims[a] + 1) >> 1);   // bit width of the BUCKET coordinate
-        if (L.bits[a] > 11) return M3DREG_ERR_GRID_TOO_LARGE;
-        g.cb[a] = L.bits[a];
-        total_bits += L.bits[a];
-        float ext = mx[a] - mn[a];
-        float half = ext * 0.5f;
-        g.center[a] = mn[a] + half;
-        if (half > half_max) half_max = half;
-        amax = std::fmax(amax, std::fmax(std::fabs(mn[a]), std::fabs(mx[a])));
-        ext_max = std::fmax(ext_max, ext);
-    }
-    if (total_bits + 3 > 31) return M3DREG_ERR_GRID_TOO_LARGE;
-    L.lbound = half_max + 3.0f * leaf;
-    // hash table: worst-case allocation is a power of two >= 2n; the used size (power of two >= 2 * occupied
-    // voxels) is derived on the device after the sort and read back once at the end of cloud_create
-    uint32_t hs = 16;
-    while (hs < 2u * uint32_t(n)) hs <<= 1;
-    L.hcap = hs;
-    g.hmask = 0;
-    g.hshift = 0;
-    // pruning slack (not part of the results: only makes the box test conservative)
-    g.prune_slack = 1.0e-6f * (amax + ext_max) + 1.0e-3f * leaf;
-    return M3DREG_OK;
-}
-
-void fixed_exps(float lbound, float max_corr_dist, int32_t e[6]) {
-    const double lb = double(lbound), D = double(max_corr_dist) * 1.001;
-    e[0] = 30 - ceil_log2_d(3.0 * lb * lb);
-    e[1] = 30 - ceil_log2_d(1.7320508075688772 * lb);
-    e[2] = 30;
-    e[3] = 30 - ceil_log2_d(1.7320508075688772 * lb * D);
-    e[4] = 30 - ceil_log2_d(D);
-    e[5] = 30 - ceil_log2_d(D * D);
-}
+static_assert(M3D_ERR_GRID_TOO_LARGE == M3DREG_ERR_GRID_TOO_LARGE && M3D_ERR_EMPTY_CLOUD == M3DREG_ERR_EMPTY_CLOUD, "device error codes");
 
 const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
 
@@ -268,12 +207,6 @@ void free_cloud(m3dreg_handle* h, m3dreg_cloud* c) {
     delete c;
 }
 
-int sort_passes_for(const DevLevel& L, bool has_invalid) {
-    if (has_invalid) return 4;  // the 0xFFFFFFFF keys of non-finite points must end up last
-    int bits = L.bits[0] + L.bits[1] + L.bits[2] + 3;
-    return (bits + 7) / 8;
-}
-
 uint32_t table_cap(size_t n) { uint32_t hs = 16; while (hs < 2u * uint32_t(n)) hs <<= 1; return hs; }
 
 // lay a cloud's arrays out in its block (base == nullptr: size only)
@@ -291,7 +224,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
         L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
-        L.dyn = k.take<uint32_t>(8);
+        L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
     }
     return (k.off + 255) & ~size_t(255);
 }
@@ -299,8 +232,9 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
 struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned;
                     bool generic = false; size_t width = 0, row_step = 0, data_bytes = 0; bool f64[3] = { false, false, false }; bool bigendian = false; };
 
-// Bucket a batch of clouds: one decode launch, ONE host sync (grid geometry is host-derived from the exact
-// AABBs), one bucketing pipeline for every grid of every cloud, one final sync (table geometry read-back).
+// Bucket a batch of clouds: one decode launch, one bucketing pipeline for every grid of every cloud, NO host synchronisation:
+// the grid geometry (from the exact AABBs), the table geometry and the error state of every cloud are derived on the device
+// and stay there (M3dLevelMeta in the cloud's block); fetch_meta reads them back when somebody asks.
 int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud** out) {
     const m3dreg_params& P = h->params;
     const bool want_normals = P.metric == M3DREG_POINT_TO_PLANE;
@@ -335,8 +269,9 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         w.take<uint8_t>(0); zero_lo = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
         uint32_t* aabb_all = w.take<uint32_t>(8 * k);              // contiguous: read back with one copy
         for (size_t i = 0; i < k; i++) aabb[i] = base ? aabb_all + 8 * i : nullptr;
-        uint32_t* dyn_all = w.take<uint32_t>(8 * n_builds);        // contiguous: read back with one copy
-        for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + 8 * b : nullptr;
+        const size_t mw = sizeof(M3dLevelMeta) / 4;
+        uint32_t* dyn_all = w.take<uint32_t>(mw * n_builds);       // one M3dLevelMeta per build (the normal grids' live here, the levels' in their clouds)
+        for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + mw * b : nullptr;
         for (size_t i = 0; i < k; i++) {
             BuildWs& B = bw[i * size_t(grids_per_cloud)];
             B.mom = want_normals ? w.take<long long>(10 * in[i].n) : nullptr;
@@ -365,14 +300,15 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     int rc = ensure_ws(h, ws_bytes, host_bytes);
     if (rc) { cleanup(); return rc; }
     layout(h->ws.p);
+    if (h->staged) { hipError_t e = hipEventSynchronize(h->staged); if (e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, "hipEventSynchronize(staging)", e); } }
     Carver hw(h->h_ws);
     M3dDecode* h_dec = hw.take<M3dDecode>(k);
     M3dBuild* h_builds = hw.take<M3dBuild>(n_builds);
-    uint32_t* h_aabb = hw.take<uint32_t>(8 * k);
 #define B_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
     B_HIP(hipMemsetAsync(zero_lo, 0, size_t(zero_hi - zero_lo), h->stream));
     // ---- a2: stage + decode ----------------------------------------------------------------------------------
-    std::vector<std::vector<float>> repack(k);
+    std::vector<std::vector<float>>& repack = h->repack;   // the previous batch's copies are done (h->staged was waited for above)
+    repack.assign(k, std::vector<float>());
     for (size_t i = 0; i < k; i++) {
         M3dDecode& D = h_dec[i];
         size_t step = in[i].step, ox = in[i].ox, oy = in[i].oy, oz = in[i].oz;
@@ -401,43 +337,34 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     }
     B_HIP(hipMemcpyAsync(d_dec, h_dec, sizeof(M3dDecode) * k, hipMemcpyHostToDevice, h->stream));
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
-    B_HIP(hipMemcpyAsync(h_aabb, aabb[0], sizeof(uint32_t) * 8 * k, hipMemcpyDeviceToHost, h->stream));
-    B_HIP(hipStreamSynchronize(h->stream));   // sync 1 of 2: the grid geometry is derived on the host from the exact AABB
-    // ---- a3/a4/a9: one build descriptor per grid ---------------------------------------------------------------
-    int max_passes = 0;
+    // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
-        const uint32_t* ab = h_aabb + 8 * i;
-        c->n_valid = int32_t(ab[6]);
-        if (c->n_valid == 0) { cleanup(); return fail(h, M3DREG_ERR_EMPTY_CLOUD, "cloud has no finite point"); }
-        for (int a = 0; a < 3; a++) { c->mn[a] = m3d_unord_f32(~ab[a]); c->mx[a] = m3d_unord_f32(ab[3 + a]); }
         c->has_normals = want_normals;
         for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
             const size_t bi = i * size_t(grids_per_cloud) + size_t(gidx);
             BuildWs& W = bw[bi];
             const bool is_ng = want_normals && gidx == 0;
             DevLevel& L = is_ng ? W.ng : c->lv[gidx - (want_normals ? 1 : 0)];
-            const float leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
-            rc = make_grid(c->mn, c->mx, leaf, c->n, c->n_valid, L);
-            if (rc) { cleanup(); return fail(h, rc, "voxel grid needs more than 31 key bits (coarsen leaf or crop the cloud)"); }
             M3dBuild& B = h_builds[bi];
             memset(&B, 0, sizeof(B));
-            B.n = c->n; B.sort_passes = sort_passes_for(L, c->n_valid != c->n); B.ntiles = m3d_sort_tiles(c->n);
-            if (B.sort_passes > max_passes) max_passes = B.sort_passes;
-            B.xyz = c->xyz; B.grid = L.grid;
+            B.n = c->n; B.sort_passes = 0; B.ntiles = m3d_sort_tiles(c->n);
+            B.xyz = c->xyz; B.aabb = aabb[i];
+            B.grid.leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
             B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
-            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's words live in its cloud (read by the jobs later)
+            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
             B.nrm_in = c->nrm_in;
             B.nrm_sorted = is_ng ? nullptr : L.nrm;
         }
     }
     B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
-    B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(n_builds), int(max_n), max_passes, want_normals, P.plane_ratio, P.normal_min_pts,
+    if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
+    B_HIP(hipEventRecord(h->staged, h->stream));
+    B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, P.plane_ratio, P.normal_min_pts,
                                   P.normal_min_spread));
-    // NO second synchronisation: the table geometry stays on the device (k_patch_jobs hands it to the registrations, fetch_meta
-    // reads it back when somebody asks). One event behind the pipeline lets OTHER handles order their streams after it.
+    // One event behind the pipeline lets OTHER handles order their streams after it.
     BatchReady* br = new BatchReady();
     if (hipEventCreateWithFlags(&br->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(br->ev, h->stream) != hipSuccess) {
         if (br->ev) hipEventDestroy(br->ev);
@@ -445,27 +372,48 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     }
 #undef B_HIP
     for (size_t i = 0; i < k; i++) {
-        cl[i]->owner = h; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false;
+        cl[i]->owner = h; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false; cl[i]->err = 0;
         out[i] = cl[i];
     }
     return M3DREG_OK;
 }
 
-// table geometry / voxel counts of a cloud on the host (waits for its bucketing)
+// geometry, counts and error state of a cloud on the host (waits for its bucketing). Returns the cloud's error, if it has one.
 int fetch_meta(m3dreg_handle* h, m3dreg_cloud* c) {
-    if (c->meta_ready) return M3DREG_OK;
-    m3dreg_handle* o = c->owner ? c->owner : h;
-    HIPCHK(h, hipSetDevice(o->device));
-    HIPCHK(h, hipStreamSynchronize(o->stream));
-    for (int l = 0; l < c->n_levels; l++) {
-        uint32_t dyn[8];
-        HIPCHK(h, hipMemcpy(dyn, c->lv[l].dyn, sizeof(dyn), hipMemcpyDeviceToHost));
-        c->lv[l].n_cells_host = dyn[0];
-        c->lv[l].grid.hmask = dyn[1];
-        c->lv[l].grid.hshift = int32_t(dyn[2]);
+    if (!c->meta_ready) {
+        m3dreg_handle* o = c->owner ? c->owner : h;
+        HIPCHK(h, hipSetDevice(o->device));
+        HIPCHK(h, hipStreamSynchronize(o->stream));
+        for (int l = 0; l < c->n_levels; l++) {
+            M3dLevelMeta M;
+            HIPCHK(h, hipMemcpy(&M, c->lv[l].dyn, sizeof(M), hipMemcpyDeviceToHost));
+            DevLevel& L = c->lv[l];
+            L.n_cells_host = M.dyn[0];
+            L.grid = M.g;
+            L.grid.hmask = M.dyn[1];
+            L.grid.hshift = int32_t(M.dyn[2]);
+            L.lbound = M.lbound;
+            for (int a = 0; a < 3; a++) { L.mx[a] = M.mx[a]; L.bits[a] = M.bits[a]; c->mn[a] = M.g.mn[a]; c->mx[a] = M.mx[a]; }
+            c->n_valid = M.g.n_valid;
+            c->err = M.err;
+        }
+        c->meta_ready = true;
     }
-    c->meta_ready = true;
+    if (c->err == M3DREG_ERR_EMPTY_CLOUD) return fail(h, c->err, "cloud has no finite point");
+    if (c->err) return fail(h, c->err, "voxel grid needs more than 31 key bits (coarsen leaf or crop the cloud)");
     return M3DREG_OK;
+}
+
+// the synchronous entry points: wait for the bucketing and report what the device found, like the old host-side checks did
+int finish_sync(m3dreg_handle* h, m3dreg_cloud** cl, size_t k) {
+    int rc = M3DREG_OK;
+    for (size_t i = 0; i < k && rc == M3DREG_OK; i++) rc = fetch_meta(h, cl[i]);
+    if (rc != M3DREG_OK) {
+        const std::string msg = h->err;
+        for (size_t i = 0; i < k; i++) { free_cloud(h, cl[i]); cl[i] = nullptr; }
+        h->err = msg;
+    }
+    return rc;
 }
 
 M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
@@ -583,15 +531,15 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         if (P.metric == M3DREG_POINT_TO_PLANE && !t->has_normals) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "target cloud has no normals");
         for (const m3dreg_cloud* c : { s, t })   // a cloud bucketed on ANOTHER handle's stream: this stream waits for that pipeline
             if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
-        if (s->n_valid > max_n_src) max_n_src = s->n_valid;
+        if (s->n > max_n_src) max_n_src = s->n;   // launch geometry only (the finite count stays on the device; results do not depend on it)
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
-            J.src = s->lv[s->n_levels - 1].pts; J.n_src = s->n_valid; J.metric = P.metric;
+            J.src = s->lv[s->n_levels - 1].pts; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
+            J.src_dyn = s->lv[s->n_levels - 1].dyn;
             J.tgt = level_dev(t->lv[l], t->nrm_in);
+            J.dmax = P.max_corr_dist[l];
             J.dmax2 = P.max_corr_dist[l] * P.max_corr_dist[l];
-            fixed_exps(t->lv[l].lbound, P.max_corr_dist[l], J.exps);
-            for (int k = 0; k < 6; k++) J.S[k] = std::ldexp(1.0f, J.exps[k]);
             J.min_corr = P.min_correspondences;
             J.last_level = (l == P.n_levels - 1) ? 1 : 0;
             J.eps_rot2 = P.eps_rot * P.eps_rot;
@@ -700,6 +648,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets }) if (p) hipFree(p);
     for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->staged) hipEventDestroy(h->staged);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return M3DREG_OK;
@@ -726,12 +675,22 @@ static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput&
     return M3DREG_OK;
 }
 
-int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
+int m3dreg_cloud_create_batch_async(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
     if (!h || !descs || !out || n_clouds == 0 || n_clouds > 4096) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_batch: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<CloudInput> in(n_clouds);
     for (size_t i = 0; i < n_clouds; i++) { out[i] = nullptr; int rc = check_input(h, descs[i], in[i]); if (rc) return rc; }
     return create_clouds(h, in.data(), n_clouds, out);
+}
+
+int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
+    const int rc = m3dreg_cloud_create_batch_async(h, descs, n_clouds, out);
+    return rc ? rc : finish_sync(h, out, n_clouds);
+}
+
+int m3dreg_cloud_status(m3dreg_handle* h, const m3dreg_cloud* c) {
+    if (!h || !c) return M3DREG_ERR_INVALID_ARG;
+    return fetch_meta(h, const_cast<m3dreg_cloud*>(c));
 }
 
 int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
@@ -777,7 +736,8 @@ int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_byte
         ci.oy % 4 == 0 && ci.oz % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 4 == 0)
         ci.generic = false;
     HIPCHK(h, hipSetDevice(h->device));
-    return create_clouds(h, &ci, 1, out);
+    const int rc = create_clouds(h, &ci, 1, out);
+    return rc ? rc : finish_sync(h, out, 1);
 }
 
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
@@ -1541,7 +1501,10 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
         for (int k = 0; k < 6; k++) sums[21 + k] = raw[9 + k];
         sums[27] = raw[15]; sums[28] = raw[16];
     }
-    for (int i = 0; i < 6; i++) exps[i] = hj->exps[i];
+    // the exponents k_patch_jobs derived on the device, restated from the target's meta (same shared function)
+    if ((rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)))) return rc;
+    float S[6];
+    m3d_fixed_exps(target->lv[level].lbound, h->params.max_corr_dist[level], exps, S);
     return M3DREG_OK;
 }
 

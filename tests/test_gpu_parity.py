@@ -362,3 +362,37 @@ def test_clouds_bucketed_on_one_handle_register_on_another(reg, orc):
         assert np.array_equal(T, To), seed
         _same_stats(st, sto)
         assert ct.grid_info().n_cells == orc.Cloud(p, tgt).grid_info().n_cells   # lazily fetched meta data
+
+
+def test_async_bucketing_no_host_sync_and_device_side_errors(reg, orc):
+    """m3dreg_cloud_create_batch_async: nothing of the bucketing is waited for — the grid geometry, the fixed-point exponents
+    and the error state of every cloud reach the registration on the device (k_grid_params -> M3dLevelMeta -> k_patch_jobs).
+    Good pairs must come out exactly as through the synchronous path and the oracle; a cloud without a finite point or with
+    a grid beyond 31 key bits ends ITS registrations with BAD_CLOUD (pose = initial guess) and nobody else's."""
+    p = _params(leaf=(0.5, 0.25), iterations=(4, 6), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    src, tgt, Tgt = synth.config1(5000)
+    src2 = src.copy(); src2[::41] = np.nan                      # non-finite points: the finite count is a device-side quantity too
+    empty = np.full((300, 3), np.nan, np.float32)
+    huge = np.array([[0, 0, 0], [90000.0, 90000.0, 90000.0]], np.float32)   # 360 000 voxels per axis at leaf 0.25
+    cl = R.clouds([src, tgt, src2, empty, huge], wait=False)
+    T0 = synth.perturb(Tgt, np.random.default_rng(9), 1.0, 0.05)
+    pairs = [(cl[0], cl[1], T0), (cl[3], cl[1], T0), (cl[2], cl[1], T0), (cl[0], cl[4], T0), (cl[0], cl[3], T0)]
+    Ts, sts = R.align_batch(pairs)
+    ot = orc.Cloud(p, tgt)
+    for k, s in ((0, src), (2, src2)):
+        To, sto, _ = orc.align(p, orc.Cloud(p, s), ot, T0)
+        assert np.array_equal(Ts[k], To)
+        _same_stats(sts[k], sto)
+    for k in (1, 3, 4):
+        assert sts[k].status == abi.BAD_CLOUD and sts[k].iterations == 0
+        assert np.array_equal(Ts[k].astype(np.float32), T0.astype(np.float32))
+    assert [c.status() for c in cl] == [0, 0, 0, abi.ERR_EMPTY_CLOUD, abi.ERR_GRID_TOO_LARGE]
+    with pytest.raises(abi.M3dregError) as ei:
+        cl[4].grid_info()
+    assert ei.value.code == abi.ERR_GRID_TOO_LARGE
+    _check_bucketing(cl[2], orc.Cloud(p, src2), 2)               # read back lazily, equal to the oracle's geometry bit for bit
+    # the synchronous call still refuses such a batch up front
+    with pytest.raises(abi.M3dregError) as ei:
+        R.clouds([src, empty])
+    assert ei.value.code == abi.ERR_EMPTY_CLOUD
