@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block
         B.hist[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        B.blkw[blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         B.hist[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
 }
@@ -400,6 +401,51 @@ __global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restric
 }
 
 // third pass, almost always empty (a bucket of 2x2x2 voxels with more than 65535 points): 32-bit cumulative rows
+// Longest-processing-time-first order of a cloud's 256-point blocks (it is the SOURCE of a registration that uses it): a block that
+// spans few voxels is a crowded stretch of the cloud (a surface close to the sensor) — its queries meet crowded target voxels and
+// walk several times as many candidates as the rest. Started last, such blocks were the tail that set k_nn_iter's duration; started
+// first, they run while the other blocks fill the machine. One workgroup per grid ranks the blocks by occupied voxels, ascending.
+#define M3D_ORDER_CAP 8192
+__global__ __launch_bounds__(1024) void k_block_order(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.x];
+    if (!B.order) return;
+    const int nblk = (B.n + 255) / 256;
+    __shared__ uint32_t w[M3D_ORDER_CAP];
+    if (nblk > M3D_ORDER_CAP || nblk == 0) {   // (a cloud of more than 2 M points, or one in error: natural order)
+        const int nb0 = (int)((B.n > 0 ? B.n : 0) + 255) / 256;
+        for (int b = threadIdx.x; b < nb0; b += blockDim.x) B.order[b] = (uint32_t)b;
+        return;
+    }
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) w[b] = B.blkw[b];
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        const uint32_t wb = w[b];
+        int rank = 0;
+        for (int o = 0; o < nblk; o++) rank += (w[o] < wb || (w[o] == wb && o < b)) ? 1 : 0;
+        B.order[rank] = (uint32_t)b;
+    }
+}
+
+// exact AABB of every M3D_CHUNK consecutive sorted (finite) points: the search tests a crowded voxel's chunks by their boxes
+// before it gathers them (min / max of floats: exact, order-independent)
+__global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.cbox) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nv = B.grid.n_valid;
+    if (c * M3D_CHUNK >= nv) return;
+    const int j1 = min((c + 1) * M3D_CHUNK, nv);
+    float4 p = B.pts[c * M3D_CHUNK];
+    float mnx = p.x, mny = p.y, mnz = p.z, mxx = p.x, mxy = p.y, mxz = p.z;
+    for (int j = c * M3D_CHUNK + 1; j < j1; j++) {
+        p = B.pts[j];
+        mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+        mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+    }
+    B.cbox[2 * c] = make_float4(mnx, mny, mnz, 0.f);
+    B.cbox[2 * c + 1] = make_float4(mxx, mxy, mxz, 0.f);
+}
+
 __global__ __launch_bounds__(256) void k_bucket_big(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
     if (B.dyn[4] == 0u) return;
@@ -696,6 +742,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
+    hipLaunchKernelGGL(k_block_order, dim3(n_builds), dim3(1024), 0, s, d_builds);
+    M3D_DBG(s, "k_block_order");
     hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_clear_table");
     hipLaunchKernelGGL(k_finalize_level, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
@@ -704,6 +752,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_bucket_counts");
     hipLaunchKernelGGL(k_bucket_big, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_bucket_big");
+    hipLaunchKernelGGL(k_chunk_boxes, dim3((blocks + M3D_CHUNK - 1) / M3D_CHUNK, n_builds), dim3(256), 0, s, d_builds);
+    M3D_DBG(s, "k_chunk_boxes");
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");

@@ -46,6 +46,33 @@ extern "C" hipError_t m3d_debug_read_stats(unsigned long long* out, int reset) {
 #define M3D_STATW(it, what) ((void)0)
 #endif
 
+// -DM3D_BLOCKTIME: every block of k_nn_iter records {start, end} (100 MHz wall clock), where it ran and how many of its queries it
+// searched, for the Gauss-Newton iteration g_m3d_blk_iter (scripts/block_times.py). Never defined in the shipped library.
+#ifdef M3D_BLOCKTIME
+__device__ unsigned long long g_m3d_blk[8192][8];   // {start, end, where, searched, sum of gather trips, max trips of a lane, sum of chunk tests, probes}
+__device__ int g_m3d_blk_iter = 0;
+extern "C" hipError_t m3d_debug_read_blocks(unsigned long long* out, int iter) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_blk), sizeof(unsigned long long) * 8192 * 8);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_blk_iter), &iter, sizeof(int));
+    return e;
+}
+__device__ int g_bt_on[8192];
+#define M3D_BT_COUNT(W, f) ((W).f++)
+#define M3D_BT_FLUSH(W) do { if (blockIdx.x < 8192 && g_bt_on[blockIdx.x]) { atomicAdd(&g_m3d_blk[blockIdx.x][4], (unsigned long long)(W).bt_trips); atomicMax(&g_m3d_blk[blockIdx.x][5], (unsigned long long)(W).bt_trips); \
+    atomicAdd(&g_m3d_blk[blockIdx.x][6], (unsigned long long)(W).bt_chunks); atomicAdd(&g_m3d_blk[blockIdx.x][7], (unsigned long long)(W).bt_probes); } } while (0)
+#define M3D_BT_BEGIN() const unsigned long long bt0 = wall_clock64(); const bool bt_on = st->iters == g_m3d_blk_iter && blockIdx.x < 8192; \
+    if (blockIdx.x < 8192 && threadIdx.x == 0) g_bt_on[blockIdx.x] = bt_on ? 1 : 0; \
+    if (bt_on && threadIdx.x < 4) g_m3d_blk[blockIdx.x][4 + threadIdx.x] = 0ull
+#define M3D_BT_END(nsearch) do { if (bt_on && threadIdx.x == 0) { g_m3d_blk[blockIdx.x][0] = bt0; g_m3d_blk[blockIdx.x][1] = wall_clock64(); \
+    g_m3d_blk[blockIdx.x][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+    g_m3d_blk[blockIdx.x][3] = (unsigned long long)(nsearch); } } while (0)
+#else
+#define M3D_BT_BEGIN() ((void)0)
+#define M3D_BT_END(nsearch) ((void)0)
+#define M3D_BT_COUNT(W, f) ((void)0)
+#define M3D_BT_FLUSH(W) ((void)0)
+#endif
+
 #define ICP_THREADS 256
 #define ICP_WAVES (ICP_THREADS / 64)
 // LDS staging capacity per wave (k_icp_lds): buckets of the wave's query box / target points staged
@@ -329,11 +356,13 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-__device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, int& blk) {
+__device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, int& blk, int rot = 0) {
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so with a multiple of 8 pairs the
     // blocks of one pair are kept on one XCD (its L2 then holds one pair's clouds, not all eight).
     const int id = blockIdx.x;
-    if ((n_pairs & 7) == 0) { const int slot = id >> 3; pair = (slot / bpp) * 8 + (id & 7); blk = slot % bpp; }
+    // rot (per handle): concurrent batches on different handles put their k-th pairs on different XCDs — a pair that is slower than
+    // the rest of its batch (a surface close to the sensor) then does not share its XCD with the other batch's slow pair
+    if ((n_pairs & 7) == 0) { const int slot = id >> 3; pair = (slot / bpp) * 8 + ((id + rot) & 7); blk = slot % bpp; }
     else { pair = id / bpp; blk = id % bpp; }
 }
 
@@ -523,14 +552,43 @@ __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
 // sec  = BITS of a lower bound of d2 over every candidate that is not the winner (second-best seen, boxes of pruned rows);
 //        non-negative floats order like their bit patterns, so it is maintained with integer min/max (no canonicalisation
 //        instructions, no NaN cases).
+#ifdef M3D_BLOCKTIME
+struct M3dWalk { unsigned long long bkey; int best; float bound; uint32_t sec; bool any_point; uint32_t bt_trips = 0, bt_chunks = 0, bt_probes = 0; };
+#else
 struct M3dWalk { unsigned long long bkey; int best; float bound; uint32_t sec; bool any_point; };
+#endif
 #define M3D_INF_BITS 0x7F800000u
 __device__ __forceinline__ void m3d_walk_init(M3dWalk& W, float dmax2) {
     W.bkey = ((unsigned long long)M3D_INF_BITS << 32) | 0xFFFFFFFFull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = M3D_INF_BITS; W.any_point = false;
 }
 
+// candidates [t, t1) of the sorted target points against the query: exact argmin on the packed (d2, input index) key
+__device__ __forceinline__ void m3d_scan_range(m3d_gf4 pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit) {
+    for (; t < t1; t += 4) {
+        M3D_BT_COUNT(W, bt_trips);
+        M3D_STAT(sit, 12);
+        M3D_STATW(sit, 14);
+        // four independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
+        const uint32_t last = t1 - 1u - t;   // >= 0
+        uint32_t idx[4]; float4 c4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { idx[j] = t + min((uint32_t)j, last); c4[j] = m3d_ld(pts, idx[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float ex = ux - c4[j].x, ey = uy - c4[j].y, ez = uz - c4[j].z;
+            const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            const uint32_t db = (j == 0 || (uint32_t)j <= last) ? __float_as_uint(dd) : M3D_INF_BITS;
+            const unsigned long long key = ((unsigned long long)db << 32) | __float_as_uint(c4[j].w);   // .w = input index
+            W.sec = min(W.sec, max(db, (uint32_t)(W.bkey >> 32)));   // the loser of (candidate, best so far) is a non-winner
+            const bool better = key < W.bkey;
+            W.bkey = better ? key : W.bkey;
+            W.best = better ? (int)idx[j] : W.best;
+        }
+    }
+}
+
 // rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first
-__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, int vx0, int vy0,
+__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, m3d_gf4 cbox, int vx0, int vy0,
                                               int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
@@ -562,26 +620,26 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         const float gz = m3d_axis_gap(Q.ic[2], vz0 + sz, vz0 + sz, Q.gl[2], Q.gh[2]);
         const float lb2 = gx2 + gy * gy + gz * gz;
         if (lb2 > W.bound) { W.sec = min(W.sec, __float_as_uint(lb2)); if (c1 > c0) M3D_STAT(sit, 11); continue; }
-        const uint32_t t1 = base + c1;
         if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
-        for (uint32_t t = base + c0; t < t1; t += 4) {
-            M3D_STAT(sit, 12);
-            M3D_STATW(sit, 14);
-            // four independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
-            const uint32_t last = t1 - 1u - t;   // >= 0
-            uint32_t idx[4]; float4 c4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) { idx[j] = t + min((uint32_t)j, last); c4[j] = m3d_ld(pts, idx[j]); }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float ex = ux - c4[j].x, ey = uy - c4[j].y, ez = uz - c4[j].z;
-                const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                const uint32_t db = (j == 0 || (uint32_t)j <= last) ? __float_as_uint(dd) : M3D_INF_BITS;
-                const unsigned long long key = ((unsigned long long)db << 32) | __float_as_uint(c4[j].w);   // .w = input index
-                W.sec = min(W.sec, max(db, (uint32_t)(W.bkey >> 32)));   // the loser of (candidate, best so far) is a non-winner
-                const bool better = key < W.bkey;
-                W.bkey = better ? key : W.bkey;
-                W.best = better ? (int)idx[j] : W.best;
+        if (c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
+            m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit);
+        } else {
+            // A crowded row (a surface close to the sensor): chunk by chunk, each chunk's exact box first — the points of a voxel keep
+            // their input (firing) order, which sweeps the surface strip by strip, so all but the one or two chunks around the query
+            // are provably farther than the best so far and are never gathered. A skipped chunk's box distance bounds its points in `sec`.
+            const uint32_t tb = base + c0, te = base + c1;
+            const uint32_t cl = (te - 1u) / M3D_CHUNK;
+            uint32_t c = tb / M3D_CHUNK;
+            float4 bmn = m3d_ld(cbox, 2 * (size_t)c), bmx = m3d_ld(cbox, 2 * (size_t)c + 1);
+            for (; c <= cl; c++) {
+                const float4 mn = bmn, mx = bmx;
+                M3D_BT_COUNT(W, bt_chunks);
+                if (c < cl) { bmn = m3d_ld(cbox, 2 * (size_t)c + 2); bmx = m3d_ld(cbox, 2 * (size_t)c + 3); }   // the next box is in flight while this chunk is looked at
+                const float dx = fmaxf(fmaxf(mn.x - ux, ux - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - uy, uy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - uz, uz - mx.z), 0.f);
+                const float bd = dx * dx + dy * dy + dz * dz;
+                if (bd > W.bound) { W.sec = min(W.sec, __float_as_uint(bd)); M3D_STAT(sit, 15); continue; }
+                m3d_scan_range(pts, max(tb, c * M3D_CHUNK), min(te, (c + 1u) * M3D_CHUNK), ux, uy, uz, W, sit);
+                W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
             }
         }
         W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
@@ -607,7 +665,7 @@ __device__ __forceinline__ int m3d_walk_result(const M3dWalk& W, float dmax2, bo
 }
 
 // ONE QUERY PER LANE (long worklists, first iteration of a level): throughput-shaped
-__device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float ux, float uy, float uz, float dmax2,
+__device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gf4 cbox, m3d_gu32 bigcum, float ux, float uy, float uz, float dmax2,
                                              bool seeded, float dseed, long long& code_out, float& sec, int sit = 0) {
     M3dQuery Q;
     if (!m3d_query_setup(g, ux, uy, uz, Q)) return -1;
@@ -638,12 +696,14 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
                 hi = m3d_ld(tab, 2 * (size_t)slot + 1);
             }
             M3D_STAT(sit, 7);
+            M3D_BT_COUNT(W, bt_probes);
             if (lo.x != key) continue;
             M3D_STAT(sit, 8);
-            m3d_walk_rows(Q, lo, hi, bigcum, pts, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
+            m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
         }
     }
     sec = __uint_as_float(W.sec);
+    M3D_BT_FLUSH(W);
     return m3d_walk_result(W, dmax2, seeded);
 }
 
@@ -656,11 +716,12 @@ struct M3dNnArgs {
     float seed_reach;                  // seeds farther than this many voxel edges are not used (<= 0.99)
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
+    int rot;                           // XCD rotation of the block -> pair map (m3d_map_block)
 };
 
 #define NN_SETUP()                                                                                          \
     int pair, blk;                                                                                          \
-    m3d_map_block(n_pairs, bpp, pair, blk);                                                                 \
+    m3d_map_block(n_pairs, bpp, pair, blk, A.rot);                                                          \
     const M3dJob& J = jobs[pair];                                                                           \
     const M3dPairState* st = A.states + pair;   /* == J.st, without waiting for the job descriptor */      \
     if (st->done || (!first_of_level && st->level_done)) return;                                            \
@@ -669,6 +730,7 @@ struct M3dNnArgs {
     const M3dGrid g = J.tgt.g;                                                                              \
     const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));                          \
     const m3d_gf4 pts = m3d_as_global(J.tgt.pts);                                                           \
+    const m3d_gf4 cbox = m3d_as_global(J.tgt.cbox);                                                         \
     const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);                                                    \
     const m3d_gf4 src = m3d_as_global(J.src);                                                               \
     const float dmax2 = J.dmax2;                                                                            \
@@ -743,7 +805,7 @@ __device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_G
 // One query walked by the 8 lanes of a group (sub = lane & 7 holds one bucket of the 2x2x2): nearest row of every bucket,
 // bound exchange, the other rows, shuffle merge. Every lane of the wave must call it (act = this group has a query);
 // returns the match (>= 0), -1 or M3D_NN_NONE_CACHED on every lane of the group; sec / code for the state arrays.
-__device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gu32 bigcum, float dmax2, bool act, bool seeded,
+__device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gf4 cbox, m3d_gu32 bigcum, float dmax2, bool act, bool seeded,
                                               float vx, float vy, float vz, float dseed, int sub, long long& code, float& sec, int sit) {
     M3dQuery Q;
     M3dWalk W; m3d_walk_init(W, dmax2);
@@ -780,7 +842,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     }
     // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
     if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
-    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
+    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
     {
         float bnd = W.bound;
 #pragma unroll
@@ -788,7 +850,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
         W.bound = bnd;
     }
     // ... and the other rows are mostly discarded by their box distance
-    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
+    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
     // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
     // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
     unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
@@ -820,6 +882,11 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
 #endif
 __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
+    {   // the source's crowded blocks first (they run several times as long as the rest: started last they were the kernel's tail)
+        const uint32_t* ord = J.src_order;
+        if (ord && blk < J.src_nblk) blk = (int)ord[blk];
+    }
+    M3D_BT_BEGIN();
     __shared__ int s_cnt[4];
     __shared__ int s_list[256];          // worklist of the cooperative walk: owner thread | seeded << 8 ...
     __shared__ float s_wu[3][256];       // ... its transformed query ...
@@ -857,17 +924,21 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 #pragma unroll
     for (int w = 0; w < 4; w++) { if (w < wave) offW += s_cnt[w]; nW += s_cnt[w]; }
     if (i < n) { M3D_STAT(sit, 0); if (cls == 1) M3D_STAT(sit, 3); if (cls == 2) M3D_STAT(sit, 4); }
-    if (nW == 0) return;   // block-uniform
+    if (nW == 0) { M3D_BT_END(0); return; }   // block-uniform
     if (tid == 0) M3D_STAT(sit, nW >= A.lane_min ? 5 : 6);
     if (nW >= A.lane_min) {
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
             long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
+            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
             out[i] = m;
             if (m == M3D_NN_NONE_CACHED) cache[i] = code;
             if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
         }
+#ifdef M3D_BLOCKTIME
+        __syncthreads();
+#endif
+        M3D_BT_END(nW);
         return;
     }
     // ---- few queries: LDS worklist, 8 lanes per query ------------------------------------------------------------
@@ -887,13 +958,17 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         const float vx = act ? s_wu[0][q] : 0.f, vy = act ? s_wu[1][q] : 0.f, vz = act ? s_wu[2][q] : 0.f;
         long long code; float sec;
         if (tid == 0) M3D_STAT(sit, 15);
-        const int m = m3d_coop_query(g, tab, pts, bigcum, dmax2, act, (e & 256) != 0, vx, vy, vz, act ? s_wd[q] : 0.f, sub, code, sec, sit);
+        const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, (e & 256) != 0, vx, vy, vz, act ? s_wd[q] : 0.f, sub, code, sec, sit);
         if (act && sub == 0) {
             out[qi] = m;
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
             if (m >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
         }
     }
+#ifdef M3D_BLOCKTIME
+    __syncthreads();
+#endif
+    M3D_BT_END(nW);
 }
 
 // point-to-point: expand the 17 transported sums into the spec's 29 slots (exact integer identities:
@@ -1108,9 +1183,9 @@ template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve) {
+                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot) {
     int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk);
+    m3d_map_block(n_pairs, bpp, pair, blk, rot);
     const M3dJob& J = jobs[pair];
     M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
 
@@ -1242,14 +1317,14 @@ static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, 
     if (variant == 2) {
         // search: one block per 256 queries; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
         int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states;
+        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
         if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
         hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");
         if (k1) (void)hipEventRecord(k1, s);
         const int bpp_a = m3d_acc_blocks(max_n_src);
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve);
+        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot);
+        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot);
         M3D_DBG(s, "k_accumulate_matches");
     } else if (variant == 0) {
         dim3 grid(icp_blocks(max_n_src), n_pairs);

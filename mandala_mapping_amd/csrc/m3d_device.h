@@ -21,6 +21,8 @@
 #define M3D_INVALID_KEY 0xFFFFFFFFu
 #define M3D_IDX_MASK 0x0FFFFFFFu   // pts[].w = bits of the input index (at most 2^28 - 1 points per cloud)
 #define M3D_MAX_TRACE 256
+#define M3D_CHUNK 16               // sorted points per chunk box
+#define M3D_LONG_ROW 24            // a row part with more candidates than this is walked chunk by chunk, boxes first
 
 struct M3dGrid {           // geometry of one voxel grid (host computes it from the exact AABB)
     float mn[3];
@@ -65,6 +67,8 @@ struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* nrm_in;      // the same normals by INPUT index (fused kernel variants 0/1 only)
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
+    const float4* cbox;       // [2 * ceil(n / 16)] exact AABB {min, max} of every 16 consecutive sorted points: lets the search skip most of a
+                              // crowded voxel (a surface a metre from the sensor puts a hundred points into one 10 cm voxel)
     const uint32_t* dyn;      // the level's M3dLevelMeta in the cloud's block (its first 8 words are the dyn counters): derived on the
                               // device by the bucketing pipeline; k_patch_jobs copies the geometry into g (the host never waits for it)
     M3dGrid g;
@@ -98,6 +102,8 @@ struct M3dJob {            // one pair at one level
     double eps_rot2, eps_trans2, pivot_rel_tol;
     M3dPairState* st;
     double* trace;         // [M3D_MAX_TRACE][16] or null
+    int32_t src_nblk;          // entries of src_order: ceil(points of the source, finite or not, / 256)
+    const uint32_t* src_order; // the source's 256-point blocks, most crowded first: k_nn_iter starts its long-running blocks first (or null)
     const uint32_t* src_dyn;   // M3dLevelMeta of the source's finest level (n_src, error state): read by k_patch_jobs
     float dmax;                // max_corr_dist of this level (k_patch_jobs derives the fixed-point exponents from it and the target's lbound)
 };

@@ -45,6 +45,9 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t hcap;
     uint32_t* bigcum;            // [bigcap][8] out
     uint32_t bigcap;
+    float4* cbox;                // [2 * ceil(n / 16)] out: chunk boxes of the sorted points (levels only; null for normal grids)
+    uint32_t* blkw;              // [ceil(n / 256)] workspace: occupied voxels per 256 sorted positions (k_count_cells)
+    uint32_t* order;             // [ceil(n / 256)] out (levels only, else null): the 256-point blocks of the sorted cloud, most crowded first (k_block_order)
     uint32_t* dyn;               // out: the grid's M3dLevelMeta (144 B; its first 8 words are the dyn counters {occupied voxels, hmask, hshift, ...})
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
     float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
@@ -124,6 +127,7 @@ struct M3dNnWork {               // variant-2 workspace, all per pair with the s
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
+    int rot;                     // XCD rotation of the block -> pair map: differs between handles, so concurrent batches do not stack their k-th pairs on one XCD
 };
 // k0/k1 (optional): events recorded immediately before / after the dominant kernel of the iteration (k_nn_iter)
 // seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of

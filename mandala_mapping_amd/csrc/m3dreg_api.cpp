@@ -9,6 +9,7 @@
 #include "../../include/m3dreg.h"
 #include "m3d_kernels.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,8 @@ struct DevLevel {
     M3dBucket* htab = nullptr;
     uint32_t hcap = 0;             // allocated entries (worst case); the used size is grid.hmask + 1
     uint32_t* bigcum = nullptr;
+    float4* cbox = nullptr;        // chunk boxes of the sorted points
+    uint32_t* order = nullptr;     // the cloud's 256-point blocks, most crowded first
     uint32_t bigcap = 0;
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
@@ -105,6 +108,7 @@ struct m3dreg_handle {
     unsigned int seq = 0;
     uint64_t launched_iters = 0, skipped_iters = 0;
     int certify = 1;
+    int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
     int lane_min = 96;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
@@ -222,6 +226,8 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.pts = k.take<float4>(n);
         L.htab = k.take<M3dBucket>(L.hcap);
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
+        L.cbox = k.take<float4>(2 * ((n + M3D_CHUNK - 1) / M3D_CHUNK));
+        L.order = k.take<uint32_t>((n + 255) / 256);
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
         L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
         L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
@@ -258,7 +264,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     // ---- workspace layout (device) + pinned host staging -------------------------------------------------
     std::vector<uint8_t*> staged(k, nullptr);
     std::vector<uint32_t*> aabb(k, nullptr);
-    struct BuildWs { uint32_t *ka, *va, *kb, *vb, *hist, *dyn; DevLevel ng; long long* mom; };
+    struct BuildWs { uint32_t *ka, *va, *kb, *vb, *hist, *dyn, *blkw; DevLevel ng; long long* mom; };
     std::vector<BuildWs> bw(n_builds);
     M3dDecode* d_dec = nullptr; M3dBuild* d_builds = nullptr; uint8_t* zero_lo = nullptr; uint8_t* zero_hi = nullptr;
     auto layout = [&](void* base) -> size_t {
@@ -285,6 +291,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
                 BuildWs& B = bw[i * size_t(grids_per_cloud) + size_t(gidx)];
                 B.ka = w.take<uint32_t>(n); B.va = w.take<uint32_t>(n); B.kb = w.take<uint32_t>(n); B.vb = w.take<uint32_t>(n);
                 B.hist = w.take<uint32_t>(256 * size_t(m3d_sort_tiles(int(n)) + 1));
+                B.blkw = w.take<uint32_t>((n + 255) / 256);
                 if (want_normals && gidx == 0) {   // the normal grid lives in the workspace only
                     DevLevel& G = B.ng;
                     G.hcap = table_cap(n); G.bigcap = uint32_t(n / 65536 + 1);
@@ -353,6 +360,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.grid.leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
             B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
+            B.cbox = is_ng ? nullptr : L.cbox;
+            B.blkw = W.blkw; B.order = is_ng ? nullptr : L.order;
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
             B.nrm_in = c->nrm_in;
@@ -418,7 +427,7 @@ int finish_sync(m3dreg_handle* h, m3dreg_cloud** cl, size_t k) {
 
 M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
     M3dLevelDev d{};
-    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.dyn = L.dyn; d.g = L.grid;
+    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.cbox = L.cbox; d.dyn = L.dyn; d.g = L.grid;
     return d;
 }
 
@@ -504,6 +513,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.certify = h->certify;
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
+    w.rot = h->xcd_rot;
     return w;
 }
 
@@ -537,6 +547,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
             memset(&J, 0, sizeof(J));
             J.src = s->lv[s->n_levels - 1].pts; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
             J.src_dyn = s->lv[s->n_levels - 1].dyn;
+            J.src_order = s->lv[s->n_levels - 1].order; J.src_nblk = (s->n + 255) / 256;
             J.tgt = level_dev(t->lv[l], t->nrm_in);
             J.dmax = P.max_corr_dist[l];
             J.dmax2 = P.max_corr_dist[l] * P.max_corr_dist[l];
@@ -624,6 +635,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
+    { static std::atomic<int> created{0}; h->xcd_rot = (3 * created.fetch_add(1)) & 7; if (const char* v = getenv("M3DREG_XCD_ROT")) h->xcd_rot = atoi(v) & 7; }
     if (const char* v = getenv("M3DREG_LANE_MIN")) { int q = atoi(v); if (q >= 1 && q <= 257) h->lane_min = q; }
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }

@@ -19,7 +19,7 @@ for d in sorted(glob.glob(R+'/gpurun_out/diag_*')):
     for f in glob.glob(d+'/*/*counter_collection.csv'):
         per=collections.defaultdict(dict)
         for r in csv.DictReader(open(f)):
-            if not r['Kernel_Name'].startswith('k_nn_iter'): continue
+            if 'k_nn_iter' not in r['Kernel_Name']: continue
             per[int(r['Dispatch_Id'])][r['Counter_Name']]=float(r['Counter_Value'])
         ids=sorted(per)[-20:]   # the last step's 20 iterations
         for c in per[ids[0]]:

@@ -396,3 +396,35 @@ def test_async_bucketing_no_host_sync_and_device_side_errors(reg, orc):
     with pytest.raises(abi.M3dregError) as ei:
         R.clouds([src, empty])
     assert ei.value.code == abi.ERR_EMPTY_CLOUD
+
+
+def _crowded_cloud(seed, n_bg=5000):
+    """A cloud with crowded voxels: a raster-ordered surface patch (hundreds of points per 10 cm voxel, input order sweeping it strip
+    by strip, like a wall a metre from the sensor), a random-order blob, and a sparse background."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.linspace(0.0, 0.33, 70), np.linspace(0.0, 0.29, 55), indexing="ij")
+    patch = np.stack([1.0 + u.ravel(), 0.5 + v.ravel(), 0.3 + 0.2 * u.ravel()], axis=1) + rng.normal(0, 0.002, (70 * 55, 3))
+    blob = np.array([-1.0, 0.2, 0.7]) + rng.uniform(0, 0.21, (2500, 3))
+    bg = synth.planes_cloud(n_bg, seed + 1, sigma=0.01, size=6.0)
+    return np.concatenate([bg[: n_bg // 2], patch, blob, bg[n_bg // 2:]]).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
+def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
+    """Rows with more than M3D_LONG_ROW candidates are walked chunk by chunk, each chunk's exact box first (k_chunk_boxes): whatever
+    the boxes let the search skip, every per-iteration pose still equals the oracle's exhaustive search bit for bit — raster-ordered
+    points (nearly every chunk skipped), random-ordered points (hardly any), non-finite points in the cloud, seeded and certified
+    later iterations."""
+    tgt = _crowded_cloud(11)
+    Tgt = synth.make_T(synth.rot_z(np.radians(1.5)) @ synth.rot_x(np.radians(-0.8)), np.array([0.03, -0.02, 0.015]))
+    src = synth.apply_T(synth.inv_T(Tgt), _crowded_cloud(12).astype(np.float64)).astype(np.float32)
+    src[::97] = np.nan
+    tgt = tgt.copy(); tgt[5::211] = np.inf
+    p = _params(leaf=0.1, iterations=8, max_corr_dist=0.3, metric=metric, normal_leaf=0.3)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([src, tgt])
+    _check_bucketing(ct, orc.Cloud(p, tgt), 1)
+    T1, st1 = R.align(cs, ct)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True), orc.Cloud(p, tgt, omp=True), trace_cap=16)
+    assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
