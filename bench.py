@@ -44,7 +44,7 @@ def parse():
                     help="hand over HOST PointCloud2 buffers every step (PCIe-inclusive rate; reported in DESIGN.md, never the headline)")
     ap.add_argument("--converge", action="store_true",
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
     ap.add_argument("--queue-depth", type=int, default=2,
                     help="steps QUEUED per stream (the first of them runs, the others wait behind it on the same stream): with 2 a stream never "
@@ -87,8 +87,8 @@ def main():
     # fixed iteration count: eps = 0 never triggers, so every launch of the dominant kernel does full work
     params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE,
                              normal_leaf=0.4, eps_rot=1e-5 if args.converge else 0.0, eps_trans=1e-5 if args.converge else 0.0)
-    # --inflight D handles, each on its own HIP stream; step i runs entirely (bucketing + iterations) on handle i % D.
-    # With D = 2 the host enqueues step i+1 while step i is still iterating, so two 8-pair chains share the GPU:
+    # --inflight D HIP streams; step i runs entirely (bucketing + iterations) on stream i % D.
+    # The host enqueues the next steps while step i is still iterating, so D 8-pair chains share the GPU:
     # every iteration kernel is latency-bound, a second chain fills the idle CUs. Every step still
     # does all of its own work inside the timed region; steps merely overlap in time.
     D = max(1, args.inflight)
@@ -120,7 +120,7 @@ def main():
     def make_clouds(r):
         """decode + AABB + bucketing + normals of this rank's 2B clouds, one batched pipeline on r's stream"""
         if args.from_host:
-            cl = r.clouds(host_msgs)            # host buffers cross PCIe inside the timed region
+            cl = r.clouds(host_msgs, wait=False)   # host buffers (they outlive the step) cross PCIe inside the timed region
         else:
             items = []
             for ds, ns, dt, nt in payloads:
@@ -250,7 +250,7 @@ def main():
             "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter", "concurrent_chains": D, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
         }

@@ -17,7 +17,7 @@
 // -DM3D_STATS: instrumented build (scripts/walk_stats.py): counts, per Gauss-Newton iteration of pair 0's clock, what the
 // search does — one wave-aggregated atomic per event. Never defined in the shipped library.
 #ifdef M3D_STATS
-__device__ unsigned long long g_m3d_stats[64][16];
+__device__ unsigned long long g_m3d_stats[64][24];
 __device__ __forceinline__ void m3d_stat(int it, int what, unsigned int v = 1u) {
     const unsigned long long m = __ballot(1);
     unsigned int tot = v;
@@ -36,8 +36,8 @@ __device__ __forceinline__ void m3d_stat_wave(int it, int what) {   // one count
 #define M3D_STATV(it, what, v) m3d_stat(it, what, v)
 #define M3D_STATW(it, what) m3d_stat_wave(it, what)
 extern "C" hipError_t m3d_debug_read_stats(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_stats), sizeof(unsigned long long) * 64 * 16);
-    if (e == hipSuccess && reset) { static unsigned long long z[64 * 16]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_stats), z, sizeof(z)); }
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_stats), sizeof(unsigned long long) * 64 * 24);
+    if (e == hipSuccess && reset) { static unsigned long long z[64 * 24]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_stats), z, sizeof(z)); }
     return e;
 }
 #else
@@ -600,6 +600,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
     const uint32_t base = lo.y;
     const unsigned long long cumA = ((unsigned long long)hi.y << 32) | hi.x, cumB = ((unsigned long long)hi.w << 32) | hi.z;
     for (int k = k0; k < k1; k++) {
+        M3D_STATW(sit, 21);
         const int sy = (k & 1) ^ ny, sz = (k >> 1) ^ nz;
         if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
         const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
@@ -614,6 +615,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
             c0 = s_first ? bc[s_first - 1] : 0u;
         }
         W.any_point = W.any_point || (c1 > c0);
+        M3D_STATW(sit, 18);
         M3D_STAT(sit, 9);
         if (c1 > c0) M3D_STAT(sit, 10);
         const float gy = m3d_axis_gap(Q.ic[1], vy0 + sy, vy0 + sy, Q.gl[1], Q.gh[1]);
@@ -621,6 +623,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         const float lb2 = gx2 + gy * gy + gz * gz;
         if (lb2 > W.bound) { W.sec = min(W.sec, __float_as_uint(lb2)); if (c1 > c0) M3D_STAT(sit, 11); continue; }
         if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
+        M3D_STATW(sit, 19);
         if (c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
             m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit);
         } else {
@@ -683,6 +686,7 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
         uint32_t slot_n = m3d_hash_slot(key_n, g.hshift);
         uint4 lo_n = m3d_ld(tab, 2 * (size_t)slot_n), hi_n = m3d_ld(tab, 2 * (size_t)slot_n + 1);
         for (int bi = 0; bi < nb; bi++) {
+            M3D_STATW(sit, 16);
             uint4 lo = lo_n, hi = hi_n; const uint32_t key = key_n; uint32_t slot = slot_n;
             const int ox = (bi & nbx) ^ hx, oy = ((bi >> shy) & nby) ^ hy, oz = ((bi >> shz) & nbz) ^ hz;
             if (bi + 1 < nb) {   // software pipelining: the next bucket's entry is in flight while this one is walked
@@ -699,6 +703,7 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
             M3D_BT_COUNT(W, bt_probes);
             if (lo.x != key) continue;
             M3D_STAT(sit, 8);
+            M3D_STATW(sit, 17);
             m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
         }
     }

@@ -13,7 +13,7 @@ B = 8
 params = abi.Params.make(leaf=0.1, iterations=20, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
 reg = binding.Registrar(params, device=0)
 L = binding.lib()
-buf = (C.c_ulonglong * (64 * 16))()
+buf = (C.c_ulonglong * (64 * 24))()
 pairs = []
 for i in range(B):
     src, tgt, _ = synth.config4_pair(i, 3125)
@@ -22,7 +22,7 @@ for i in range(B):
 L.m3d_debug_read_stats(buf, 1)
 reg.align_batch(pairs)
 L.m3d_debug_read_stats(buf, 1)
-a = np.array(buf[:], dtype=np.uint64).reshape(64, 16).astype(np.float64)
+a = np.array(buf[:], dtype=np.uint64).reshape(64, 24).astype(np.float64)
 names = ["queries", "certified", "none-cached", "seeded", "full", "blk lane", "blk coop", "probes", "found", "rows", "rows>0", "pruned>0", "batches", "cands", "wave trips", "coop passes"]
 print(" it " + " ".join(f"{n:>11s}" for n in names))
 for it in range(20):
@@ -30,4 +30,8 @@ for it in range(20):
 s = a[:20].sum(0)
 srch = s[3] + s[4]
 print(f"gather-loop trips per WAVE-slot vs per lane: {s[14]:.0f} wave trips x 64 lanes = {64*s[14]:.0f} lane slots for {s[12]:.0f} lane batches ({100*s[12]/max(1,64*s[14]):.1f} % of the slots useful)")
+w = a[:20]
+print("wave-level executions per iteration (it: bucket-loop trips, found-bucket bodies, row-loop trips, valid-row bodies, rows reaching the scan, gather trips):")
+for it in (0, 1, 3, 5, 8, 12):
+    print(f"  it{it:2d}: {w[it,16]:9.0f} {w[it,17]:9.0f} {w[it,21]:9.0f} {w[it,18]:9.0f} {w[it,19]:9.0f} {w[it,14]:9.0f}")
 print(f"per searched query: probes {s[7]/srch:.2f} found {s[8]/srch:.2f} rows {s[9]/srch:.2f} nonempty {s[10]/srch:.2f} pruned-nonempty {s[11]/srch:.2f} batches {s[12]/srch:.2f} candidates {s[13]/srch:.2f}")
