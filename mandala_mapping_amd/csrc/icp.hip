@@ -1211,9 +1211,9 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     const int n = J.n_src;
     const int* in = match + (size_t)pair * match_stride;
     const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
-    // four queries per trip, every load of a stage issued before the first use: the pass is a chain of
+    // NB queries per trip, every load of a stage issued before the first use: the pass is a chain of
     // dependent gathers (match -> point, normal), so its speed is the number of them in flight
-    constexpr int NB = 4;
+    constexpr int NB = 2;   // (4 in flight: 180 VGPRs = 2 waves per SIMD; 2: 154 = 3 waves, same duration alone, +1.7 % with three chains sharing the GPU)
     const int stride = bpp * ICP_THREADS;
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB];
