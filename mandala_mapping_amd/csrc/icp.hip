@@ -847,15 +847,15 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     }
     // nearest row of every bucket (the home voxel's row among them), then the group agrees on the bound ...
     if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
-    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, 0, 1, sit);
-    {
+#pragma unroll 1
+    for (int phase = 0; phase < 2; phase++) {   // (one copy of the row walk in the code: a rolled loop, not two inlined calls)
+        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit);
+        // ... the group agrees on the bound; the other rows are then mostly discarded by their box distance
         float bnd = W.bound;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
         W.bound = bnd;
     }
-    // ... and the other rows are mostly discarded by their box distance
-    if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, 1, 4, sit);
     // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
     // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
     unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
