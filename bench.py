@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--event-every", type=int, default=7, help="bracket every n-th iteration with hipEvents (n should not divide --iters)")
     ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
     ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
+    ap.add_argument("--pair-offset", type=int, default=None,
+                    help="index of this rank's first scan pair (default rank * pairs-per-gpu): lets one GPU run the shard another rank gets at N > 1")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -104,7 +106,7 @@ def main():
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
     payloads, gts, host_pairs, host_msgs = [], [], [], []
     for i in range(B):
-        src, tgt, Tgt = synth.config4_pair(rank * B + i, args.azimuth)
+        src, tgt, Tgt = synth.config4_pair((rank * B if args.pair_offset is None else args.pair_offset) + i, args.azimuth)
         ms, mt = encode_xyz(src), encode_xyz(tgt)
         ds = torch.frombuffer(bytearray(ms.data), dtype=torch.uint8).to(dev)
         dt = torch.frombuffer(bytearray(mt.data), dtype=torch.uint8).to(dev)
@@ -239,7 +241,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (int64 fixed-point sums, f64 solve)", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4 shard: {B} HDL-32-shaped scan pairs per GPU per step, "
-                                   f"{n_pts} pts/cloud, point-to-plane, leaf 0.1 m, {args.iters} fixed iterations, "
+                                   f"{n_pts} pts/cloud (100000 rays per sweep, as m3d_aggregator publishes them: its +-1 m self-filter box applied), "
+                                   f"point-to-plane, leaf 0.1 m, {args.iters} fixed iterations, "
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step",

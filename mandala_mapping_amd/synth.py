@@ -132,9 +132,12 @@ def _ray_box_enter(o, d, bmin, bmax):
     return np.where(hit, tn, np.inf)
 
 
-def hdl32_scan(pose, n_azimuth, seed, sigma=0.02, rmin=0.4, rmax=100.0):
+def hdl32_scan(pose, n_azimuth, seed, sigma=0.02, rmin=0.4, rmax=100.0, self_filter=None):
     """One sweep of a 32-beam lidar at world pose `pose` (4x4, sensor -> world); returns points in the
-    SENSOR frame, firing order (azimuth-major, 32 beams per azimuth step)."""
+    SENSOR frame, firing order (azimuth-major, 32 beams per azimuth step).
+    self_filter (metres or None): the aggregator's self-filter box — m3d_aggregator keeps a point only when at least one
+    of its coordinates lies outside [-box, +box] (m3d_aggregator.cpp:65-73, node defaults +-1 m at :164-171), so the clouds it
+    publishes never hold the returns of whatever stands within a metre of the unit."""
     rng = np.random.default_rng(seed)
     az = (2.0 * np.pi / n_azimuth) * np.arange(n_azimuth)
     el = np.radians(HDL32_ELEV_DEG)
@@ -149,19 +152,22 @@ def hdl32_scan(pose, n_azimuth, seed, sigma=0.02, rmin=0.4, rmax=100.0):
         t = np.minimum(t, _ray_box_enter(o_w, d_w, bmin, bmax))
     r = t + rng.normal(0.0, sigma, size=t.shape)
     keep = (r >= rmin) & (r <= rmax) & np.isfinite(r)
-    return (d_s[keep] * r[keep, None]).astype(np.float32)
+    pts = (d_s[keep] * r[keep, None]).astype(np.float32)
+    if self_filter is not None:
+        pts = pts[(np.abs(pts) > np.float32(self_filter)).any(axis=1)]
+    return pts
 
 
 def sensor_pose(x, y, yaw_deg, z=SENSOR_HEIGHT):
     return make_T(rot_z(np.radians(yaw_deg)), np.array([x, y, z]))
 
 
-def hdl32_pair(n_azimuth, seed_tgt, seed_src, dx=0.5, dy=0.1, dyaw_deg=3.0, base=(0.0, 0.0, 0.0)):
+def hdl32_pair(n_azimuth, seed_tgt, seed_src, dx=0.5, dy=0.1, dyaw_deg=3.0, base=(0.0, 0.0, 0.0), self_filter=None):
     """(source, target, T_gt) for two sweeps taken at poses P1 (target) and P2 (source)."""
     P1 = sensor_pose(base[0], base[1], base[2])
     P2 = P1 @ make_T(rot_z(np.radians(dyaw_deg)), np.array([dx, dy, 0.0]))
-    tgt = hdl32_scan(P1, n_azimuth, seed_tgt)
-    src = hdl32_scan(P2, n_azimuth, seed_src)
+    tgt = hdl32_scan(P1, n_azimuth, seed_tgt, self_filter=self_filter)
+    src = hdl32_scan(P2, n_azimuth, seed_src, self_filter=self_filter)
     return src, tgt, inv_T(P1) @ P2
 
 
@@ -175,14 +181,18 @@ def config3():
     return hdl32_pair(3125, 100, 101)
 
 
-def config4_pair(k, n_azimuth=3125):
+def config4_pair(k, n_azimuth=3125, self_filter=1.0):
     """k-th loop-closure candidate pair of config 4 (seeds 1000+k): random base pose in the room,
-    random relative motion <= 5 deg / <= 0.5 m (yaw + planar translation dominate, as for a ground robot)."""
+    random relative motion <= 5 deg / <= 0.5 m (yaw + planar translation dominate, as for a ground robot).
+    The clouds are what m3d_aggregator would publish from these sweeps: its +-1 m self-filter box is applied (hdl32_scan).
+    The poses are random, a few stand half a metre from a wall: unfiltered, such a sweep puts a thousand points into one
+    10 cm voxel and a third of the cloud into voxels of more than 32 (self_filter=None reproduces that; tests and
+    scripts/crowded_bench.py keep exercising it)."""
     rng = np.random.default_rng(1000 + k)
     base = (rng.uniform(-6.0, 6.0), rng.uniform(-4.0, 4.0), rng.uniform(-180.0, 180.0))
     dyaw = rng.uniform(-5.0, 5.0)
     dx, dy = rng.uniform(-0.35, 0.35, size=2)
-    return hdl32_pair(n_azimuth, 2000 + 2 * k, 2001 + 2 * k, dx=dx, dy=dy, dyaw_deg=dyaw, base=base)
+    return hdl32_pair(n_azimuth, 2000 + 2 * k, 2001 + 2 * k, dx=dx, dy=dy, dyaw_deg=dyaw, base=base, self_filter=self_filter)
 
 
 def config5(n_scans=20, n_azimuth=3125, dedup=0.02):

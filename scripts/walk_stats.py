@@ -15,7 +15,9 @@ reg = binding.Registrar(params, device=0)
 L = binding.lib()
 buf = (C.c_ulonglong * (64 * 24))()
 pairs = []
-for i in range(B):
+PAIRS = [int(x) for x in os.environ.get('M3D_PAIRS', '').split(',') if x] or list(range(8))
+B = len(PAIRS)
+for i in PAIRS:
     src, tgt, _ = synth.config4_pair(i, 3125)
     cs, ct = reg.clouds([src, tgt])
     pairs.append((cs, ct, None))
