@@ -137,7 +137,7 @@ def main():
             ticket = sharding.gather_results_start([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, cdev)
             drain_gather()
             last["pending_gather"] = ticket
-        last["T"], last["st"], last["clouds"] = T, st, clouds
+        last["T"], last["st"] = T, st
 
     def drain_gather():
         if last.get("pending_gather") is not None:
@@ -154,9 +154,10 @@ def main():
         host_log.append(("enq", i, 1e3 * (tb - ta), 1e3 * (time.perf_counter() - tb)))
         return clouds
 
-    def run_steps(k):
-        """k steps, at most D in flight: step i+D-1 is enqueued (its bucketing runs, its iterations queue up on its own
-        stream) before the host waits for step i"""
+    def run_steps(k, keep_clouds=False):
+        """k steps, at most D * Q enqueued: a step's bucketing and iterations queue up on its stream before the host waits for
+        an earlier one. A finished step's clouds go back to their handle's block pool BEFORE the next step is enqueued on it,
+        so the pools reach their steady state with the first step of every handle (no hipMalloc inside the timed region)."""
         pending, nxt = [], 0
         while nxt < min(len(regs), k):
             pending.append((nxt, enqueue(nxt))); nxt += 1
@@ -167,13 +168,17 @@ def main():
             T, st = regs[idx % len(regs)].batch_wait(B)
             host_log.append(("wait", idx, 1e3 * (time.perf_counter() - ta), 0.0))
             finish(T, st, clouds)
+            if not (keep_clouds and i == k - 1):
+                for s_, t_ in clouds:
+                    s_.free(); t_.free()
+                clouds = None
             if nxt < k:
                 pending.append((nxt, enqueue(nxt))); nxt += 1
         drain_gather()   # the last step's poses are on every rank before the timed region ends
         return clouds
 
     def step():
-        return run_steps(1)
+        return run_steps(1, keep_clouds=True)
 
     # algorithmic bytes of one launch of the dominant kernel, from the real clouds
     clouds0 = step()

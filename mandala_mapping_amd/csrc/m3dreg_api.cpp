@@ -164,6 +164,8 @@ int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
         return M3DREG_OK;
     }
     void* p = nullptr;
+    static const bool dbg_pool = getenv("M3DREG_DEBUG_POOL") != nullptr;
+    if (dbg_pool) fprintf(stderr, "[m3dreg] pool miss: hipMalloc(%zu) (%zu blocks cached)\n", bytes, h->pool.size());
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {   // make room: drop the cache and retry once
         hipStreamSynchronize(h->stream);
