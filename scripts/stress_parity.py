@@ -26,7 +26,7 @@ for case in range(n_cases):
     k_pairs = int(rng.integers(1, 10))
     pairs, refs = [], []
     for k in range(k_pairs):
-        n_az = int(rng.integers(100, 700))
+        n_az = int(rng.integers(100, 700)) if rng.integers(0, 4) else int(rng.integers(1500, 3200))   # a quarter at full sweep density (crowded voxels near walls)
         src, tgt, Tgt = synth.hdl32_pair(n_az, int(rng.integers(1, 10**6)), int(rng.integers(1, 10**6)), dx=float(rng.uniform(-0.4, 0.4)),
                                          dy=float(rng.uniform(-0.3, 0.3)), dyaw_deg=float(rng.uniform(-4, 4)),
                                          base=(float(rng.uniform(-5, 5)), float(rng.uniform(-3, 3)), float(rng.uniform(-180, 180))))
@@ -35,7 +35,7 @@ for case in range(n_cases):
         if rng.integers(0, 4) == 0:
             tgt = tgt[: max(50, len(tgt) // int(rng.integers(2, 9)))]
         T0 = synth.perturb(Tgt, rng, 1.0, 0.1) if rng.integers(0, 2) else np.eye(4)
-        cs, ct = R.clouds([src, tgt])
+        cs, ct = R.clouds([src, tgt], wait=bool(rng.integers(0, 2)))   # half of the clouds through the enqueue-only bucketing
         pairs.append((cs, ct, T0))
         refs.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=64))
     Tb, stb = R.align_batch(pairs)
