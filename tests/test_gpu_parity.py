@@ -428,3 +428,35 @@ def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
     T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True), orc.Cloud(p, tgt, omp=True), trace_cap=16)
     assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
     _same_stats(st1, st2)
+
+
+def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
+    """The bench's pipeline: several handles share ONE HIP stream, each holds a batch — bucketing (enqueue-only) and iterations of
+    batch k+1 are queued behind batch k, nothing is waited for until every batch has been enqueued, and clouds go back to their
+    handle's pool and are re-used while other batches are still in flight. Every pose must equal the oracle's, bit for bit."""
+    import ctypes as C
+    p = _params(leaf=0.2, iterations=7, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    first = reg.Registrar(p)
+    stream = C.c_void_p(first.stream())
+    handles = [first] + [reg.Registrar(p, stream=stream) for _ in range(2)]
+    data, refs = [], []
+    for k in range(6):
+        src, tgt, Tgt = synth.hdl32_pair(300 + 60 * k, 40 + k, 50 + k, dx=0.15, dy=-0.1, dyaw_deg=1.5 + 0.3 * k)
+        if k == 4:
+            src = src.copy(); src[::29] = np.nan
+        data.append((src, tgt))
+        refs.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+    for rnd in range(2):                                       # the second round runs on recycled blocks
+        pending = []
+        for b in range(3):                                     # batch b = pairs 2b, 2b+1 on handle b; all three enqueued before any wait
+            h = handles[b]
+            cl = h.clouds([data[2 * b][0], data[2 * b][1], data[2 * b + 1][0], data[2 * b + 1][1]], wait=False)
+            h.align_batch_async(h._pairs([(cl[0], cl[1], None), (cl[2], cl[3], None)]), 2)
+            pending.append((h, cl))
+        for b, (h, cl) in enumerate(pending):
+            T, st = h.batch_wait(2)
+            for j in range(2):
+                assert np.array_equal(T[j], refs[2 * b + j][0]), (rnd, b, j)
+                _same_stats(st[j], refs[2 * b + j][1])
+            for c in cl:
+                c.free()
