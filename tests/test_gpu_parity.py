@@ -437,7 +437,7 @@ def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
     import ctypes as C
     p = _params(leaf=0.2, iterations=7, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
     first = reg.Registrar(p)
-    stream = C.c_void_p(first.stream())
+    stream = C.c_void_p(first.stream)
     handles = [first] + [reg.Registrar(p, stream=stream) for _ in range(2)]
     data, refs = [], []
     for k in range(6):
