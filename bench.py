@@ -218,6 +218,22 @@ def main():
         c, d = r.profile_read(0, reset=True)       # search + reduction of one linearisation
         launches, kern_ms, iters_timed, iter_ms = launches + a, kern_ms + b, iters_timed + c, iter_ms + d
         r.profile_enable(False)
+    # After the timed region, untimed: the same kernel with NOTHING else on the GPU (one step, one handle, every launch bracketed).
+    # With several chains sharing the GPU a launch takes longer although more launches complete per second; this is the kernel's own
+    # duration, reported beside the contract's figure as roofline.alone.
+    alone_ms = 0.0
+    if not args.no_events and world == 1:
+        last_T, last_st = last.get("T"), last.get("st")
+        regs[0].profile_enable(True, every=1)
+        regs[0].profile_read(1, reset=True)
+        c_ = make_clouds(regs[0])
+        regs[0].align_batch_async(regs[0]._pairs([(s_, t_, None) for s_, t_ in c_]), B)
+        regs[0].batch_wait(B)
+        a_, b_ = regs[0].profile_read(1, reset=True)
+        regs[0].profile_enable(False)
+        alone_ms = b_ / max(1, a_)
+        del c_
+        last["T"], last["st"] = last_T, last_st
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
@@ -260,7 +276,10 @@ def main():
             "iterations_executed_pair0": int(last["st"][0].iterations),
             "roofline": {"bound": "hbm", "kernel": "k_nn_iter", "concurrent_chains": D, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches},
+                         "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches,
+                         "alone": ({"avg_launch_ms": alone_ms, "achieved": alg_bytes / (alone_ms / 1e3) / 1e9, "frac": alg_bytes / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "the same kernel with nothing else on the GPU: one extra, untimed step after the timed region, every launch bracketed"}
+                                   if alone_ms > 0 else None)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, host_pairs, args.iters, args.cpu_threads)
