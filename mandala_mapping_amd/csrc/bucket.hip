@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restric
 // walk several times as many candidates as the rest. Started last, such blocks were the tail that set k_nn_iter's duration; started
 // first, they run while the other blocks fill the machine. One workgroup per grid ranks the blocks by occupied voxels, ascending.
 #define M3D_ORDER_CAP 8192
-__global__ __launch_bounds__(1024) void k_block_order(const M3dBuild* __restrict__ builds) {
+__global__ __launch_bounds__(512) void k_block_order(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.x];
     if (!B.order) return;
     const int nblk = (B.n + 255) / 256;
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(1024) void k_block_order(const M3dBuild* __restrict
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
         const uint32_t wb = w[b];
         int rank = 0;
+#pragma unroll 8
         for (int o = 0; o < nblk; o++) rank += (w[o] < wb || (w[o] == wb && o < b)) ? 1 : 0;
         B.order[rank] = (uint32_t)b;
     }
@@ -431,19 +432,33 @@ __global__ __launch_bounds__(1024) void k_block_order(const M3dBuild* __restrict
 __global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.cbox) return;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // four lanes per chunk, four points each (a lane's 16-B loads and its neighbours' fall into the same cache lines), xor-shuffle merge
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = t >> 2, sub = t & 3;
     const int nv = B.grid.n_valid;
-    if (c * M3D_CHUNK >= nv) return;
-    const int j1 = min((c + 1) * M3D_CHUNK, nv);
-    float4 p = B.pts[c * M3D_CHUNK];
-    float mnx = p.x, mny = p.y, mnz = p.z, mxx = p.x, mxy = p.y, mxz = p.z;
-    for (int j = c * M3D_CHUNK + 1; j < j1; j++) {
-        p = B.pts[j];
-        mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
-        mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+    const bool chunk_ok = c * M3D_CHUNK < nv;              // uniform over the 4 lanes of a chunk
+    const float inf = __uint_as_float(0x7F800000u);
+    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
+    if (chunk_ok) {
+#pragma unroll
+        for (int k = 0; k < M3D_CHUNK / 4; k++) {
+            const int j = c * M3D_CHUNK + 4 * k + sub;
+            if (j < nv) {
+                const float4 p = B.pts[j];
+                mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+                mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+            }
+        }
     }
-    B.cbox[2 * c] = make_float4(mnx, mny, mnz, 0.f);
-    B.cbox[2 * c + 1] = make_float4(mxx, mxy, mxz, 0.f);
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {   // every lane of the wave takes part (lanes of finished chunks carry +-inf)
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+    }
+    if (chunk_ok && sub == 0) {
+        B.cbox[2 * c] = make_float4(mnx, mny, mnz, 0.f);
+        B.cbox[2 * c + 1] = make_float4(mxx, mxy, mxz, 0.f);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bucket_big(const M3dBuild* __restrict__ builds) {
@@ -742,7 +757,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
-    hipLaunchKernelGGL(k_block_order, dim3(n_builds), dim3(1024), 0, s, d_builds);
+    hipLaunchKernelGGL(k_block_order, dim3(n_builds), dim3(512), 0, s, d_builds);   // (391 blocks per 100 k-point cloud: 1024 threads only crowd the SIMDs)
     M3D_DBG(s, "k_block_order");
     hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_clear_table");
@@ -752,7 +767,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_bucket_counts");
     hipLaunchKernelGGL(k_bucket_big, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_bucket_big");
-    hipLaunchKernelGGL(k_chunk_boxes, dim3((blocks + M3D_CHUNK - 1) / M3D_CHUNK, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_chunk_boxes, dim3((4 * blocks + M3D_CHUNK - 1) / M3D_CHUNK, n_builds), dim3(256), 0, s, d_builds);   // 4 lanes per chunk
     M3D_DBG(s, "k_chunk_boxes");
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
