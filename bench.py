@@ -306,9 +306,54 @@ def cpu_baseline(params, host_pairs, iters, threads=0):
         if time.perf_counter() - t0 > 20.0:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "registrations/s", "cores": threads, "kind": "port",
+    kd = None
+    try:
+        kd = cpu_kdtree_baseline(params, host_pairs[:2], iters, threads, orc)
+    except Exception as e:   # scipy missing on the box: the figure is optional
+        kd = {"error": repr(e)}
+    return {"value": done / dt, "unit": "registrations/s", "cores": threads, "kind": "port", "kdtree": kd,
             "sample": f"{done} of the same scan pairs (bucketing+normals of both clouds + {iters} iterations each), "
                       f"oracle/m3d_oracle.c built with -O2 -fopenmp, {threads} threads"}
+
+
+def cpu_kdtree_baseline(params, host_pairs, iters, threads, orc):
+    """What pcl::IterativeClosestPoint with a point-to-plane estimator would do (the reference includes pcl/registration/icp.h but
+    never calls it: m3d_calibration_sa.cpp:22): k-d tree on the target (scipy.spatial.cKDTree, all cores for the queries), 1-NN per
+    source point with the max-distance reject, linearised point-to-plane Gauss-Newton in float64. The target normals are the
+    oracle's (its bucketing is inside the timed region). Not bit-comparable with anything: a second CPU figure beside the port."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    dmax = float(params.max_corr_dist[0])
+    done, t0 = 0, time.perf_counter()
+    for src, tgt in host_pairs:
+        ct = orc.Cloud(params, tgt, omp=True)
+        e = ct.export(0)
+        q_xyz, q_nrm = e["sorted_xyz"].astype(np.float64), e["normals"].astype(np.float64)
+        tree = cKDTree(q_xyz)
+        p = src[np.isfinite(src).all(axis=1)].astype(np.float64)
+        T = np.eye(4)
+        for _ in range(iters):
+            u = p @ T[:3, :3].T + T[:3, 3]
+            d, j = tree.query(u, k=1, distance_upper_bound=dmax, workers=threads)
+            ok = np.isfinite(d)
+            n = q_nrm[j[ok]]
+            ok2 = (n * n).sum(1) > 0.5
+            uu, qq, nn = u[ok][ok2], q_xyz[j[ok]][ok2], n[ok2]
+            r = ((uu - qq) * nn).sum(1)
+            J = np.concatenate([np.cross(uu, nn), nn], axis=1)
+            x = np.linalg.solve(J.T @ J, -J.T @ r)
+            w, v = x[:3], x[3:]
+            th = np.linalg.norm(w)
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            R = np.eye(3) + (np.sin(th) / th if th > 1e-12 else 1.0) * K + ((1 - np.cos(th)) / th ** 2 if th > 1e-12 else 0.5) * (K @ K)
+            D = np.eye(4); D[:3, :3] = R; D[:3, 3] = v
+            T = D @ T
+        done += 1
+        if time.perf_counter() - t0 > 15.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "registrations/s", "cores": threads,
+            "sample": f"{done} of the same scan pairs, scipy cKDTree 1-NN ({threads} workers) + point-to-plane Gauss-Newton in numpy, {iters} iterations each"}
 
 
 if __name__ == "__main__":
