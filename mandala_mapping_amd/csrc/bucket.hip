@@ -598,9 +598,14 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= B.dyn[5]) return;
-    const int j = (int)voxel_head_list(B)[v];   // first sorted position of the voxel (a finite point)
+    // three lanes per occupied voxel, one z layer of the 27-voxel neighbourhood each (the sums are exact integers: any split gives the
+    // same bits), merged with two shuffles; lane 0 of the triple then solves. 192 of a block's 256 lanes form 64 triples.
+    const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int trip = tl / 3, part = tl - 3 * trip;                  // lanes 63 of every wave: no triple
+    const bool lane_ok = tl < 63;
+    const uint32_t v = (blockIdx.x * 4u + (uint32_t)wv) * 21u + (uint32_t)trip;
+    const bool act = lane_ok && v < B.dyn[5];
+    const int j = act ? (int)voxel_head_list(B)[v] : 0;   // first sorted position of the voxel (a finite point)
     const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const long long* mom = B.mom;
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
               icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    for (int dz = -1; dz <= 1; dz++) { const int cz = icz + dz; if (cz < 0 || cz >= g.dims[2]) continue;
+    { const int dz = part - 1; const int cz = icz + dz; if (act && cz >= 0 && cz < g.dims[2]) {
     for (int dy = -1; dy <= 1; dy++) { const int cy = icy + dy; if (cy < 0 || cy >= g.dims[1]) continue;
     for (int dx = -1; dx <= 1; dx++) { const int cx = icx + dx; if (cx < 0 || cx >= g.dims[0]) continue;
         const uint2 vr = m3d_find_voxel(L, cx, cy, cz);
@@ -627,7 +632,16 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
         q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
         q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
         q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
-    }}}
+    }}}}
+    {   // lane 3t collects the sums of lanes 3t + 1, 3t + 2 (every lane of the wave shuffles)
+        long long* acc[10] = { &k, &s0, &s1, &s2, &q0, &q1, &q2, &q3, &q4, &q5 };
+#pragma unroll
+        for (int a = 0; a < 10; a++) {
+            const long long a1 = __shfl_down(*acc[a], 1), a2 = __shfl_down(*acc[a], 2);
+            *acc[a] += a1 + a2;
+        }
+    }
+    if (!act || part != 0) return;
     do {
         if (k < (long long)min_pts || k < 3) break;
         const double inv = 1.0 / (double)k;
@@ -772,7 +786,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);
+        hipLaunchKernelGGL(k_normals, dim3((max_n + 83) / 84, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);   // 84 voxels per block (3 lanes each)
         M3D_DBG(s, "k_normals");
         hipLaunchKernelGGL(k_spread_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_spread_normals");
