@@ -171,8 +171,9 @@ int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dr
  * iteration covers the whole batch (grid.y = pair). out_T: 16*n_pairs floats. */
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T,
                        m3dreg_stats* stats);
-/* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. Used by bench.py to time
- * the device work with HIP events on the handle's stream. */
+/* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. A handle holds the state of ONE batch: a second
+ * m3dreg_align_batch_async before the wait is refused (M3DREG_ERR_INVALID_ARG) — to queue batches behind each other, give
+ * several handles the same stream (m3dreg_create's `stream`), as bench.py does. */
 int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs);
 int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats);
 int m3dreg_synchronize(m3dreg_handle* h);

@@ -762,6 +762,7 @@ int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
 
 int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
+    if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch_async: a batch is pending on this handle (a handle holds the state of ONE batch: call m3dreg_batch_wait, or use another handle on the same stream)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_batch(h, n_pairs);
     if (rc) return rc;

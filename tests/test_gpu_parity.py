@@ -460,3 +460,20 @@ def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
                 _same_stats(st[j], refs[2 * b + j][1])
             for c in cl:
                 c.free()
+
+
+def test_a_handle_holds_one_batch(reg):
+    """m3dreg_align_batch_async twice without m3dreg_batch_wait would overwrite the first batch's pinned descriptors in flight: refused."""
+    p = _params(leaf=0.25, iterations=3, max_corr_dist=0.5, metric=abi.POINT_TO_POINT)
+    R = reg.Registrar(p)
+    src, tgt, _ = synth.config1(3000)
+    cs, ct = R.clouds([src, tgt])
+    arr = R._pairs([(cs, ct, None)])
+    R.align_batch_async(arr, 1)
+    with pytest.raises(abi.M3dregError) as ei:
+        R.align_batch_async(arr, 1)
+    assert ei.value.code == abi.ERR_INVALID_ARG
+    T, st = R.batch_wait(1)
+    R.align_batch_async(arr, 1)
+    T2, _ = R.batch_wait(1)
+    assert np.array_equal(T, T2)
