@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
     ap.add_argument("--pair-offset", type=int, default=None,
                     help="index of this rank's first scan pair (default rank * pairs-per-gpu): lets one GPU run the shard another rank gets at N > 1")
+    ap.add_argument("--pair-list", default=None, help="comma-separated indices of this rank's scan pairs (diagnostics: run any shard of any N on one GPU)")
+    ap.add_argument("--shard", default="lpt", choices=["lpt", "consecutive"],
+                    help="N > 1: which pairs a rank gets. lpt = the world_size * pairs-per-gpu pairs dealt longest-processing-time-first by an "
+                         "a-priori cost estimate (synth.crowdedness of both clouds), the same number to every rank (SURVEY 8d config 4: "
+                         "LPT-sharded); consecutive = rank r takes pairs r * B ... r * B + B - 1")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline leg (0 = min(cores, 64))")
     return ap.parse_args()
 
@@ -105,8 +110,21 @@ def main():
 
     # ---- synthetic workload: this rank's B pairs, resident in HBM as PointCloud2 payloads -------------
     payloads, gts, host_pairs, host_msgs = [], [], [], []
+    if args.pair_list is not None:
+        pair_ids, generated = [int(x) for x in args.pair_list.split(",")], {}
+        assert len(pair_ids) == B, "--pair-list must name --pairs-per-gpu pairs"
+    elif args.pair_offset is not None:
+        pair_ids, generated = [args.pair_offset + i for i in range(B)], {}
+    elif world > 1 and args.shard == "lpt":
+        # every rank generates all pairs and derives the same assignment: no communication, deterministic
+        generated = {k: synth.config4_pair(k, args.azimuth) for k in range(world * B)}
+        costs = [synth.crowdedness(generated[k][0]) + synth.crowdedness(generated[k][1]) for k in range(world * B)]
+        pair_ids = sharding.lpt_assign(costs, world, capacity=B)[rank]
+        generated = {k: generated[k] for k in pair_ids}
+    else:
+        pair_ids, generated = [rank * B + i for i in range(B)], {}
     for i in range(B):
-        src, tgt, Tgt = synth.config4_pair((rank * B if args.pair_offset is None else args.pair_offset) + i, args.azimuth)
+        src, tgt, Tgt = generated[pair_ids[i]] if pair_ids[i] in generated else synth.config4_pair(pair_ids[i], args.azimuth)
         ms, mt = encode_xyz(src), encode_xyz(tgt)
         ds = torch.frombuffer(bytearray(ms.data), dtype=torch.uint8).to(dev)
         dt = torch.frombuffer(bytearray(mt.data), dtype=torch.uint8).to(dev)
@@ -134,7 +152,7 @@ def main():
         if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI).
             # It is enqueued here and read one step later (or at the end of the timed region): the ranks exchange every
             # step's results without falling into lock-step at every step.
-            ticket = sharding.gather_results_start([rank * B + i for i in range(B)], T, [x.status for x in st], world * B, dist, cdev)
+            ticket = sharding.gather_results_start(pair_ids, T, [x.status for x in st], world * B, dist, cdev)
             drain_gather()
             last["pending_gather"] = ticket
         last["T"], last["st"] = T, st
@@ -270,7 +288,7 @@ def main():
                                    f"point-to-plane, leaf 0.1 m, {args.iters} fixed iterations, "
                                    "bucketing+normals of both clouds inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
-                       "parallelism": f"pairs sharded over {world} GPU(s), one all_gather of poses per step",
+                       "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step",
                        "overlap": ("none (serial steps)" if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
                                   (f"; {Q} steps queued per stream" if Q > 1 else "")},
             "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),

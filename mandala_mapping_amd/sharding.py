@@ -10,8 +10,9 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 
-def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = None) -> List[List[int]]:
+def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = None, capacity: int = None) -> List[List[int]]:
     """Longest-processing-time-first assignment of work items to ranks.
+    capacity (optional): at most this many items per rank (weak scaling: every GPU gets the same number of pairs per step).
 
     costs[i]: estimated cost of pair i (N_src + N_tgt is a good proxy: both the bucketing and the NN search
     are linear in the cloud sizes). groups[i] (optional): pairs with the same group id share a target
@@ -28,7 +29,10 @@ def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = Non
     load = [0.0] * n_ranks
     out: List[List[int]] = [[] for _ in range(n_ranks)]
     for u in order:
-        r = min(range(n_ranks), key=lambda k: (load[k], k))
+        fits = [k for k in range(n_ranks) if capacity is None or len(out[k]) + len(u) <= capacity]
+        if not fits:
+            raise ValueError("lpt_assign: the items do not fit the ranks' capacity")
+        r = min(fits, key=lambda k: (load[k], k))
         out[r].extend(u)
         load[r] += sum(costs[i] for i in u)
     return [sorted(x) for x in out]

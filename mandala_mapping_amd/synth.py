@@ -195,6 +195,16 @@ def config4_pair(k, n_azimuth=3125, self_filter=1.0):
     return hdl32_pair(n_azimuth, 2000 + 2 * k, 2001 + 2 * k, dx=dx, dy=dy, dyaw_deg=dyaw, base=base, self_filter=self_filter)
 
 
+def crowdedness(xyz, leaf=0.1):
+    """Mean population of the voxel a point of the cloud lies in (sum of squared voxel counts / points): what a query meets in its
+    home voxel. Single registrations of the config-4 pairs take 0.72 ... 1.40 ms on an MI355X and this number explains it
+    (correlation 0.9 over 19 measured pairs): the cost estimate the bench shards the pairs by."""
+    c = xyz[np.isfinite(xyz).all(axis=1)]
+    v = np.floor((c - c.min(0)) / np.float32(leaf)).astype(np.int64)
+    _, cnt = np.unique(v[:, 0] + 8192 * (v[:, 1] + 8192 * v[:, 2]), return_counts=True)
+    return float((cnt.astype(np.float64) ** 2).sum() / max(1, len(c)))
+
+
 def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
     """(live scan, map, T_gt, T_init): map = n_scans sweeps along a 10 m straight trajectory merged in the
     frame of the first sweep and de-duplicated on a `dedup` grid (~2 M points at the defaults); live scan =

@@ -98,3 +98,17 @@ def test_two_rank_gather_over_gloo():
     src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(1200 + 300 * k, 80 + k)).astype(np.float32)
     T, _, _ = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))
     assert np.array_equal(T0[k], T)
+
+
+def test_lpt_assignment_with_capacity():
+    """Weak scaling: every rank gets the same number of pairs; the expensive ones are spread first."""
+    costs = [9.0, 1.0, 1.0, 1.0, 8.0, 1.0, 1.0, 7.0]
+    sh = sharding.lpt_assign(costs, 2, capacity=4)
+    assert sorted(sum(sh, [])) == list(range(8)) and [len(x) for x in sh] == [4, 4]
+    assert 0 in sh[0] and 4 in sh[1]                       # the two most expensive pairs never share a rank
+    loads = sorted(sum(costs[i] for i in x) for x in sh)
+    assert loads == [12.0, 17.0]                            # the best any 4 + 4 split of these costs can do
+    assert sharding.lpt_assign(costs, 2, capacity=4) == sh  # deterministic: every rank derives the same table
+    import pytest
+    with pytest.raises(ValueError):
+        sharding.lpt_assign(costs, 2, capacity=3)
