@@ -477,3 +477,25 @@ def test_a_handle_holds_one_batch(reg):
     R.align_batch_async(arr, 1)
     T2, _ = R.batch_wait(1)
     assert np.array_equal(T, T2)
+
+
+def test_config4_shard_full_size_properties(reg):
+    """BASELINE config 4 at full size, one GPU's shard (8 pairs x 100 000 rays, clouds as the aggregator publishes them): properties that
+    need no oracle run — the batch equals the eight single registrations bit for bit, in any batch order, through the enqueue-only
+    bucketing as well; every pose lands on the generator's ground truth."""
+    p = _params(leaf=0.1, iterations=20, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    data = [synth.config4_pair(k) for k in range(8)]
+    flat = [c for src, tgt, _ in data for c in (src, tgt)]
+    cl = R.clouds(flat, wait=False)
+    pairs = [(cl[2 * k], cl[2 * k + 1], None) for k in range(8)]
+    Tb, stb = R.align_batch(pairs)
+    Tr, _ = R.align_batch(pairs[::-1])
+    assert np.array_equal(Tb, Tr[::-1])                                     # batch composition / order never changes a bit
+    for k in (0, 4, 7):                                                     # pair 4 stands next to an obstacle (crowded voxels)
+        cs, ct = R.clouds([data[k][0], data[k][1]])                         # synchronous bucketing, registered alone
+        T1, st1 = R.align(cs, ct)
+        assert np.array_equal(T1, Tb[k]) and st1.n_corr == stb[k].n_corr, k
+    for k in range(8):
+        rot, tra = synth.pose_error(Tb[k], data[k][2])
+        assert stb[k].status == abi.MAX_ITERATIONS and rot < 0.1 and tra < 0.006, (k, rot, tra)
