@@ -117,7 +117,7 @@ class GridInfo(C.Structure):
 
 class CloudDesc(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("point_step", C.c_size_t), ("off_x", C.c_size_t), ("off_y", C.c_size_t),
-                ("off_z", C.c_size_t), ("data_is_device", C.c_int32)]
+                ("off_z", C.c_size_t), ("data_is_device", C.c_int32), ("source_only", C.c_int32)]
 
 
 class PointField(C.Structure):   # m3dreg_point_field

@@ -249,7 +249,7 @@ class Registrar:
         self._check(lib().m3dreg_cloud_create(self._h, C.c_void_p(dev_ptr), n, point_step, offsets[0], offsets[1], offsets[2], 1, C.byref(p)), "cloud_create(device)")
         return Cloud(self, p, n)
 
-    def clouds_from_device(self, items, wait=True):
+    def clouds_from_device(self, items, wait=True, source_only=None):
         """items: list of (device address, n[, point_step, (ox, oy, oz)]) -> list of Clouds, bucketed in ONE batch.
         wait=False: m3dreg_cloud_create_batch_async — enqueue only, no host synchronisation; a cloud in error (no finite point,
         grid too large) then ends its registrations with status BAD_CLOUD and Cloud.status() names the error."""
@@ -260,12 +260,13 @@ class Registrar:
             off = it[3] if len(it) > 3 else (0, 4, 8)
             descs[i].data, descs[i].n, descs[i].point_step = it[0], it[1], step
             descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = off[0], off[1], off[2], 1
+            descs[i].source_only = 1 if (source_only is not None and source_only[i]) else 0   # no normals for clouds that are only ever sources
         out = (C.c_void_p * k)()
         fn = lib().m3dreg_cloud_create_batch if wait else lib().m3dreg_cloud_create_batch_async
         self._check(fn(self._h, descs, k, out), "cloud_create_batch")
         return [Cloud(self, C.c_void_p(out[i]), items[i][1]) for i in range(k)]
 
-    def clouds(self, arrays, wait=True):
+    def clouds(self, arrays, wait=True, source_only=None):
         """arrays: list of float32 [n,3] arrays / PointCloud2 messages -> list of Clouds, bucketed in ONE batch (wait: see
         clouds_from_device; the host buffers must stay alive until the copies have run when wait=False)."""
         msgs = [to_little_endian(encode_xyz(a) if isinstance(a, np.ndarray) else a) for a in arrays]
@@ -276,6 +277,7 @@ class Registrar:
             ox, oy, oz = m.xyz_offsets()
             descs[i].data, descs[i].n, descs[i].point_step = bufs[i].ctypes.data, m.n, m.point_step
             descs[i].off_x, descs[i].off_y, descs[i].off_z, descs[i].data_is_device = ox, oy, oz, 0
+            descs[i].source_only = 1 if (source_only is not None and source_only[i]) else 0
         out = (C.c_void_p * k)()
         fn = lib().m3dreg_cloud_create_batch if wait else lib().m3dreg_cloud_create_batch_async
         self._check(fn(self._h, descs, k, out), "cloud_create_batch")

@@ -109,7 +109,7 @@ __global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int g
         if (err) break;
         B.grid = g;
         const int kb = bits[0] + bits[1] + bits[2] + 3;
-        B.sort_passes = (n_valid != B.n) ? 4 : (kb + 7) / 8;   // the 0xFFFFFFFF keys of non-finite points must end up last
+        B.sort_passes = (B.n == 0) ? 0 : ((n_valid != B.n) ? 4 : (kb + 7) / 8);   // the 0xFFFFFFFF keys of non-finite points must end up last; n = 0: a build the host switched off
         M->g = g; M->lbound = lbound;
         for (int a = 0; a < 3; a++) { M->mx[a] = mx[a]; M->bits[a] = bits[a]; }
     }

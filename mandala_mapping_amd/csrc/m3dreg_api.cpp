@@ -237,7 +237,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     return (k.off + 255) & ~size_t(255);
 }
 
-struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned;
+struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned; bool src_only = false;
                     bool generic = false; size_t width = 0, row_step = 0, data_bytes = 0; bool f64[3] = { false, false, false }; bool bigendian = false; };
 
 // Bucket a batch of clouds: one decode launch, one bucketing pipeline for every grid of every cloud, NO host synchronisation:
@@ -349,7 +349,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
-        c->has_normals = want_normals;
+        const bool no_normals = in[i].src_only;   // a source-only cloud: sorted, no normal grid, no normals
+        c->has_normals = want_normals && !no_normals;
         for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
             const size_t bi = i * size_t(grids_per_cloud) + size_t(gidx);
             BuildWs& W = bw[bi];
@@ -367,7 +368,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
             B.nrm_in = c->nrm_in;
-            B.nrm_sorted = is_ng ? nullptr : L.nrm;
+            B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
+            if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
         }
     }
     B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
@@ -682,6 +684,7 @@ static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput&
         return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: field offsets outside point_step");
     ci.data = d.data; ci.n = d.n; ci.step = d.point_step; ci.ox = d.off_x; ci.oy = d.off_y; ci.oz = d.off_z;
     ci.is_device = d.data_is_device != 0;
+    ci.src_only = d.source_only != 0;
     // device code reads 4-byte aligned floats; anything else is repacked on the host first
     ci.aligned = (d.point_step % 4 == 0) && (d.off_x % 4 == 0) && (d.off_y % 4 == 0) && (d.off_z % 4 == 0) &&
                  (reinterpret_cast<uintptr_t>(d.data) % 4 == 0);
@@ -712,6 +715,7 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
     if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
     m3dreg_cloud_desc d;
     d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z; d.data_is_device = data_is_device;
+    d.source_only = 0;
     return m3dreg_cloud_create_batch(h, &d, 1, out);
 }
 

@@ -499,3 +499,25 @@ def test_config4_shard_full_size_properties(reg):
     for k in range(8):
         rot, tra = synth.pose_error(Tb[k], data[k][2])
         assert stb[k].status == abi.MAX_ITERATIONS and rot < 0.1 and tra < 0.006, (k, rot, tra)
+
+
+def test_source_only_clouds_skip_the_normal_grid(reg, orc):
+    """m3dreg_cloud_desc.source_only: a cloud that will only ever be a source is sorted but gets no normals (its normal-estimation grid
+    is not built). Registering it gives exactly the oracle's poses; as a point-to-plane TARGET it is refused."""
+    p = _params(leaf=(0.4, 0.2), iterations=(6, 8), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    src, tgt, Tgt = synth.hdl32_pair(700, 61, 62, dx=0.25, dy=0.1, dyaw_deg=2.5)
+    src = src.copy(); src[::37] = np.nan
+    T0 = synth.perturb(Tgt, np.random.default_rng(2), 0.8, 0.06)
+    To, sto, tro = orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=32)
+    for wait in (True, False):
+        cs, ct = R.clouds([src, tgt], wait=wait, source_only=[True, False])
+        T, st = R.align(cs, ct, T0)
+        assert np.array_equal(R.trace(), tro) and np.array_equal(T, To)
+        _same_stats(st, sto)
+        assert cs.grid_info(1).has_normals == 0 and ct.grid_info(1).has_normals == 1
+        e, eo = cs.export(1), orc.Cloud(p, src).export(1)
+        assert np.array_equal(e["perm"], eo["perm"]) and np.array_equal(e["sorted_xyz"], eo["sorted_xyz"], equal_nan=True)
+        with pytest.raises(abi.M3dregError) as ei:
+            R.align(ct, cs, T0)
+        assert ei.value.code == abi.ERR_LEVEL_MISMATCH
