@@ -148,8 +148,9 @@ typedef struct m3dreg_cloud_desc {
     size_t n, point_step, off_x, off_y, off_z;
     int32_t data_is_device;
     int32_t source_only;  /* != 0: the cloud will only ever be the SOURCE of registrations: it is sorted along the grid's curve (its queries
-                             then stream spatially coherent) but gets no normals — the normal-estimation grid, half of a point-to-plane
-                             cloud's bucketing, is skipped. As a point-to-plane target it is refused (M3DREG_ERR_LEVEL_MISMATCH). */
+                             then stream spatially coherent) but gets no bucket table, no chunk boxes and no normals — the
+                             normal-estimation grid alone is half of a point-to-plane cloud's bucketing. As a target it is refused
+                             (M3DREG_ERR_LEVEL_MISMATCH); m3dmap_insert and the export calls take it. */
 } m3dreg_cloud_desc;
 int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);
 int m3dreg_cloud_create_batch_async(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out);

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
 
 __global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
+    if (!B.htab) return;   // a source-only cloud has no table
     const uint32_t T2 = 2u * (B.dyn[1] + 1u);
     uint4* t = reinterpret_cast<uint4*>(B.htab);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T2; i += gridDim.x * blockDim.x)
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
     B.pts[j] = p;
-    if (bhead) {
+    if (bhead && B.htab) {
         const uint32_t bk = bucket_key_of_point(B.grid, p);
         uint32_t h = m3d_hash_slot(bk, hshift);
         for (;;) {   // bucket keys are unique here, so a successful CAS owns the slot
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restric
     const M3dBuild& B = builds[blockIdx.y];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = B.n;
-    if (j >= n) return;
+    if (j >= n || !B.htab) return;   // (a source-only cloud has no table)
     const uint32_t* skey = B.skey_out;
     const uint32_t k = skey[j];
     if (k == M3D_INVALID_KEY) return;

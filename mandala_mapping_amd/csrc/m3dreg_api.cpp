@@ -64,6 +64,7 @@ struct m3dreg_cloud {
     int32_t n_levels = 0;
     float leaf[M3DREG_MAX_LEVELS]{};
     bool has_normals = false;
+    bool source_only = false;      // m3dreg_cloud_desc.source_only: sorted, but no hash table / chunk boxes / normals — never a target
     float4* xyz = nullptr;         // coordinates in input order
     float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
@@ -351,6 +352,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         m3dreg_cloud* c = cl[i];
         const bool no_normals = in[i].src_only;   // a source-only cloud: sorted, no normal grid, no normals
         c->has_normals = want_normals && !no_normals;
+        c->source_only = no_normals;
         for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
             const size_t bi = i * size_t(grids_per_cloud) + size_t(gidx);
             BuildWs& W = bw[bi];
@@ -370,6 +372,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.nrm_in = c->nrm_in;
             B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
             if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
+            if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
         }
     }
     B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
@@ -542,6 +545,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         if (!s || !t) return fail(h, M3DREG_ERR_INVALID_ARG, "null cloud in pair");
         int rc = check_levels(h, t);
         if (rc) return rc;
+        if (t->source_only) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "a source-only cloud (m3dreg_cloud_desc.source_only) cannot be the target of a registration");
         if (P.metric == M3DREG_POINT_TO_PLANE && !t->has_normals) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "target cloud has no normals");
         for (const m3dreg_cloud* c : { s, t })   // a cloud bucketed on ANOTHER handle's stream: this stream waits for that pipeline
             if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
@@ -1469,6 +1473,7 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
                     int32_t* out_idx, float* out_d2) {
     if (!h || !target || !queries_xyz || !out_idx || !out_d2 || level < 0 || level >= target->n_levels || nq == 0 || nq >= 0x7FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "debug_nn: bad argument");
+    if (target->source_only) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "debug_nn: a source-only cloud has no bucket table");
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     float* dq = nullptr; int32_t* di = nullptr; float* dd = nullptr;

@@ -521,3 +521,5 @@ def test_source_only_clouds_skip_the_normal_grid(reg, orc):
         with pytest.raises(abi.M3dregError) as ei:
             R.align(ct, cs, T0)
         assert ei.value.code == abi.ERR_LEVEL_MISMATCH
+        with pytest.raises(abi.M3dregError):
+            cs.nn(src[:10], 0.5, level=1)                   # no bucket table to search
