@@ -334,7 +334,7 @@ def cpu_baseline(params, host_pairs, iters, threads=0):
     except Exception as e:   # scipy missing on the box: the figure is optional
         kd = {"error": repr(e)}
     return {"value": done / dt, "unit": "registrations/s", "cores": threads, "kind": "port", "kdtree": kd,
-            "sample": f"{done} of the same scan pairs (bucketing+normals of both clouds + {iters} iterations each), "
+            "sample": f"{done} of the same scan pairs (bucketing + normals of BOTH clouds — the oracle has no source-only mode — + {iters} iterations each), "
                       f"oracle/m3d_oracle.c built with -O2 -fopenmp, {threads} threads"}
 
 

@@ -283,7 +283,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + mw * b : nullptr;
         for (size_t i = 0; i < k; i++) {
             BuildWs& B = bw[i * size_t(grids_per_cloud)];
-            B.mom = want_normals ? w.take<long long>(10 * in[i].n) : nullptr;
+            B.mom = (want_normals && !in[i].src_only) ? w.take<long long>(10 * in[i].n) : nullptr;   // (zeroed every batch: 80 B per point)
         }
         w.take<uint8_t>(0); zero_hi = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
         // --- the rest ---
