@@ -355,7 +355,13 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
         uint32_t off = B.hist[2 * blockIdx.x];
 #pragma unroll
         for (int w = 0; w < 4; w++) if (w < wave) off += s_wc[w];
-        if (vhead) voxel_head_list(B)[off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
+        if (vhead) {
+            voxel_head_list(B)[off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
+            // the voxel's moment slot, zeroed here: k_cell_moments adds the pieces of a run cut by a wave boundary with atomics, k_normals
+            // reads head slots only — no 80-B-per-point memset of the whole array (64 MB per step for eight 100 k-point targets)
+#pragma unroll
+            for (int i = 0; i < 10; i++) B.mom[10 * (size_t)j + i] = 0;
+        }
     }
     if (!inb) return;
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));

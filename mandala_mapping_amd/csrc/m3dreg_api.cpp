@@ -274,18 +274,18 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         Carver w(base);
         d_dec = w.take<M3dDecode>(k);
         d_builds = w.take<M3dBuild>(n_builds);
-        // --- region zeroed with one memset: aabb, dyn, moments ---
+        // --- region zeroed with one memset: aabb, dyn (the moments are zeroed where they are used: k_finalize_level, per voxel head) ---
         w.take<uint8_t>(0); zero_lo = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
         uint32_t* aabb_all = w.take<uint32_t>(8 * k);              // contiguous: read back with one copy
         for (size_t i = 0; i < k; i++) aabb[i] = base ? aabb_all + 8 * i : nullptr;
         const size_t mw = sizeof(M3dLevelMeta) / 4;
         uint32_t* dyn_all = w.take<uint32_t>(mw * n_builds);       // one M3dLevelMeta per build (the normal grids' live here, the levels' in their clouds)
         for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + mw * b : nullptr;
+        w.take<uint8_t>(0); zero_hi = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
         for (size_t i = 0; i < k; i++) {
             BuildWs& B = bw[i * size_t(grids_per_cloud)];
-            B.mom = (want_normals && !in[i].src_only) ? w.take<long long>(10 * in[i].n) : nullptr;   // (zeroed every batch: 80 B per point)
+            B.mom = (want_normals && !in[i].src_only) ? w.take<long long>(10 * in[i].n) : nullptr;   // 80 B per point slot, only the voxel heads' slots are used
         }
-        w.take<uint8_t>(0); zero_hi = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
         // --- the rest ---
         for (size_t i = 0; i < k; i++) {
             const size_t n = in[i].n;
