@@ -345,8 +345,6 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         D.bigendian = in[i].bigendian ? 1 : 0;
         D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
-    B_HIP(hipMemcpyAsync(d_dec, h_dec, sizeof(M3dDecode) * k, hipMemcpyHostToDevice, h->stream));
-    B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
     // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
@@ -375,7 +373,14 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
         }
     }
-    B_HIP(hipMemcpyAsync(d_builds, h_builds, sizeof(M3dBuild) * n_builds, hipMemcpyHostToDevice, h->stream));
+    // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
+    // on the stream's critical path)
+    {
+        const size_t span = size_t(reinterpret_cast<uint8_t*>(d_builds + n_builds) - reinterpret_cast<uint8_t*>(d_dec));
+        if (size_t(reinterpret_cast<uint8_t*>(h_builds + n_builds) - reinterpret_cast<uint8_t*>(h_dec)) != span) { cleanup(); return fail(h, M3DREG_ERR_HIP, "descriptor staging layout"); }
+        B_HIP(hipMemcpyAsync(d_dec, h_dec, span, hipMemcpyHostToDevice, h->stream));
+    }
+    B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
     if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
     B_HIP(hipEventRecord(h->staged, h->stream));
     B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, P.plane_ratio, P.normal_min_pts,
@@ -807,7 +812,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     }
     if (h->profiling && prev_sampled) { hipEvent_t e = next_event(h); h->ev_kind.push_back(2); if (e) (void)hipEventRecord(e, h->stream); }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_trace, h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE, hipMemcpyDeviceToHost, h->stream));
+    // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
     return M3DREG_OK;
 }
@@ -1541,7 +1546,12 @@ int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]) {
 int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out) {
     if (!h || !n_out) return M3DREG_ERR_INVALID_ARG;
     size_t k = h->last_trace_n < cap ? h->last_trace_n : cap;
-    if (poses && k) memcpy(poses, h->h_trace, sizeof(double) * 16 * k);
+    if (poses && k) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipMemcpyAsync(h->h_trace, h->d_trace, sizeof(double) * 16 * k, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        memcpy(poses, h->h_trace, sizeof(double) * 16 * k);
+    }
     *n_out = h->last_trace_n;
     return M3DREG_OK;
 }
