@@ -453,16 +453,16 @@ int check_levels(m3dreg_handle* h, const m3dreg_cloud* c) {
 int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
     if (n_pairs <= h->cap_pairs) return M3DREG_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->d_jobs) hipFree(h->d_jobs);
-    if (h->d_states) hipFree(h->d_states);
+    if (h->d_jobs) hipFree(h->d_jobs);       // jobs and states share one block on either side (one copy moves both)
     if (h->h_jobs) hipHostFree(h->h_jobs);
-    if (h->h_states) hipHostFree(h->h_states);
     h->d_jobs = nullptr; h->d_states = nullptr; h->h_jobs = nullptr; h->h_states = nullptr; h->cap_pairs = 0;
     size_t cap = n_pairs < 8 ? 8 : n_pairs;
-    HIPCHK(h, hipMalloc((void**)&h->d_jobs, sizeof(M3dJob) * cap * M3DREG_MAX_LEVELS));
-    HIPCHK(h, hipMalloc((void**)&h->d_states, sizeof(M3dPairState) * cap));
-    HIPCHK(h, hipHostMalloc((void**)&h->h_jobs, sizeof(M3dJob) * cap * M3DREG_MAX_LEVELS, hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void**)&h->h_states, sizeof(M3dPairState) * cap, hipHostMallocDefault));
+    static_assert(sizeof(M3dJob) % 8 == 0, "the pair states follow the jobs in one block");
+    const size_t block = sizeof(M3dJob) * cap * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * cap;
+    HIPCHK(h, hipMalloc((void**)&h->d_jobs, block));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_jobs, block, hipHostMallocDefault));
+    h->d_states = reinterpret_cast<M3dPairState*>(h->d_jobs + cap * M3DREG_MAX_LEVELS);
+    h->h_states = reinterpret_cast<M3dPairState*>(h->h_jobs + cap * M3DREG_MAX_LEVELS);
     if (!h->d_trace) {
         HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE));
         HIPCHK(h, hipHostMalloc((void**)&h->h_trace, sizeof(double) * 16 * M3D_MAX_TRACE, hipHostMallocDefault));
@@ -670,8 +670,8 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_states, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets }) if (p) hipFree(p);
-    for (void* p : { (void*)h->h_jobs, (void*)h->h_states, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets }) if (p) hipFree(p);   // (the states live in the jobs' block)
+    for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->staged) hipEventDestroy(h->staged);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -783,8 +783,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     if ((rc = build_jobs(h, pairs, n_pairs, max_n_src))) return rc;
     const m3dreg_params& P = h->params;
     if ((rc = ensure_match(h, n_pairs, max_n_src))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * size_t(P.n_levels), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
     const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
     bool prev_sampled = false;
