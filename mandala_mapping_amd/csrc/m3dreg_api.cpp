@@ -510,8 +510,8 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
         h->d_tickets = nullptr; h->tickets_cap = 0;
         HIPCHK(h, hipMalloc((void**)&h->d_tickets, sizeof(unsigned int) * (n_tk + n_tk / 4)));
         h->tickets_cap = n_tk + n_tk / 4;
+        HIPCHK(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned int) * h->tickets_cap, h->stream));   // once: every launch leaves its arrival counters at zero
     }
-    HIPCHK(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned int) * n_tk, h->stream));   // (the kernels leave them at zero as well)
     h->match_stride = int(stride);
     h->match_pairs = n_pairs;
     return M3DREG_OK;
