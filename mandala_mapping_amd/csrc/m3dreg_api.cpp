@@ -311,11 +311,14 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     if (rc) { cleanup(); return rc; }
     layout(h->ws.p);
     if (h->staged) { hipError_t e = hipEventSynchronize(h->staged); if (e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, "hipEventSynchronize(staging)", e); } }
-    Carver hw(h->h_ws);
+    Carver hw(h->h_ws);   // the same sequence of takes as the device layout above: the staging block mirrors it byte for byte
     M3dDecode* h_dec = hw.take<M3dDecode>(k);
     M3dBuild* h_builds = hw.take<M3dBuild>(n_builds);
+    hw.take<uint8_t>(0);
+    uint32_t* h_aabb0 = hw.take<uint32_t>(8 * k);   // zeros for the AABB accumulators: they travel with the descriptors (no memset)
+    memset(h_aabb0, 0, sizeof(uint32_t) * 8 * k);
 #define B_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, #expr, _e); } } while (0)
-    B_HIP(hipMemsetAsync(zero_lo, 0, size_t(zero_hi - zero_lo), h->stream));
+    (void)zero_lo; (void)zero_hi;   // (the metas in this region are written in full by k_grid_params / k_table_params before anything reads them)
     // ---- a2: stage + decode ----------------------------------------------------------------------------------
     std::vector<std::vector<float>>& repack = h->repack;   // the previous batch's copies are done (h->staged was waited for above)
     repack.assign(k, std::vector<float>());
@@ -376,8 +379,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
     // on the stream's critical path)
     {
-        const size_t span = size_t(reinterpret_cast<uint8_t*>(d_builds + n_builds) - reinterpret_cast<uint8_t*>(d_dec));
-        if (size_t(reinterpret_cast<uint8_t*>(h_builds + n_builds) - reinterpret_cast<uint8_t*>(h_dec)) != span) { cleanup(); return fail(h, M3DREG_ERR_HIP, "descriptor staging layout"); }
+        const size_t span = size_t(reinterpret_cast<uint8_t*>(aabb[0] + 8 * k) - reinterpret_cast<uint8_t*>(d_dec));
+        if (size_t(reinterpret_cast<uint8_t*>(h_aabb0 + 8 * k) - reinterpret_cast<uint8_t*>(h_dec)) != span) { cleanup(); return fail(h, M3DREG_ERR_HIP, "descriptor staging layout"); }
         B_HIP(hipMemcpyAsync(d_dec, h_dec, span, hipMemcpyHostToDevice, h->stream));
     }
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
