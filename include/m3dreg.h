@@ -127,7 +127,11 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
                  m3dreg_stats* stats);
 
 /* ---- resident clouds (loop-closure batches, scan-to-scan chains, benchmarks) ---------------- */
-/* `data_is_device` != 0: `data` is a device pointer on the handle's device (no PCIe copy). */
+/* `data_is_device`: 0 = host payload, 1 = `data` is a device pointer on the handle's device (no PCIe copy); the single-cloud calls
+ * (m3dreg_cloud_create, m3dreg_cloud_create_pc2) also take it as a flag word: | M3DREG_CLOUD_SOURCE_ONLY = the cloud will only ever be
+ * a source (see m3dreg_cloud_desc.source_only). */
+#define M3DREG_CLOUD_DEVICE 1
+#define M3DREG_CLOUD_SOURCE_ONLY 2
 int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step,
                         size_t off_x, size_t off_y, size_t off_z, int data_is_device,
                         m3dreg_cloud** out);

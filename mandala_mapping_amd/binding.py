@@ -231,8 +231,9 @@ class Registrar:
         self._check(lib().m3dreg_cloud_create(self._h, buf, n, point_step, offsets[0], offsets[1], offsets[2], 0, C.byref(p)), "cloud_create")
         return Cloud(self, p, n)
 
-    def cloud_pc2(self, msg: PointCloud2):
-        """The message as it is — field table, byte order, row padding — decoded on the device (m3dreg_cloud_create_pc2)."""
+    def cloud_pc2(self, msg: PointCloud2, source_only=False):
+        """The message as it is — field table, byte order, row padding — decoded on the device (m3dreg_cloud_create_pc2).
+        source_only: the sweep will only ever be a source (and a map insert): sorted, no table, no normals."""
         k = len(msg.fields)
         ft = (abi.PointField * k)()
         for i, f in enumerate(msg.fields):
@@ -240,7 +241,7 @@ class Registrar:
         buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
         p = C.c_void_p()
         self._check(lib().m3dreg_cloud_create_pc2(self._h, buf, len(msg.data), msg.width, msg.height, msg.point_step, msg.row_step, ft, k,
-                                                  1 if msg.is_bigendian else 0, 0, C.byref(p)), "cloud_create_pc2")
+                                                  1 if msg.is_bigendian else 0, 2 if source_only else 0, C.byref(p)), "cloud_create_pc2")
         return Cloud(self, p, msg.n)
 
     def cloud_from_device(self, dev_ptr, n, point_step=16, offsets=(0, 4, 8)):
@@ -533,7 +534,7 @@ class Gpu6dSlamNode:
     def on_cloud(self, msg: PointCloud2):
         """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None). Like the shim, the message
         crosses the ABI with its own field table and every sweep is bucketed once."""
-        cur = self.reg.cloud_pc2(msg)
+        cur = self.reg.cloud_pc2(msg, source_only=self._map is not None)   # scan-to-map: a sweep is only ever a source and a map insert
         if self._map is not None:
             if len(self._map) == 0:
                 self._map.insert(cur, self.pose)

@@ -726,8 +726,9 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
                         int data_is_device, m3dreg_cloud** out) {
     if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
     m3dreg_cloud_desc d;
-    d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z; d.data_is_device = data_is_device;
-    d.source_only = 0;
+    d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z;
+    d.data_is_device = (data_is_device & M3DREG_CLOUD_DEVICE) ? 1 : 0;
+    d.source_only = (data_is_device & M3DREG_CLOUD_SOURCE_ONLY) ? 1 : 0;
     return m3dreg_cloud_create_batch(h, &d, 1, out);
 }
 
@@ -745,7 +746,8 @@ int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_byte
     if (size_t(row_step) < size_t(width) * point_step || size_t(row_step) * height > data_bytes || size_t(row_step) * height > 0x7FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: width * point_step / row_step * height do not fit the data");
     CloudInput ci{};
-    ci.data = data; ci.n = n; ci.step = point_step; ci.is_device = data_is_device != 0; ci.aligned = true;
+    ci.data = data; ci.n = n; ci.step = point_step; ci.is_device = (data_is_device & M3DREG_CLOUD_DEVICE) != 0; ci.aligned = true;
+    ci.src_only = (data_is_device & M3DREG_CLOUD_SOURCE_ONLY) != 0;
     ci.generic = true; ci.width = width; ci.row_step = row_step; ci.data_bytes = size_t(row_step) * height; ci.bigendian = is_bigendian != 0;
     size_t* off[3] = { &ci.ox, &ci.oy, &ci.oz };
     bool have[3] = { false, false, false };

@@ -75,7 +75,7 @@ private:
             ft[i] = m3dreg_point_field{ m.fields[i].name.c_str(), m.fields[i].offset, m.fields[i].datatype, m.fields[i].count };
         m3dreg_cloud* c = nullptr;
         const int rc = m3dreg_cloud_create_pc2(h_, m.data.data(), m.data.size(), m.width, m.height, m.point_step, m.row_step, ft.data(), ft.size(),
-                                               m.is_bigendian ? 1 : 0, 0, &c);
+                                               m.is_bigendian ? 1 : 0, map_ ? M3DREG_CLOUD_SOURCE_ONLY : 0, &c);   // scan-to-map: a sweep is only a source and a map insert
         if (rc != M3DREG_OK) ROS_WARN("m3dreg_cloud_create_pc2: %s", m3dreg_last_error(h_));   // logged and swallowed, m3d_aggregator.cpp:239-241
         return rc == M3DREG_OK ? c : nullptr;
     }

@@ -35,7 +35,7 @@ for case in range(n_cases):
         if rng.integers(0, 4) == 0:
             tgt = tgt[: max(50, len(tgt) // int(rng.integers(2, 9)))]
         T0 = synth.perturb(Tgt, rng, 1.0, 0.1) if rng.integers(0, 2) else np.eye(4)
-        cs, ct = R.clouds([src, tgt], wait=bool(rng.integers(0, 2)))   # half of the clouds through the enqueue-only bucketing
+        cs, ct = R.clouds([src, tgt], wait=bool(rng.integers(0, 2)), source_only=[bool(rng.integers(0, 2)), False])   # half of the clouds through the enqueue-only bucketing, half of the sources source_only
         pairs.append((cs, ct, T0))
         refs.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt), T0, trace_cap=64))
     Tb, stb = R.align_batch(pairs)
