@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 2
+#define M3DREG_ABI_VERSION 2   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+                                     M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
