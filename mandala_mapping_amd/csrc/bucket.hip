@@ -271,7 +271,6 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block
         B.hist[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        B.blkw[blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         B.hist[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
 }
@@ -282,17 +281,27 @@ __host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap
     hmask = hs - 1; hshift = 32 - hb;
 }
 
+// Longest-processing-time-first order of a cloud's 256-point blocks (it is the SOURCE of a registration that uses it): a block that
+// spans few voxels is a crowded stretch of the cloud (a surface close to the sensor) — its queries meet crowded target voxels and
+// walk several times as many candidates as the rest. Started last, such blocks were the tail that set k_nn_iter's duration; started
+// first, they run while the other blocks fill the machine. k_table_params (one workgroup per grid, it has the per-block voxel
+// counts in hand) ranks the blocks by occupied voxels, ascending.
+#define M3D_ORDER_CAP 8192
+
 // one workgroup per build: totals of the per-block counts (dyn[0] voxels, dyn[3] buckets), exclusive prefix of the voxel
 // heads in place (where each block of k_finalize_level appends its heads), table geometry
 __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
     const M3dBuild& B = builds[blockIdx.x];
     const int nblk = (B.n + 255) / 256;
     __shared__ uint32_t sh[2][256];
+    __shared__ uint32_t wv[M3D_ORDER_CAP];   // occupied voxels of every 256-point block (k_count_cells), for the block order below
+    const bool want_order = B.order != nullptr && nblk <= M3D_ORDER_CAP;
     uint32_t carryV = 0, carryB = 0;
     const int t = threadIdx.x;
     for (int base = 0; base < nblk; base += 256) {
         const int b = base + t;
         const uint32_t vV = b < nblk ? B.hist[2 * b] : 0u, vB = b < nblk ? B.hist[2 * b + 1] : 0u;
+        if (want_order && b < nblk) wv[b] = vV;
         sh[0][t] = vV; sh[1][t] = vB;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
@@ -310,6 +319,16 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
         m3d_table_size(carryB, B.hcap, hmask, hshift);
         B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u;   // every word this pipeline reads is written here: no memset needed
         B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
+    }
+    if (B.order) {   // (the loop above ended with a barrier: wv is complete)
+        for (int b = t; b < nblk; b += 256) {
+            if (!want_order) { B.order[b] = (uint32_t)b; continue; }   // a cloud of more than 2 M points: natural order
+            const uint32_t wb = wv[b];
+            int rank = 0;
+#pragma unroll 8
+            for (int o = 0; o < nblk; o++) rank += (wv[o] < wb || (wv[o] == wb && o < b)) ? 1 : 0;
+            B.order[rank] = (uint32_t)b;
+        }
     }
 }
 
@@ -408,36 +427,33 @@ __global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restric
 }
 
 // third pass, almost always empty (a bucket of 2x2x2 voxels with more than 65535 points): 32-bit cumulative rows
-// Longest-processing-time-first order of a cloud's 256-point blocks (it is the SOURCE of a registration that uses it): a block that
-// spans few voxels is a crowded stretch of the cloud (a surface close to the sensor) — its queries meet crowded target voxels and
-// walk several times as many candidates as the rest. Started last, such blocks were the tail that set k_nn_iter's duration; started
-// first, they run while the other blocks fill the machine. One workgroup per grid ranks the blocks by occupied voxels, ascending.
-#define M3D_ORDER_CAP 8192
-__global__ __launch_bounds__(512) void k_block_order(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.x];
-    if (!B.order) return;
-    const int nblk = (B.n + 255) / 256;
-    __shared__ uint32_t w[M3D_ORDER_CAP];
-    if (nblk > M3D_ORDER_CAP || nblk == 0) {   // (a cloud of more than 2 M points, or one in error: natural order)
-        const int nb0 = (int)((B.n > 0 ? B.n : 0) + 255) / 256;
-        for (int b = threadIdx.x; b < nb0; b += blockDim.x) B.order[b] = (uint32_t)b;
-        return;
-    }
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) w[b] = B.blkw[b];
-    __syncthreads();
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
-        const uint32_t wb = w[b];
-        int rank = 0;
-#pragma unroll 8
-        for (int o = 0; o < nblk; o++) rank += (w[o] < wb || (w[o] == wb && o < b)) ? 1 : 0;
-        B.order[rank] = (uint32_t)b;
-    }
+__device__ __forceinline__ void bucket_big_point(const M3dBuild& B, int j) {
+    const int n = B.n;
+    if (j >= n) return;
+    const uint32_t* skey = B.skey_out;
+    const uint32_t k = skey[j];
+    if (k == M3D_INVALID_KEY) return;
+    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
+    if (kn == k) return;
+    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
+    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
+    const uint32_t hmask = B.dyn[1];
+    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
+    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
+    while (B.htab[h].key != bk) h = (h + 1) & hmask;
+    const uint32_t big = B.htab[h].big;
+    if (big == 0u || big - 1u >= B.bigcap) return;
+    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
+    for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v;
 }
 
 // exact AABB of every M3D_CHUNK consecutive sorted (finite) points: the search tests a crowded voxel's chunks by their boxes
 // before it gathers them (min / max of floats: exact, order-independent)
 __global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
+    // (the same launch rewrites the rows of buckets with more than 65535 points as 32-bit counts: normally there are none, and an
+    // extra, empty launch cost its 5 us on every step's critical path)
+    if (B.htab && B.dyn[4] != 0u) bucket_big_point(B, (int)(blockIdx.x * blockDim.x + threadIdx.x));
     if (!B.cbox) return;
     // four lanes per chunk, four points each (a lane's 16-B loads and its neighbours' fall into the same cache lines), xor-shuffle merge
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,28 +484,6 @@ __global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_bucket_big(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    if (B.dyn[4] == 0u) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = B.n;
-    if (j >= n) return;
-    const uint32_t* skey = B.skey_out;
-    const uint32_t k = skey[j];
-    if (k == M3D_INVALID_KEY) return;
-    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
-    if (kn == k) return;
-    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
-    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
-    const uint32_t hmask = B.dyn[1];
-    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
-    while (B.htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t big = B.htab[h].big;
-    if (big == 0u || big - 1u >= B.bigcap) return;
-    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
-    for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v;
-}
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
 __device__ __forceinline__ void sym3_square(const double m[6], double o[6]) {
@@ -778,17 +772,13 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
-    hipLaunchKernelGGL(k_block_order, dim3(n_builds), dim3(512), 0, s, d_builds);   // (391 blocks per 100 k-point cloud: 1024 threads only crowd the SIMDs)
-    M3D_DBG(s, "k_block_order");
     hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_clear_table");
     hipLaunchKernelGGL(k_finalize_level, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_finalize_level");
     hipLaunchKernelGGL(k_bucket_counts, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_bucket_counts");
-    hipLaunchKernelGGL(k_bucket_big, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
-    M3D_DBG(s, "k_bucket_big");
-    hipLaunchKernelGGL(k_chunk_boxes, dim3((4 * blocks + M3D_CHUNK - 1) / M3D_CHUNK, n_builds), dim3(256), 0, s, d_builds);   // 4 lanes per chunk
+    hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
     M3D_DBG(s, "k_chunk_boxes");
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);

@@ -47,7 +47,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t bigcap;
     float4* cbox;                // [2 * ceil(n / 16)] out: chunk boxes of the sorted points (levels only; null for normal grids)
     uint32_t* blkw;              // [ceil(n / 256)] workspace: occupied voxels per 256 sorted positions (k_count_cells)
-    uint32_t* order;             // [ceil(n / 256)] out (levels only, else null): the 256-point blocks of the sorted cloud, most crowded first (k_block_order)
+    uint32_t* order;             // [ceil(n / 256)] out (levels only, else null): the 256-point blocks of the sorted cloud, most crowded first (k_table_params)
     uint32_t* dyn;               // out: the grid's M3dLevelMeta (144 B; its first 8 words are the dyn counters {occupied voxels, hmask, hshift, ...})
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
     float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
