@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
     if (t == 0) {
         uint32_t hmask; int hshift;
         m3d_table_size(carryB, B.hcap, hmask, hshift);
-        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u;   // every word this pipeline reads is written here: no memset needed
+        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u; B.dyn[6] = 0u;   // every word this pipeline reads is written here: no memset needed (dyn[6]: pool images handed out by k_tile_build)
         B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
     }
     if (B.order) {   // (the loop above ended with a barrier: wv is complete)
@@ -484,6 +484,197 @@ __global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict_
     }
 }
 
+
+// ---- target tiles: what a workgroup of the LDS-staged search (icp.hip: k_nn_tiles) holds in LDS -------------------------------------
+// One workgroup per tile (m3d_device.h): the tile's own buckets are the bucket heads among its M3D_TILE_PTS sorted positions; every
+// occupied bucket within one bucket of an own one (27 probes of the level's hash table per own bucket) joins them in an LDS hash set
+// (CAS on the key: duplicates fall out). The set is then numbered in slot order, the populations are scanned into LDS positions, and
+// the image is written: directory slots, entries, and the sorted position of every staged point. Built once per target cloud and
+// level; every Gauss-Newton iteration of every registration against it re-uses it.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_w, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+    __syncthreads();                       // s_w may still be read from a previous call
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) off += s_w[w]; }
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (!B.thdr || !B.htab) return;
+    const int nv = B.grid.n_valid;
+    const int t = blockIdx.x, p0 = t * M3D_TILE_PTS;
+    if (p0 >= nv) return;
+    const int p1 = min(p0 + M3D_TILE_PTS, nv);
+    __shared__ uint32_t s_key[M3D_TILE_HS], s_gs[M3D_TILE_HS];
+    __shared__ uint32_t s_vk[M3D_TILE_VS], s_vv[M3D_TILE_VS];
+    __shared__ uint32_t s_head[M3D_TILE_PTS];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_ip[M3D_TILE_MAXIMG];   // points | voxels << 16 of every image
+    __shared__ uint32_t s_cnt, s_over;
+    const int tid = threadIdx.x;
+    const M3dGrid& g = B.grid;
+    const uint32_t hmask = B.dyn[1];
+    const int hshift = (int)B.dyn[2];
+    const uint32_t* skey = B.skey_out;
+    for (int i = tid; i < M3D_TILE_HS; i += 256) s_key[i] = M3D_INVALID_KEY;
+    if (tid == 0) { s_cnt = 0u; s_over = 0u; }
+    // own bucket heads, in sorted order
+    uint32_t nheads = 0;
+#pragma unroll
+    for (int r = 0; r < M3D_TILE_PTS / 256; r++) {
+        const int j = p0 + r * 256 + tid;
+        bool head = false;
+        if (j < p1) { const uint32_t k = skey[j]; head = (j == 0) || ((skey[j - 1] >> 3) != (k >> 3)); }
+        uint32_t tot;
+        const uint32_t pos = block_excl_scan_256(head ? 1u : 0u, s_w, tot);
+        if (head) s_head[nheads + pos] = (uint32_t)j;
+        nheads += tot;
+    }
+    __syncthreads();
+    // the 27 bucket positions around every own bucket: probe the level's table, collect the occupied ones
+    const int nb0 = (g.dims[0] + 1) >> 1, nb1 = (g.dims[1] + 1) >> 1, nb2 = (g.dims[2] + 1) >> 1;
+    for (uint32_t item = (uint32_t)tid; item < nheads * 27u; item += 256u) {
+        const uint32_t hd = item / 27u, d = item - hd * 27u;
+        const float4 p = B.pts[s_head[hd]];
+        const int cx = ((int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1) + (int)(d % 3u) - 1;
+        const int cy = ((int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1) + (int)((d / 3u) % 3u) - 1;
+        const int cz = ((int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1) + (int)(d / 9u) - 1;
+        if (cx < 0 || cy < 0 || cz < 0 || cx >= nb0 || cy >= nb1 || cz >= nb2) continue;
+        const uint32_t key = m3d_bucket_key(g, cx, cy, cz);
+        uint4 lo;
+        const int gs = m3d_find_bucket(B.htab, hmask, hshift, key, lo);
+        if (gs < 0) continue;
+        uint32_t h = (key * 0x9E3779B1u) >> (32 - 10);
+        static_assert(M3D_TILE_HS == 1024, "staged-bucket set hash: 10 bits");
+        int tries = 0;
+        for (; tries < M3D_TILE_HS; tries++) {
+            const uint32_t old = atomicCAS(&s_key[h], M3D_INVALID_KEY, key);
+            if (old == M3D_INVALID_KEY) { s_gs[h] = (uint32_t)gs; atomicAdd(&s_cnt, 1u); break; }
+            if (old == key) break;
+            h = (h + 1u) & (M3D_TILE_HS - 1u);
+        }
+        if (tries == M3D_TILE_HS) s_over = 1u;
+    }
+    __syncthreads();
+    M3dTileHdr* H = B.thdr + t;
+    const uint32_t n_e = s_cnt;
+    bool over = s_over != 0u || n_e > (uint32_t)M3D_TILE_ECAP;   // block-uniform
+    // populations of the staged buckets, in slot order (thread tid: slots SPT tid .. SPT tid + SPT - 1)
+    constexpr int SPT = M3D_TILE_HS / 256;
+    uint32_t kk[SPT], cnt[SPT], nvx[SPT]; uint4 lo[SPT], hi[SPT];
+    bool occ[SPT];
+    bool anybig = false, crowd = false;
+    uint32_t my_p = 0u, my_v = 0u;
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+        const int sl = SPT * tid + q;
+        kk[q] = s_key[sl]; occ[q] = kk[q] != M3D_INVALID_KEY;
+        lo[q] = make_uint4(0u, 0u, 0u, 0u); hi[q] = lo[q]; cnt[q] = 0u; nvx[q] = 0u;
+        if (occ[q] && !over) {
+            const uint32_t gs = s_gs[sl];
+            lo[q] = reinterpret_cast<const uint4*>(B.htab)[2 * (size_t)gs];
+            hi[q] = reinterpret_cast<const uint4*>(B.htab)[2 * (size_t)gs + 1];
+            cnt[q] = lo[q].z;
+            anybig = anybig || lo[q].w != 0u || cnt[q] > (uint32_t)M3D_TILE_PCAP;
+            const unsigned long long cumA = ((unsigned long long)hi[q].y << 32) | hi[q].x, cumB = ((unsigned long long)hi[q].w << 32) | hi[q].z;
+            uint32_t c0 = 0u;
+            for (int sub = 0; sub < 8; sub++) {
+                const uint32_t c1 = (uint32_t)(((sub < 4) ? cumA : cumB) >> (16 * (sub & 3))) & 0xFFFFu;
+                nvx[q] += c1 > c0 ? 1u : 0u; crowd = crowd || (c1 - c0 > (uint32_t)M3D_LONG_ROW); c0 = c1;
+            }
+        }
+        my_p += cnt[q]; my_v += nvx[q];
+    }
+    uint32_t tot_p, tot_v;
+    const uint32_t l0 = block_excl_scan_256(my_p, s_w, tot_p);
+    (void)block_excl_scan_256(my_v, s_w, tot_v);
+    __syncthreads();
+    if (anybig) s_over = 1u;
+    __syncthreads();
+    over = over || s_over != 0u;
+    if (over) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
+    // which image every staged bucket goes to, and where: one image when everything fits (nearly always); else a greedy cut in slot
+    // order by one thread (a crowded stretch: a few tiles per cloud)
+    uint32_t im[SPT], off[SPT];
+    { uint32_t l = l0; for (int q = 0; q < SPT; q++) { im[q] = 0u; off[q] = l; l += cnt[q]; } }
+    uint32_t n_img = 1u;
+    if (tot_p > (uint32_t)M3D_TILE_PCAP || tot_v > (uint32_t)M3D_TILE_VCAP) {
+        // (s_vk is free here: [slot] = points | voxels << 16 in, image | offset << 8 out)
+        for (int q = 0; q < SPT; q++) s_vk[SPT * tid + q] = cnt[q] | (nvx[q] << 16);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t img_i = 0u, p = 0u, v = 0u;
+            for (int sl = 0; sl < M3D_TILE_HS; sl++) {
+                const uint32_t w = s_vk[sl], bp = w & 0xFFFFu, bv = w >> 16;
+                if (bp == 0u) continue;
+                if (p + bp > (uint32_t)M3D_TILE_PCAP || v + bv > (uint32_t)M3D_TILE_VCAP) { s_ip[img_i < M3D_TILE_MAXIMG ? img_i : 0] = p | (v << 16); img_i++; p = 0u; v = 0u; }
+                s_vk[sl] = (img_i & 0xFFu) | (p << 8);
+                p += bp; v += bv;
+            }
+            s_ip[img_i < M3D_TILE_MAXIMG ? img_i : 0] = p | (v << 16);
+            s_cnt = img_i + 1u;
+        }
+        __syncthreads();
+        n_img = s_cnt;
+        for (int q = 0; q < SPT; q++) { const uint32_t w = s_vk[SPT * tid + q]; im[q] = w & 0xFFu; off[q] = w >> 8; }
+        __syncthreads();
+        if (n_img > (uint32_t)M3D_TILE_MAXIMG) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
+        if (tid == 0) {   // the extra images come from the level's pool
+            const uint32_t base = atomicAdd(&B.dyn[6], n_img - 1u);
+            s_cnt = (base + n_img - 1u <= (uint32_t)m3d_tile_pool(m3d_tiles_of(B.n))) ? (uint32_t)m3d_tiles_of(B.n) + base : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (s_cnt == 0xFFFFFFFFu) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
+    } else if (tid == 0) { s_ip[0] = tot_p | (tot_v << 16); s_cnt = 0u; }
+    if (crowd) s_over = 1u;   // (re-used: some voxel of the tile is crowded — every image of the tile then gets chunk boxes)
+    __syncthreads();
+    const bool crowded = s_over != 0u;
+    const uint32_t extra = s_cnt;
+    const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
+    for (uint32_t j = 0; j < n_img; j++) {
+        const uint32_t image = j == 0u ? (uint32_t)t : extra + j - 1u;
+        uint8_t* img = B.timg + (size_t)image * M3D_TILE_IMG_BYTES;
+        uint32_t* gidx = reinterpret_cast<uint32_t*>(img + M3D_TILE_VS * 8);
+        for (int i = tid; i < M3D_TILE_VS; i += 256) s_vk[i] = M3D_INVALID_KEY;
+        __syncthreads();
+        // the occupied voxels of this image's buckets into its directory; the sorted position of every staged point
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+            if (!occ[q] || im[q] != j) continue;
+            const uint32_t cx = kk[q] & ((1u << g.cb[0]) - 1u), cy = (kk[q] >> g.cb[0]) & ((1u << g.cb[1]) - 1u), cz = kk[q] >> (g.cb[0] + g.cb[1]);
+            const unsigned long long cumA = ((unsigned long long)hi[q].y << 32) | hi[q].x, cumB = ((unsigned long long)hi[q].w << 32) | hi[q].z;
+            uint32_t c0 = 0u;
+            for (int sub = 0; sub < 8; sub++) {
+                const uint32_t c1 = (uint32_t)(((sub < 4) ? cumA : cumB) >> (16 * (sub & 3))) & 0xFFFFu;
+                if (c1 > c0) {
+                    const uint32_t vkey = (2u * cx + (uint32_t)(sub & 1)) | ((2u * cy + (uint32_t)((sub >> 1) & 1)) << sh1) | ((2u * cz + (uint32_t)(sub >> 2)) << sh2);
+                    uint32_t h = (vkey * 0x9E3779B1u) >> (32 - 11);
+                    static_assert(M3D_TILE_VS == 2048, "voxel directory hash: 11 bits");
+                    for (;;) {   // voxel keys are unique: a successful CAS owns the slot (at most VCAP of the VS slots are ever taken)
+                        if (atomicCAS(&s_vk[h], M3D_INVALID_KEY, vkey) == M3D_INVALID_KEY) { s_vv[h] = (off[q] + c0) | ((c1 - c0) << 16); break; }
+                        h = (h + 1u) & (M3D_TILE_VS - 1u);
+                    }
+                }
+                c0 = c1;
+            }
+            for (uint32_t k = 0; k < cnt[q]; k++) gidx[off[q] + k] = lo[q].y + k;
+        }
+        __syncthreads();
+        uint2* vslots = reinterpret_cast<uint2*>(img);
+        for (int i = tid; i < M3D_TILE_VS; i += 256) vslots[i] = make_uint2(s_vk[i], s_vv[i]);
+        if (tid == 0) B.timeta[image] = M3dTileImgMeta{ s_ip[j] & 0xFFFFu, (s_ip[j] >> 16) | (crowded ? 0x80000000u : 0u) };
+        __syncthreads();
+    }
+    if (tid == 0) *H = M3dTileHdr{ extra, n_img, 0u, 0u };
+}
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------
 __device__ __forceinline__ void sym3_square(const double m[6], double o[6]) {
@@ -749,7 +940,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 
 // the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   float plane_ratio, int min_pts, float min_spread) {
+                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread) {
     const int n_builds = n_clouds * grids_per_cloud;
     const int max_passes = 4;   // a build whose keys need fewer skips the later ones on the device
     hipLaunchKernelGGL(k_grid_params, dim3((n_clouds + 63) / 64), dim3(64), 0, s, d_builds, n_clouds, grids_per_cloud);
@@ -780,6 +971,10 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_bucket_counts");
     hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
     M3D_DBG(s, "k_chunk_boxes");
+    if (any_tiles) {
+        hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_builds), dim3(256), 0, s, d_builds);
+        M3D_DBG(s, "k_tile_build");
+    }
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");

@@ -57,6 +57,18 @@ extern "C" hipError_t m3d_debug_read_blocks(unsigned long long* out, int iter) {
     return e;
 }
 __device__ int g_bt_on[8192];
+__device__ unsigned long long g_m3d_tblk[16384][8];   // k_nn_tiles: {start, end, where, kind (0 tile / 1 global walk), records, staged points, staged at, pair}
+extern "C" hipError_t m3d_debug_read_tile_blocks(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_tblk), sizeof(unsigned long long) * 16384 * 8);
+    static unsigned long long z[16384 * 8];
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_tblk), z, sizeof(z));
+    return e;
+}
+#define M3D_TBT_BEGIN() const unsigned long long tb0 = wall_clock64(); unsigned long long tb_st = 0; const bool tb_on = st->iters == g_m3d_blk_iter && blockIdx.x < 16384
+#define M3D_TBT_STAGED() do { if (tb_on) tb_st = wall_clock64(); } while (0)
+#define M3D_TBT_END(kind, nrec, npts) do { if (tb_on) { __syncthreads(); if (threadIdx.x == 0) { unsigned long long* b = g_m3d_tblk[blockIdx.x]; b[0] = tb0; b[1] = wall_clock64(); \
+    b[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+    b[3] = (kind); b[4] = (nrec); b[5] = (npts); b[6] = tb_st; b[7] = (unsigned long long)pair; } } } while (0)
 #define M3D_BT_COUNT(W, f) ((W).f++)
 #define M3D_BT_FLUSH(W) do { if (blockIdx.x < 8192 && g_bt_on[blockIdx.x]) { atomicAdd(&g_m3d_blk[blockIdx.x][4], (unsigned long long)(W).bt_trips); atomicMax(&g_m3d_blk[blockIdx.x][5], (unsigned long long)(W).bt_trips); \
     atomicAdd(&g_m3d_blk[blockIdx.x][6], (unsigned long long)(W).bt_chunks); atomicAdd(&g_m3d_blk[blockIdx.x][7], (unsigned long long)(W).bt_probes); } } while (0)
@@ -71,14 +83,13 @@ __device__ int g_bt_on[8192];
 #define M3D_BT_END(nsearch) ((void)0)
 #define M3D_BT_COUNT(W, f) ((void)0)
 #define M3D_BT_FLUSH(W) ((void)0)
+#define M3D_TBT_BEGIN() ((void)0)
+#define M3D_TBT_STAGED() ((void)0)
+#define M3D_TBT_END(kind, nrec, npts) ((void)0)
 #endif
 
 #define ICP_THREADS 256
 #define ICP_WAVES (ICP_THREADS / 64)
-// LDS staging capacity per wave (k_icp_lds): buckets of the wave's query box / target points staged
-#define ICP_CCAP 256
-#define ICP_PCAP 512
-#define ICP_ROUNDS (ICP_CCAP / 64)
 
 // ---- a6: exact NN over the 27 voxels around u --------------------------------------------------
 // The 27 voxels live in at most 2x2x2 buckets: up to 8 independent hash probes are issued first
@@ -303,59 +314,6 @@ __device__ __forceinline__ void m3d_load_pose(const M3dPairState* st, float (&R)
     }
 }
 
-// ---- variant 0 (kept for A/B and as the reference structure): one thread per query, every voxel of the
-// 27-neighbourhood probed in global memory. grid = (blocks per pair, pairs). Latency-bound: see profiles/.
-template <int METRIC>
-__global__ __launch_bounds__(ICP_THREADS) void k_icp_accumulate(const M3dJob* __restrict__ jobs, int first_of_level) {
-    const M3dJob& J = jobs[blockIdx.y];
-    M3dPairState* st = J.st;
-    if (st->done || (!first_of_level && st->level_done)) return;
-    float R[9], tt[3];
-    m3d_load_pose(st, R, tt);
-    const M3dLevelDev& L = J.tgt;
-    const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
-    const float dmax2 = J.dmax2;
-    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
-    constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
-    const int n = J.n_src;
-    for (int i = blockIdx.x * ICP_THREADS + threadIdx.x; i < n; i += gridDim.x * ICP_THREADS) {
-        const float4 p = J.src[i];
-        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        if (!m3d_finite3(ux, uy, uz)) continue;
-        float d2; float4 q;
-        const int j = m3d_nn27(L, ux, uy, uz, dmax2, d2, q);
-        if (j < 0) continue;
-        float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (METRIC == 1) nq = L.nrm_in[__float_as_uint(q.w) & M3D_IDX_MASK];
-        m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q, d2, nq, cx, cy, cz, S);
-    }
-    block_reduce_to_global<NACC>(acc, st->sums);
-}
-
-// ---- variant 1: wave-cooperative, LDS-staged voxel buckets ------------------------------------------
-// A wave takes 64 consecutive source points (the source cloud is streamed in ITS OWN voxel-sorted order,
-// so the 64 transformed queries fall into a compact box of target voxels). The wave (1) reduces the box
-// of its queries' voxel coordinates, (2) probes every voxel of the box (+1 halo) in the hash table — all
-// probes independent, 64 per instruction —, (3) stages the occupied voxels' points into LDS with fully
-// parallel 16-B loads, (4) lets every lane search its own 27 voxels in LDS only. Boxes that do not fit
-// the LDS budget (ICP_CCAP voxels / ICP_PCAP points) fall back to the global walk for that chunk.
-// The result is bit-identical to variant 0 (exact argmin with index tie-break, integer sums).
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-
 __device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, int& blk, int rot = 0) {
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so with a multiple of 8 pairs the
     // blocks of one pair are kept on one XCD (its L2 then holds one pair's clouds, not all eight).
@@ -366,152 +324,6 @@ __device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, i
     else { pair = id / bpp; blk = id % bpp; }
 }
 
-template <int METRIC>
-__global__ __launch_bounds__(ICP_THREADS) void k_icp_lds(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level) {
-    __shared__ uint4 s_cum[ICP_WAVES][ICP_CCAP];       // per box bucket: its 8 cumulative voxel populations (uint16 x 8)
-    __shared__ uint32_t s_off[ICP_WAVES][ICP_CCAP];    // per box bucket: LDS offset of its first staged point, 0xFFFFFFFF = empty
-    __shared__ float4 s_pts[ICP_WAVES][ICP_PCAP];      // staged target points
-    int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk);
-    const M3dJob& J = jobs[pair];
-    M3dPairState* st = J.st;
-    if (st->done || (!first_of_level && st->level_done)) return;
-    float R[9], tt[3];
-    m3d_load_pose(st, R, tt);
-    const M3dLevelDev& L = J.tgt;
-    const M3dGrid& g = L.g;
-    const float cx = g.center[0], cy = g.center[1], cz = g.center[2];
-    const float dmax2 = J.dmax2;
-    const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
-    constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint4* cumt = s_cum[wave];
-    uint32_t* offt = s_off[wave];
-    float4* spt = s_pts[wave];
-    const uint4* tab = reinterpret_cast<const uint4*>(L.htab);
-    const int n = J.n_src;
-    const int n_chunks = (n + 63) >> 6;
-    const int cpb = (n_chunks + bpp - 1) / bpp;          // chunks per block: contiguous range per block
-    const int c_end = min(n_chunks, (blk + 1) * cpb);
-    for (int chunk = blk * cpb + wave; chunk < c_end; chunk += ICP_WAVES) {
-        const int i = (chunk << 6) + lane;
-        const bool v = i < n;
-        const float4 p = v ? J.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
-        const float uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
-        const float uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        M3dQuery Q;
-        const bool inside = v && m3d_finite3(ux, uy, uz) && m3d_query_setup(g, ux, uy, uz, Q);
-        // (1) bucket box of the wave's neighbourhoods
-        const int BIG = 0x3FFFFFFF;
-        const int x0 = wave_min_i32(inside ? (Q.lo[0] >> 1) : BIG), x1 = wave_max_i32(inside ? (Q.hi[0] >> 1) : -BIG);
-        if (x1 < x0) continue;                            // no query of this chunk is near the grid (wave-uniform)
-        const int y0 = wave_min_i32(inside ? (Q.lo[1] >> 1) : BIG), y1 = wave_max_i32(inside ? (Q.hi[1] >> 1) : -BIG);
-        const int z0 = wave_min_i32(inside ? (Q.lo[2] >> 1) : BIG), z1 = wave_max_i32(inside ? (Q.hi[2] >> 1) : -BIG);
-        const int bx = x1 - x0 + 1, by = y1 - y0 + 1, bz = z1 - z0 + 1;
-        const int bxy = bx * by;
-        const long long nb_ll = (long long)bxy * bz;
-        bool fast = nb_ll <= ICP_CCAP;                    // wave-uniform
-        M3dBest B; B.found = -1; B.d2 = 3.0e38f; B.oi = 0; B.q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fast) {
-            const int nb = (int)nb_ll;
-            // (2) probe every bucket of the box: 64 independent probes per round
-            const float rbx = 1.0f / (float)bx, rbxy = 1.0f / (float)bxy;
-            uint32_t stt[ICP_ROUNDS], cnn[ICP_ROUNDS];
-            uint32_t mytotal = 0;
-            bool anybig = false;
-#pragma unroll
-            for (int r = 0; r < ICP_ROUNDS; r++) {
-                const int c = r * 64 + lane;
-                stt[r] = 0; cnn[r] = 0;
-                if (c < nb) {
-                    const int qz = (int)(((float)c + 0.5f) * rbxy);
-                    const int rem = c - qz * bxy;
-                    const int qy = (int)(((float)rem + 0.5f) * rbx);
-                    const int qx = rem - qy * bx;
-                    uint4 lo;
-                    const int h = m3d_find_bucket(L.htab, g.hmask, g.hshift, m3d_bucket_key(g, x0 + qx, y0 + qy, z0 + qz), lo);
-                    if (h >= 0) {
-                        stt[r] = lo.y; cnn[r] = lo.z;
-                        anybig = anybig || (lo.w != 0);
-                        cumt[c] = tab[2 * (size_t)h + 1];
-                        mytotal += lo.z;
-                    }
-                }
-            }
-            // lane-major LDS layout: one exclusive scan over the lanes' totals
-            uint32_t incl = mytotal;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
-            const uint32_t P = (uint32_t)__shfl((int)incl, 63);
-            fast = (P <= ICP_PCAP) && (__ballot(anybig) == 0ull);   // wave-uniform
-            if (fast) {
-                uint32_t off = incl - mytotal;
-#pragma unroll
-                for (int r = 0; r < ICP_ROUNDS; r++) {
-                    const int c = r * 64 + lane;
-                    if (c < nb) {
-                        offt[c] = cnn[r] ? off : 0xFFFFFFFFu;
-                        for (uint32_t k = 0; k < cnn[r]; k++) spt[off + k].w = __uint_as_float(stt[r] + k);   // global index, resolved below
-                        off += cnn[r];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // (3) stage: all lanes busy, every load independent
-                for (uint32_t f = lane; f < P; f += 64) {
-                    const uint32_t idx = __float_as_uint(spt[f].w);
-                    spt[f] = L.pts[idx];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // (4) every lane searches its neighbourhood in LDS only
-                if (inside) {
-                    float bound = dmax2 * 1.0001f;
-                    const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
-                    const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
-                    for (int b = 0; b < 8; b++) {
-                        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
-                        if (ox > nbx || oy > nby || oz > nbz) continue;
-                        const int c = (b0x + ox - x0) + bx * (b0y + oy - y0) + bxy * (b0z + oz - z0);
-                        const uint32_t o0 = offt[c];
-                        if (o0 == 0xFFFFFFFFu) continue;
-                        const uint4 hi = cumt[c];
-                        const uint4 lo = make_uint4(0u, o0, 0u, 0u);
-                        const int vx0 = 2 * (b0x + ox), vy0 = 2 * (b0y + oy), vz0 = 2 * (b0z + oz);
-#pragma unroll
-                        for (int sub = 0; sub < 8; sub++) {
-                            const int vx = vx0 + (sub & 1), vy = vy0 + ((sub >> 1) & 1), vz = vz0 + (sub >> 2);
-                            if (vx < Q.lo[0] || vx > Q.hi[0] || vy < Q.lo[1] || vy > Q.hi[1] || vz < Q.lo[2] || vz > Q.hi[2]) continue;
-                            if (m3d_voxel_lb2(Q, vx, vy, vz) > bound) continue;
-                            const uint2 rg = m3d_sub_range(lo, hi, nullptr, sub);
-                            for (uint32_t t = rg.x; t < rg.y; t++) m3d_consider(B, spt[t], ux, uy, uz);
-                            bound = fminf(bound, B.d2 * 1.0001f);
-                        }
-                    }
-                    if (B.found >= 0 && !(B.d2 <= dmax2)) B.found = -1;
-                }
-                __builtin_amdgcn_wave_barrier();          // LDS of this wave is reused by its next chunk
-            }
-        }
-        if (!fast) {
-            if (inside) B.found = m3d_nn27(L, ux, uy, uz, dmax2, B.d2, B.q);
-        }
-        if (lane == 0) atomicAdd(&st->ctr[fast ? 0 : 1], 1u);
-        if (B.found >= 0) {
-            float4 nq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (METRIC == 1) nq = L.nrm_in[__float_as_uint(B.q.w) & M3D_IDX_MASK];
-            m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, B.q, B.d2, nq, cx, cy, cz, S);
-        }
-    }
-    block_reduce_to_global<NACC>(acc, st->sums);
-}
 
 // ---- variant 2 (default): the two stages as two kernels -------------------------------------------
 // k_nn_search: a6 only. One thread per query, nothing but the search state in registers, so the kernel
@@ -562,8 +374,15 @@ __device__ __forceinline__ void m3d_walk_init(M3dWalk& W, float dmax2) {
     W.bkey = ((unsigned long long)M3D_INF_BITS << 32) | 0xFFFFFFFFull; W.best = -1; W.bound = dmax2 * 1.0001f; W.sec = M3D_INF_BITS; W.any_point = false;
 }
 
-// candidates [t, t1) of the sorted target points against the query: exact argmin on the packed (d2, input index) key
-__device__ __forceinline__ void m3d_scan_range(m3d_gf4 pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit) {
+// LDS-resident target points (k_nn_tiles): address space 3, so the loads are ds_read_b128 and never flat
+typedef const __attribute__((address_space(3))) m3d_f32x4* m3d_lf4;
+__device__ __forceinline__ float4 m3d_ld(m3d_lf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
+// candidates [t, t1) of the sorted target points against the query: exact argmin on the packed (d2, input index) key.
+// PP = where the candidates live (global memory: t is a sorted position; LDS: t is a position in the staged tile and gdelta
+// turns it back into the sorted position the result is reported as).
+template <typename PP>
+__device__ __forceinline__ void m3d_scan_range(PP pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit, uint32_t gdelta = 0u) {
     for (; t < t1; t += 4) {
         M3D_BT_COUNT(W, bt_trips);
         M3D_STAT(sit, 12);
@@ -582,13 +401,16 @@ __device__ __forceinline__ void m3d_scan_range(m3d_gf4 pts, uint32_t t, const ui
             W.sec = min(W.sec, max(db, (uint32_t)(W.bkey >> 32)));   // the loser of (candidate, best so far) is a non-winner
             const bool better = key < W.bkey;
             W.bkey = better ? key : W.bkey;
-            W.best = better ? (int)idx[j] : W.best;
+            W.best = better ? (int)(idx[j] + gdelta) : W.best;
         }
     }
 }
 
-// rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first
-__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, m3d_gf4 cbox, int vx0, int vy0,
+// rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first.
+// LDS = the bucket is a staged tile entry: lo = {key, first LDS position, sorted position - LDS position, population}, its points are
+// read from LDS, and a crowded row is simply scanned (an LDS read costs a fraction of a gather; no chunk boxes, no 32-bit rows).
+template <bool LDS, typename PP>
+__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, PP pts, m3d_gf4 cbox, int vx0, int vy0,
                                               int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
@@ -605,7 +427,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
         const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
         uint32_t c0, c1;
-        if (lo.w == 0) {
+        if (LDS || lo.w == 0) {
             c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
             const int sm = s_first - 1;
             c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
@@ -624,9 +446,9 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         if (lb2 > W.bound) { W.sec = min(W.sec, __float_as_uint(lb2)); if (c1 > c0) M3D_STAT(sit, 11); continue; }
         if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
         M3D_STATW(sit, 19);
-        if (c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
-            m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit);
-        } else {
+        if (LDS || c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
+            m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit, LDS ? lo.z : 0u);
+        } else if (!LDS) {
             // A crowded row (a surface close to the sensor): chunk by chunk, each chunk's exact box first — the points of a voxel keep
             // their input (firing) order, which sweeps the surface strip by strip, so all but the one or two chunks around the query
             // are provably farther than the best so far and are never gathered. A skipped chunk's box distance bounds its points in `sec`.
@@ -704,12 +526,145 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
             if (lo.x != key) continue;
             M3D_STAT(sit, 8);
             M3D_STATW(sit, 17);
-            m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
+            m3d_walk_rows<false>(Q, lo, hi, bigcum, pts, cbox, 2 * (b0x + ox), 2 * (b0y + oy), 2 * (b0z + oz), ux, uy, uz, W, 0, 4, sit);
         }
     }
     sec = __uint_as_float(W.sec);
     M3D_BT_FLUSH(W);
     return m3d_walk_result(W, dmax2, seeded);
+}
+
+// ONE QUERY PER LANE, EVERYTHING IN LDS (k_nn_tiles). The staged tile is addressed by VOXEL: an LDS hash {voxel key, first LDS
+// position | population << 16}; the key is linear in the voxel coordinates, so a neighbour's key is the query voxel's key plus a
+// constant. The 27 voxels are visited home first, then faces, edges, corners (compile-time order, fully unrolled): a voxel whose box
+// is provably farther than the best so far costs two adds and a compare — after the home voxel that is nearly all of them; the rest
+// cost one LDS probe and one ds_read_b128 per candidate. None of the per-bucket / per-row bookkeeping of the global walk
+// (variable 64-bit shifts of the cumulative counts, row clipping, 4-wide gather batches with masked slots) exists here: the walk of
+// the hash-of-buckets layout cost ~5000 instructions per wave of 64 queries and was VALU-bound even with every operand in LDS.
+// Exactly the candidates the spec names are compared (a voxel is skipped only when its box distance exceeds 1.0001 x the best
+// squared distance so far, the same test as the global walk's rows), with the same arithmetic: same exact argmin.
+// Returns the LDS position of the match, -1, or M3D_NN_NONE_CACHED; sec = squared lower bound of every non-winning candidate.
+typedef uint32_t m3d_u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) m3d_u32x2* m3d_lu2;
+// candidates [t, t1) of the staged points, two per trip (a repeated last point counts as +inf)
+__device__ __forceinline__ void m3d_tile_scan(m3d_lf4 sp, uint32_t t, const uint32_t t1, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec) {
+    for (; t < t1; t += 2) {
+        const uint32_t tb = min(t + 1u, t1 - 1u);
+        const float4 ca = m3d_ld(sp, t), cb = m3d_ld(sp, tb);
+        {
+            const float ex = ux - ca.x, ey = uy - ca.y, ez = uz - ca.z;
+            const uint32_t db = __float_as_uint(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+            const unsigned long long k = ((unsigned long long)db << 32) | __float_as_uint(ca.w);
+            sec = min(sec, max(db, (uint32_t)(bkey >> 32)));
+            const bool better = k < bkey;
+            bkey = better ? k : bkey; best = better ? (int)t : best;
+        }
+        {
+            const float ex = ux - cb.x, ey = uy - cb.y, ez = uz - cb.z;
+            const uint32_t db = (tb != t) ? __float_as_uint(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) : M3D_INF_BITS;
+            const unsigned long long k = ((unsigned long long)db << 32) | __float_as_uint(cb.w);
+            sec = min(sec, max(db, (uint32_t)(bkey >> 32)));
+            const bool better = k < bkey;
+            bkey = better ? k : bkey; best = better ? (int)tb : best;
+        }
+    }
+}
+// slot of voxel `key` in the directory (linear probing past the rare collision), or an empty slot
+__device__ __forceinline__ m3d_u32x2 m3d_tile_find(m3d_lu2 vs, uint32_t key) {
+    uint32_t h = (key * 0x9E3779B1u) >> (32 - 11);
+    m3d_u32x2 s = vs[h];
+    while (s.x != key && s.x != M3D_INVALID_KEY) { h = (h + 1u) & (M3D_TILE_VS - 1u); s = vs[h]; }
+    return s;
+}
+// one staged voxel {first LDS position | population << 16} against the query. A crowded voxel (a surface close to the sensor puts a
+// hundred and more points into one 10 cm voxel) is walked chunk by chunk — M3D_CHUNK consecutive LDS positions, their exact box
+// (computed when the image was staged) first: the points of a voxel keep their firing order, which sweeps the surface strip by
+// strip, so once a good candidate is known all but the chunks around the query are provably farther and never read. A skipped
+// chunk's box distance bounds its points in `sec`, like a pruned voxel's.
+__device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, m3d_lf4 boxes, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, float& bound) {
+    const uint32_t t = sv & 0xFFFFu, n = sv >> 16;
+    if (boxes == nullptr || n <= (uint32_t)M3D_LONG_ROW) { m3d_tile_scan(sp, t, t + n, ux, uy, uz, bkey, best, sec); return; }
+    const uint32_t te = t + n, cl = (te - 1u) / M3D_CHUNK;
+    for (uint32_t c = t / M3D_CHUNK; c <= cl; c++) {
+        const float4 mn = m3d_ld(boxes, 2 * c), mx = m3d_ld(boxes, 2 * c + 1);
+        const float dx = fmaxf(fmaxf(mn.x - ux, ux - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - uy, uy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - uz, uz - mx.z), 0.f);
+        const float bd = dx * dx + dy * dy + dz * dz;
+        if (bd > bound) { sec = min(sec, __float_as_uint(bd)); continue; }
+        m3d_tile_scan(sp, max(t, c * M3D_CHUNK), min(te, (c + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
+        bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+    }
+}
+// phase 1 of the search, voxel B of the compile-time visiting order at offset (DX, DY, DZ): one unconditional directory probe (no
+// branch: 26 of them are in flight together); the voxel enters the lane's work mask when it exists, is not provably farther than
+// the bound the home voxel left, and its first slot holds it (or something else: phase 2 then probes on)
+template <int B, int DX, int DY, int DZ>
+__device__ __forceinline__ void m3d_tile_probe(m3d_lu2 vs, const float (&G)[3][3], uint32_t key0, int sh1, int sh2, float bound, uint32_t& sec, uint32_t& mask) {
+    const float lb = G[0][DX + 1] + G[1][DY + 1] + G[2][DZ + 1];
+    const uint32_t key = key0 + (uint32_t)(DX + DY * (1 << sh1) + DZ * (1 << sh2));
+    const m3d_u32x2 s = vs[(key * 0x9E3779B1u) >> (32 - 11)];
+    const bool near = !(lb > bound);
+    sec = near ? sec : min(sec, __float_as_uint(lb));          // a pruned voxel bounds its points (+inf = outside the grid: no-op)
+    mask |= (near && s.x != M3D_INVALID_KEY) ? (1u << B) : 0u;
+}
+// per-query search state carried across the images of a tile
+struct M3dTileQ {
+    float G[3][3];              // squared conservative gaps to the voxels at offset -1 / 0 / +1 per axis; +inf = outside the grid
+    uint32_t key0;              // key of the query's voxel (modular arithmetic: exact for every voxel inside the grid)
+    unsigned long long bkey;    // (d2 bits << 32 | input index) of the best candidate so far
+    uint32_t sec;               // bits of a squared lower bound of every non-winning candidate
+    float bound;                // prune voxels whose box is farther than this
+};
+__device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float uy, float uz, float dmax2, bool seeded, float dseed, M3dTileQ& Q, long long& code_out) {
+    const float u[3] = { ux, uy, uz };
+    int ic[3];
+    const float inf = __uint_as_float(M3D_INF_BITS);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float f = m3d_cell_f(u[a], g.mn[a], g.inv_leaf);     // k_nn_iter filed the query: -1 <= f <= dims
+        ic[a] = (int)f;
+        const float r = (u[a] - g.mn[a]) - f * g.leaf;
+        const float gl = fmaxf(r - g.prune_slack, 0.f), gh = fmaxf((g.leaf - r) - g.prune_slack, 0.f);
+        Q.G[a][0] = (ic[a] >= 1) ? gl * gl : inf;                       // (ic - 1 <= dims - 1 always)
+        Q.G[a][1] = (ic[a] >= 0 && ic[a] < g.dims[a]) ? 0.f : inf;
+        Q.G[a][2] = (ic[a] + 1 < g.dims[a]) ? gh * gh : inf;            // (ic + 1 >= 0 always)
+    }
+    code_out = (long long)(ic[0] + 1) | ((long long)(ic[1] + 1) << 16) | ((long long)(ic[2] + 1) << 32);
+    const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
+    Q.key0 = (uint32_t)ic[0] + ((uint32_t)ic[1] << sh1) + ((uint32_t)ic[2] << sh2);
+    Q.bkey = ((unsigned long long)M3D_INF_BITS << 32) | 0xFFFFFFFFull;
+    Q.sec = M3D_INF_BITS;
+    Q.bound = dmax2 * 1.0001f;
+    if (seeded) Q.bound = fminf(Q.bound, dseed * 1.0001f);   // the previous match lies within these 27 voxels: it bounds the search before the first probe
+}
+// one staged image: returns the LDS position of a NEW best candidate, or -1 when the best so far stands
+__device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d_lf4 sp, m3d_lf4 boxes, const int* kdelta, float ux, float uy, float uz, M3dTileQ& Q) {
+    const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
+    int best = -1;
+    // home voxel: every lane, no divergence; leaves the bound that prunes most of the other 26
+    if (Q.G[0][1] + Q.G[1][1] + Q.G[2][1] == 0.f) {
+        const m3d_u32x2 s = m3d_tile_find(vs, Q.key0);
+        if (s.x == Q.key0) m3d_tile_voxel(sp, boxes, s.y, ux, uy, uz, Q.bkey, best, Q.sec, Q.bound);
+        Q.bound = fminf(Q.bound, m3d_key_d2(Q.bkey) * 1.0001f);
+    }
+    uint32_t mask = 0u;
+#define M3D_P(b, dx, dy, dz) m3d_tile_probe<b, dx, dy, dz>(vs, Q.G, Q.key0, sh1, sh2, Q.bound, Q.sec, mask)
+    M3D_P(1, -1, 0, 0); M3D_P(2, 1, 0, 0); M3D_P(3, 0, -1, 0); M3D_P(4, 0, 1, 0); M3D_P(5, 0, 0, -1); M3D_P(6, 0, 0, 1);
+    M3D_P(7, -1, -1, 0); M3D_P(8, 1, -1, 0); M3D_P(9, -1, 1, 0); M3D_P(10, 1, 1, 0);
+    M3D_P(11, -1, 0, -1); M3D_P(12, 1, 0, -1); M3D_P(13, -1, 0, 1); M3D_P(14, 1, 0, 1);
+    M3D_P(15, 0, -1, -1); M3D_P(16, 0, 1, -1); M3D_P(17, 0, -1, 1); M3D_P(18, 0, 1, 1);
+    M3D_P(19, -1, -1, -1); M3D_P(20, 1, -1, -1); M3D_P(21, -1, 1, -1); M3D_P(22, 1, 1, -1);
+    M3D_P(23, -1, -1, 1); M3D_P(24, 1, -1, 1); M3D_P(25, -1, 1, 1); M3D_P(26, 1, 1, 1);
+#undef M3D_P
+    // phase 2: the voxels that survived, nearest kinds first (faces, edges, corners), each scanned in full
+    while (mask) {
+        const int b = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        const uint32_t key = Q.key0 + (uint32_t)kdelta[b];
+        const m3d_u32x2 s = m3d_tile_find(vs, key);
+        if (s.x == key) m3d_tile_voxel(sp, boxes, s.y, ux, uy, uz, Q.bkey, best, Q.sec, Q.bound);
+    }
+    Q.bound = fminf(Q.bound, m3d_key_d2(Q.bkey) * 1.0001f);
+    return best;
 }
 
 struct M3dNnArgs {
@@ -722,6 +677,16 @@ struct M3dNnArgs {
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
     int rot;                           // XCD rotation of the block -> pair map (m3d_map_block)
+    // the LDS-staged search: a block with many queries to search BINS them by the target tile that owns their home bucket
+    // (k_nn_iter), k_nn_tiles then answers every tile's queries from LDS
+    int tiles;                         // 1 = on
+    int ntile_max;                     // tiles per pair the workspace is laid out for (>= tiles of every target of the batch)
+    float4* rec;                       // per pair [ntile_max][M3D_TILE_QCAP] + [match_stride]: query records {u.xyz, bits(query | seeded << 31)} of the
+                                       //   tiles, then the records that take the global walk (home bucket empty, tile flagged, slab full)
+    float* recd;                       // same layout: squared distance to the seed (the previous match)
+    unsigned long long rec_stride;     // records per pair
+    unsigned int* tcnt;                // per pair [ntile_max + 1]: records per tile, then records of the global-walk list (zero between iterations)
+    int cnt_stride;
 };
 
 #define NN_SETUP()                                                                                          \
@@ -849,7 +814,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {   // (one copy of the row walk in the code: a rolled loop, not two inlined calls)
-        if (found) m3d_walk_rows(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit);
+        if (found) m3d_walk_rows<false>(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit);
         // ... the group agrees on the bound; the other rows are then mostly discarded by their box distance
         float bnd = W.bound;
 #pragma unroll
@@ -931,6 +896,88 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     if (i < n) { M3D_STAT(sit, 0); if (cls == 1) M3D_STAT(sit, 3); if (cls == 2) M3D_STAT(sit, 4); }
     if (nW == 0) { M3D_BT_END(0); return; }   // block-uniform
     if (tid == 0) M3D_STAT(sit, nW >= A.lane_min ? 5 : 6);
+    if (nW >= A.lane_min && A.tiles && J.tgt.thdr) {
+        // ---- many queries to search, the target has tiles: bin them, k_nn_tiles answers them from LDS ----------------
+        // A query goes to the tile that owns its home bucket (one probe of the level's table: the bucket's first sorted position
+        // names the tile); every other bucket of its 2x2x2 neighbourhood is within one bucket of that one, hence staged with
+        // the tile. A query whose home bucket is empty or outside the grid, whose tile is flagged (staged set too large) or
+        // whose tile's slab is full goes to the pair's global-walk list instead. One returning atomic per wave and tile.
+        const M3dTileHdr* thdr = J.tgt.thdr;
+        unsigned int* tcnt = A.tcnt + (size_t)pair * A.cnt_stride;
+        int tile = -2;   // -2 = nothing to file, -1 = global-walk list, >= 0 = tile
+        if (cls != 0) {
+            M3dQuery Q;
+            if (!m3d_query_setup(g, ux, uy, uz, Q)) out[i] = -1;
+            else {
+                // the 2x2x2 buckets of the (unrestricted) neighbourhood: ANY occupied one names a tile that stages them all; the home
+                // bucket is probed first (it is the occupied one for two queries in three), the others together, only when it is empty
+                const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+                const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
+                const int hx = min(max((Q.ic[0] >> 1) - b0x, 0), nbx), hy = min(max((Q.ic[1] >> 1) - b0y, 0), nby), hz = min(max((Q.ic[2] >> 1) - b0z, 0), nbz);
+                {
+                    const uint32_t key = m3d_bucket_key(g, b0x + hx, b0y + hy, b0z + hz);
+                    uint32_t slot = m3d_hash_slot(key, g.hshift);
+                    uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
+                    while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
+                    if (lo.x == key) tile = (int)(lo.y / (uint32_t)M3D_TILE_PTS);
+                }
+                if (tile < 0) {
+                    uint32_t key[8], slot[8]; uint4 lo[8]; bool act[8];
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+                        act[b] = ox <= nbx && oy <= nby && oz <= nbz && !(ox == hx && oy == hy && oz == hz);
+                        key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
+                        slot[b] = m3d_hash_slot(key[b], g.hshift);
+                        lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+                        if (act[b]) lo[b] = m3d_ld(tab, 2 * (size_t)slot[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        if (!act[b]) continue;
+                        while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) { slot[b] = (slot[b] + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot[b]); }
+                        if (lo[b].x == key[b] && tile < 0) tile = (int)(lo[b].y / (uint32_t)M3D_TILE_PTS);
+                    }
+                    if (tile < 0) {   // no occupied bucket around the query: answered here (what the walk would find: nothing, not even a point)
+                        tile = -2;
+                        if (cls == 1) out[i] = -1;   // (cannot happen: a seed lies in one of these buckets)
+                        else { out[i] = M3D_NN_NONE_CACHED; cache[i] = m3d_voxel_code(Q); }
+                    }
+                }
+            }
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t pos = 0;
+        unsigned long long todo = __ballot(tile >= 0);
+        while (todo) {   // wave-uniform: one trip per distinct tile of the wave (neighbouring queries: a handful)
+            const int leader = (int)__ffsll((long long)todo) - 1;
+            const int t0 = __shfl(tile, leader);
+            const unsigned long long same = __ballot(tile == t0);
+            uint32_t base = 0xFFFFFFFFu;
+            if (lane == leader && thdr[t0].flags == 0u) base = atomicAdd(&tcnt[t0], (unsigned int)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (tile == t0) {
+                pos = base + (uint32_t)__popcll(same & lt);
+                if (base == 0xFFFFFFFFu || pos >= (uint32_t)M3D_TILE_QCAP) tile = -1;
+            }
+            todo &= ~same;
+        }
+        const unsigned long long om = __ballot(tile == -1);
+        if (om) {
+            const int leader = (int)__ffsll((long long)om) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&tcnt[A.ntile_max], (unsigned int)__popcll(om));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (tile == -1) pos = base + (uint32_t)__popcll(om & lt);
+        }
+        if (tile >= -1) {
+            const size_t r = (size_t)pair * A.rec_stride + (size_t)(tile >= 0 ? tile : A.ntile_max) * M3D_TILE_QCAP + pos;
+            A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
+            A.recd[r] = dseed;
+        }
+        M3D_BT_END(nW);
+        return;
+    }
     if (nW >= A.lane_min) {
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
@@ -974,6 +1021,154 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __syncthreads();
 #endif
     M3D_BT_END(nW);
+}
+
+// k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
+// the voxel directory and the tile's own + neighbouring buckets' points (one coalesced index stream, one 16-B gather per staged
+// point, all independent) — and answers every query record of the tile against it, one record per thread; a tile with several
+// images (a crowded stretch) stages them one after the other, the queries' best-so-far riding in registers. Results go where
+// k_nn_iter puts its own (match / cache / state).
+// Workgroups are dealt over the XCDs tile by tile, NOT pair by pair like the other kernels of the iteration: nothing here is read
+// twice (records, images and points stream through once), and a pair with crowded tiles then loads all XCDs instead of one.
+#define M3D_TILE_THREADS 512
+__global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int n_pairs, int ntile, int first_of_level, M3dNnArgs A) {
+    __shared__ m3d_f32x4 s_pts[M3D_TILE_PCAP];
+    __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
+    __shared__ m3d_f32x4 s_box[2 * (M3D_TILE_PCAP / M3D_CHUNK)];   // exact {min, max} of every M3D_CHUNK staged points (images with crowded voxels only)
+    __shared__ int s_kd[32];
+    const int blk = (int)(blockIdx.x / (unsigned)n_pairs), pair = (int)((blockIdx.x + (unsigned)blk) % (unsigned)n_pairs);   // tile t of pair p: XCD (p - t) mod 8
+    const int tid = (int)threadIdx.x;
+    unsigned int* tcnt = A.tcnt + (size_t)pair * A.cnt_stride;
+    const unsigned int qn_all = tcnt[blk];          // (uniform: every thread reads the same word)
+    if (qn_all == 0u) return;
+    const M3dJob& J = jobs[pair];
+    const M3dPairState* st = A.states + pair;
+    if (st->done || (!first_of_level && st->level_done)) return;   // (k_nn_iter then filed nothing: unreachable)
+    M3D_TBT_BEGIN();
+    const M3dGrid g = J.tgt.g;
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts);
+    const float dmax2 = J.dmax2;
+    const M3dTileHdr H = J.tgt.thdr[blk];
+    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+    if (tid < 27) {   // key offset of voxel b of the visiting order (m3d_tile_search): dx + dy * 2^sh1 + dz * 2^sh2
+        const int ord[27] = { 13, 12, 14, 10, 16, 4, 22, 9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26 };   // index = (dx+1) + 3 (dy+1) + 9 (dz+1)
+        const int v = ord[tid], dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
+        s_kd[tid] = dx + dy * (1 << (g.cb[0] + 1)) + dz * (1 << (g.cb[0] + g.cb[1] + 2));
+    }
+    const unsigned int qn = min(qn_all, (unsigned int)M3D_TILE_QCAP);
+    const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP);
+    const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP;
+    const m3d_lu2 vs = (m3d_lu2)s_vs;
+    const m3d_lf4 sp = (m3d_lf4)s_pts;
+    unsigned int n_staged = 0;
+    bool crowded = false;
+    for (unsigned int q0 = 0; q0 < qn; q0 += M3D_TILE_THREADS) {
+        const unsigned int q = q0 + (unsigned int)tid;
+        const bool have = q < qn;
+        // the record first: its loads are in flight while the image is staged
+        const float4 r4 = have ? m3d_ld(rec, (size_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float dseed = have ? recd[q] : 0.f;
+        const uint32_t w = __float_as_uint(r4.w);
+        const bool seeded = (w >> 31) != 0u;
+        M3dTileQ Q; long long code = 0;
+        int m = -1;
+        for (unsigned int j = 0; j < H.n_img; j++) {
+            const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
+            const uint8_t* img = J.tgt.timg + (size_t)image * M3D_TILE_IMG_BYTES;
+            const m3d_gu32 gi = m3d_as_global(reinterpret_cast<const uint32_t*>(img + M3D_TILE_VS * 8));
+            if (j != 0u || q0 == 0u || H.n_img > 1u) {   // stage (a single-image tile with more than one round of records is staged once)
+                if (j != 0u || q0 != 0u) __syncthreads();   // everybody is done with the previous image
+                const M3dTileImgMeta IM = J.tgt.timeta[image];
+                const unsigned int n_points = IM.n_points;
+                crowded = (IM.n_voxels >> 31) != 0u;
+                const m3d_gu4 gs = m3d_as_global(reinterpret_cast<const uint4*>(img));
+                static_assert(M3D_TILE_VS * 8 == 2 * 16 * M3D_TILE_THREADS, "directory staging");
+                const uint4 v0 = m3d_ld(gs, (size_t)tid), v1 = m3d_ld(gs, (size_t)(tid + M3D_TILE_THREADS));
+                uint32_t gx[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); gx[r] = k < n_points ? gi[k] : 0u; }
+                static_assert(M3D_TILE_PCAP == 4 * M3D_TILE_THREADS, "point staging");
+                s_vs[2 * tid] = (m3d_u32x2){ v0.x, v0.y }; s_vs[2 * tid + 1] = (m3d_u32x2){ v0.z, v0.w };
+                s_vs[2 * (tid + M3D_TILE_THREADS)] = (m3d_u32x2){ v1.x, v1.y }; s_vs[2 * (tid + M3D_TILE_THREADS) + 1] = (m3d_u32x2){ v1.z, v1.w };
+                float4 pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) pv[r] = m3d_ld(pts, (size_t)gx[r]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); if (k < n_points) s_pts[k] = (m3d_f32x4){ pv[r].x, pv[r].y, pv[r].z, pv[r].w }; }
+                __syncthreads();
+                if (crowded) {   // chunk boxes: four lanes per chunk, four points each, xor-shuffle merge (every lane of a wave takes part)
+                    static_assert(M3D_TILE_THREADS * 4 == M3D_TILE_PCAP && M3D_CHUNK == 16, "one box lane per four staged points");
+                    const float inf = __uint_as_float(M3D_INF_BITS);
+                    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned int pi = (unsigned int)(tid >> 2) * M3D_CHUNK + 4u * k + (unsigned int)(tid & 3);
+                        if (pi < n_points) {
+                            const m3d_f32x4 pq = s_pts[pi];
+                            mnx = fminf(mnx, pq.x); mny = fminf(mny, pq.y); mnz = fminf(mnz, pq.z);
+                            mxx = fmaxf(mxx, pq.x); mxy = fmaxf(mxy, pq.y); mxz = fmaxf(mxz, pq.z);
+                        }
+                    }
+#pragma unroll
+                    for (int o = 1; o < 4; o <<= 1) {
+                        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+                        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+                    }
+                    if ((tid & 3) == 0) { s_box[2 * (tid >> 2)] = (m3d_f32x4){ mnx, mny, mnz, 0.f }; s_box[2 * (tid >> 2) + 1] = (m3d_f32x4){ mxx, mxy, mxz, 0.f }; }
+                    __syncthreads();
+                }
+                n_staged += n_points;
+                M3D_TBT_STAGED();
+            }
+            if (have) {
+                if (j == 0u) m3d_tile_query(g, r4.x, r4.y, r4.z, dmax2, seeded, dseed, Q, code);
+                const int b = m3d_tile_search(g, vs, sp, crowded ? (m3d_lf4)s_box : (m3d_lf4)nullptr, s_kd, r4.x, r4.y, r4.z, Q);
+                if (b >= 0) m = (int)gi[b];   // LDS position -> sorted position
+            }
+        }
+        if (have) {
+            const int qi = (int)(w & 0x7FFFFFFFu);
+            const float d2 = m3d_key_d2(Q.bkey);
+            // "nothing at all in the 27 voxels" may be cached only when every existing voxel was looked up and found empty
+            if (!(m >= 0 && d2 <= dmax2)) m = (seeded || m >= 0 || Q.sec != M3D_INF_BITS) ? -1 : M3D_NN_NONE_CACHED;
+            out[qi] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, __uint_as_float(Q.sec) };
+        }
+    }
+    if (tid == 0) { tcnt[blk] = 0u; atomicAdd(&A.states[pair].ctr[0], qn); }   // the counter is zero again for the next iteration
+    M3D_TBT_END(0, qn, n_staged);
+}
+
+// k_nn_gwalk: the pair's global-walk list (queries of flagged tiles and of full slabs: normally empty), the per-lane walk of k_nn_iter
+// over records. A few workgroups per pair stride over the list; the reduction pass zeroes its counter.
+#define M3D_GWALK_BLOCKS 32
+__global__ __launch_bounds__(256) void k_nn_gwalk(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    NN_SETUP();
+    (void)src; (void)R; (void)tt; (void)n;
+    const unsigned int on = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
+    if ((unsigned int)blk * 256u >= on) return;
+    const size_t rbase = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
+    const float4* rec = A.rec + rbase;
+    const float* recd = A.recd + rbase;
+    unsigned int done = 0;
+    for (unsigned int q0 = (unsigned int)blk * 256u; q0 < on; q0 += (unsigned int)bpp * 256u) {
+        const unsigned int q = q0 + threadIdx.x;
+        if (q < on) {
+            const float4 r4 = rec[q];
+            const uint32_t w = __float_as_uint(r4.w);
+            const int qi = (int)(w & 0x7FFFFFFFu);
+            long long code = 0; float sec = 0.f;
+            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, r4.x, r4.y, r4.z, dmax2, (w >> 31) != 0u, recd[q], code, sec, 0);
+            out[qi] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
+        }
+        done += min(256u, on - q0);
+    }
+    if (threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], done);
 }
 
 // point-to-point: expand the 17 transported sums into the spec's 29 slots (exact integer identities:
@@ -1188,9 +1383,11 @@ template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot) {
+                                                                    M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
+                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk, rot);
+    if (gw_cnt && blk == 0 && threadIdx.x == 0) gw_cnt[(size_t)pair * gw_stride] = 0u;   // k_nn_tiles' global-walk list: read by several of its workgroups, so zeroed one launch later
     const M3dJob& J = jobs[pair];
     M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
 
@@ -1244,33 +1441,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
 }
 
 
-__global__ __launch_bounds__(256) void k_solve_update(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, unsigned int seq,
-                                                      unsigned long long* __restrict__ progress, const long long* __restrict__ partials, int bpp_a) {
-    // one workgroup per pair: add up the reduction pass's block partials (8 segments x 32 slots), then one thread solves
-    __shared__ long long s_part[8][M3D_PARTIAL_STRIDE];
-    const int p = blockIdx.x;
-    const M3dJob& J = jobs[p];
-    M3dPairState* st = J.st;
-    const bool skip = st->done || (!first_of_level && st->level_done);
-    if (!skip && partials) {
-        const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
-        long long v = 0;
-        if (slot < M3D_NSUMS) for (int b = seg; b < bpp_a; b += 8) v += partials[((size_t)p * bpp_a + b) * M3D_PARTIAL_STRIDE + slot];
-        s_part[seg][slot] = v;
-        __syncthreads();
-        if (threadIdx.x < M3D_NSUMS) {
-            long long t = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
-            s_part[0][threadIdx.x] = t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    if (!skip) m3d_solve_pair(J, first_of_level, partials ? s_part[0] : nullptr);
-    m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
-}
-
 // ---- introspection: NN of arbitrary queries --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_debug_nn(M3dLevelDev L, const float* __restrict__ q, int nq, float dmax2,
                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_d2) {
@@ -1287,21 +1457,6 @@ __global__ __launch_bounds__(256) void k_debug_nn(M3dLevelDev L, const float* __
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-static inline int icp_blocks(int max_n_src) {
-    int b = (max_n_src + ICP_THREADS - 1) / ICP_THREADS;
-    return b < 1 ? 1 : b;
-}
-// blocks per pair of the LDS variant: fill the chip about once (256 CUs x 3 resident blocks), at least one
-// chunk per wave, and amortise the 29-term reduction over several chunks per wave when the batch is large
-static inline int icp_lds_bpp(int max_n_src, int n_pairs) {
-    const int n_chunks = (max_n_src + 63) / 64;
-    int need = (n_chunks + ICP_WAVES - 1) / ICP_WAVES;
-    int cap = (256 * 3) / (n_pairs < 1 ? 1 : n_pairs);
-    if (cap < 8) cap = 8;
-    int b = need < cap ? need : cap;
-    return b < 1 ? 1 : b;
-}
-
 // blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
 __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }
 int m3d_ticket_words(int n_pairs, int max_n_src) {
@@ -1316,33 +1471,29 @@ int m3d_acc_blocks(int max_n_src) {
     return b < 1 ? 1 : b;
 }
 
-static void launch_accumulate(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, int variant,
-                              const M3dNnWork& w, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr, long long* partials = nullptr,
-                              unsigned int seq = 0, unsigned long long* progress = nullptr, int fuse_solve = 0) {
-    if (variant == 2) {
-        // search: one block per 256 queries; reduction: ~8 queries per thread so the 29-term wave reduction is amortised
-        int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-        M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
-        if (k0) (void)hipEventRecord(k0, s);    // the dominant kernel alone (bench.py roofline)
-        hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-        M3D_DBG(s, "k_nn_iter");
-        if (k1) (void)hipEventRecord(k1, s);
-        const int bpp_a = m3d_acc_blocks(max_n_src);
-        if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot);
-        else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot);
-        M3D_DBG(s, "k_accumulate_matches");
-    } else if (variant == 0) {
-        dim3 grid(icp_blocks(max_n_src), n_pairs);
-        if (metric == 1) hipLaunchKernelGGL(k_icp_accumulate<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
-        else hipLaunchKernelGGL(k_icp_accumulate<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, first_of_level);
-        M3D_DBG(s, "k_icp_accumulate");
-    } else {
-        const int bpp = icp_lds_bpp(max_n_src, n_pairs);
-        dim3 grid(bpp * n_pairs);
-        if (metric == 1) hipLaunchKernelGGL(k_icp_lds<1>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
-        else hipLaunchKernelGGL(k_icp_lds<0>, grid, dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp, first_of_level);
-        M3D_DBG(s, "k_icp_lds");
+// One Gauss-Newton iteration: k_nn_iter (classify; sparse blocks search cooperatively, dense blocks bin their queries by target
+// tile), k_nn_tiles (the binned queries, from LDS), k_accumulate_matches (residuals, 29-term reduction; with fuse_solve the last
+// block of every pair solves and updates the pose).
+static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, const M3dNnWork& w,
+                             hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
+    int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
+    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
+    A.tiles = w.tiles; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
+    if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
+    hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+    M3D_DBG(s, "k_nn_iter");
+    if (w.tiles) {
+        hipLaunchKernelGGL(k_nn_tiles, dim3(w.ntile_max * n_pairs), dim3(M3D_TILE_THREADS), 0, s, d_jobs, n_pairs, w.ntile_max, first_of_level, A);   // block -> (pair, tile): tile-major
+        M3D_DBG(s, "k_nn_tiles");
+        hipLaunchKernelGGL(k_nn_gwalk, dim3(M3D_GWALK_BLOCKS * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, M3D_GWALK_BLOCKS, first_of_level, A);
+        M3D_DBG(s, "k_nn_gwalk");
     }
+    if (k1) (void)hipEventRecord(k1, s);
+    const int bpp_a = m3d_acc_blocks(max_n_src);
+    unsigned int* gw = w.tiles ? w.tcnt + w.ntile_max : nullptr;   // the global-walk list's counter: zeroed here, behind its readers
+    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride);
+    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride);
+    M3D_DBG(s, "k_accumulate_matches");
 }
 
 // Everything a job needs from the bucketing of its clouds, straight from the pipeline's device-side words (M3dLevelMeta): the
@@ -1374,32 +1525,14 @@ hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int
     return hipGetLastError();
 }
 
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
-                                      const M3dNnWork& w) {
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, 1, variant, w);
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w) {
+    launch_iteration(s, d_jobs, n_pairs, max_n_src, metric, 1, w, nullptr, nullptr, nullptr, 0u, nullptr, 0);   // sums by atomics into the state, no solve
     return hipGetLastError();
 }
 
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
-                                    hipEvent_t k1) {
-    static const bool fuse = [] { const char* v = getenv("M3DREG_FUSE_SOLVE"); return v ? atoi(v) != 0 : true; }();   // A/B switch
-    if (variant == 2 && fuse) {
-        // search kernel + reduction pass; the reduction's last block of every pair solves and updates the pose (a8)
-        launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials, seq, progress, 1);
-        return hipGetLastError();
-    }
-    if (variant == 2) {
-        launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, k0, k1, w.partials);
-        hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)w.partials, m3d_acc_blocks(max_n_src));
-        M3D_DBG(s, "k_solve_update");
-        return hipGetLastError();
-    }
-    if (k0) (void)hipEventRecord(k0, s);
-    launch_accumulate(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, variant, w, nullptr, nullptr, nullptr);   // fused variants add into the state with atomics
-    if (k1) (void)hipEventRecord(k1, s);
-    hipLaunchKernelGGL(k_solve_update, dim3(n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, seq, progress, (const long long*)nullptr, 0);
-    M3D_DBG(s, "k_solve_update");
+                                    const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0, hipEvent_t k1) {
+    launch_iteration(s, d_jobs, n_pairs, max_n_src, metric, first_of_level, w, k0, k1, w.partials, seq, progress, 1);
     return hipGetLastError();
 }
 

@@ -61,10 +61,42 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
     uint16_t cum[8];       // cum[s] = points of the bucket in voxels 0..s (s = (ix&1)|(iy&1)<<1|(iz&1)<<2)
 };
 
+// ---- target tiles: the LDS-staged search (k_nn_tiles) ------------------------------------------------------------------
+// A TILE owns the buckets whose first sorted position lies in [t * M3D_TILE_PTS, (t + 1) * M3D_TILE_PTS): consecutive buckets of the
+// Morton order, i.e. one compact patch of the scanned surface. Its IMAGE, built once per target by the bucketing pipeline
+// (k_tile_build), is what a workgroup must hold in LDS to answer every query that has an occupied bucket of the tile among the
+// 2x2x2 buckets of its 27-voxel neighbourhood: the tile's own buckets plus every occupied bucket within one bucket of them.
+//   vslots[M3D_TILE_VS]    open-addressing directory of the staged VOXELS: {voxel key, first LDS position | population << 16}
+//                          (all-ones key = empty); voxel key = ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2): a neighbour's key is
+//                          the query voxel's key plus a constant
+//   gidx[n_points]         sorted position (in the level's pts array) of every staged point, in LDS order
+// A staged set that exceeds one image's capacities (a crowded stretch: a surface a metre from the sensor) is cut, bucket by bucket,
+// into several images (the first is image t, the others come from a pool behind the tiles' own images); the workgroup then stages
+// them one after the other and carries every query's best-so-far across them. Only a single bucket beyond an image's capacity (or an
+// exhausted pool) flags the tile; its queries take the global walk instead.
+#define M3D_TILE_PTS 512
+#define M3D_TILE_HS 1024        // k_tile_build: slots of the staged-bucket set
+#define M3D_TILE_ECAP 512       // staged buckets per tile at most
+#define M3D_TILE_VS 2048        // slots of the voxel directory
+#define M3D_TILE_VCAP 1280      // staged voxels per tile at most
+#define M3D_TILE_PCAP 2048      // staged points per tile at most
+#define M3D_TILE_QCAP 2048      // query records a tile accepts per iteration (the rest takes the global walk)
+#define M3D_TILE_OVERSIZE 1u
+#define M3D_TILE_MAXIMG 32
+struct M3dTileHdr { uint32_t extra, n_img, flags, pad; };   // images of the tile: image t, then images extra .. extra + n_img - 2
+struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points (k_nn_tiles then builds chunk boxes)
+static_assert(sizeof(M3dTileHdr) == 16 && sizeof(M3dTileImgMeta) == 8, "tile image layout");
+__host__ __device__ inline int m3d_tile_pool(int n_tiles) { return n_tiles / 2 + 8; }   // extra images per level
+#define M3D_TILE_IMG_BYTES (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 4)
+__host__ __device__ inline int m3d_tiles_of(int n) { return (n + M3D_TILE_PTS - 1) / M3D_TILE_PTS; }
+
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* pts;
     const float4* nrm;
-    const float4* nrm_in;      // the same normals by INPUT index (fused kernel variants 0/1 only)
+    const float4* nrm_in;      // the same normals by INPUT index
+    const M3dTileHdr* thdr;    // [m3d_tiles_of(n)] tile headers, or null (the level then has no tiles: every search walks global memory)
+    const uint8_t* timg;       // [tiles + pool][M3D_TILE_IMG_BYTES] tile images
+    const M3dTileImgMeta* timeta;   // [tiles + pool] staged points / voxels of every image
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
     const float4* cbox;       // [2 * ceil(n / 16)] exact AABB {min, max} of every 16 consecutive sorted points: lets the search skip most of a
@@ -85,7 +117,7 @@ struct M3dPairState {      // per-registration state, lives in HBM for the whole
     int32_t done;                  // final: no further iteration may run
     int32_t level_done;            // current level converged: skip its remaining iterations
     uint32_t ticket;
-    uint32_t ctr[2];               // diagnostics: chunks served from LDS / chunks that fell back to the global walk
+    uint32_t ctr[2];               // diagnostics: searches answered from LDS tiles / by the global walk of the fallback blocks
     uint32_t gsync[2];             // pair 0 only: {pairs that reported this iteration, of which still active} (k_solve_update)
 };
 

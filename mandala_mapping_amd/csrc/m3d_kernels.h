@@ -52,6 +52,9 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
     float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
     float4* nrm_sorted;          // [n] out: the same normals in this level's sorted order (level builds of point-to-plane clouds, else null)
+    M3dTileHdr* thdr;            // [m3d_tiles_of(n)] out: tile headers (levels of clouds that can be targets, else null)
+    uint8_t* timg;               // [tiles + pool][M3D_TILE_IMG_BYTES] out: tile images (k_tile_build), tiles = m3d_tiles_of(n), pool = m3d_tile_pool(tiles)
+    M3dTileImgMeta* timeta;      // [tiles + pool] out
 };
 
 float m3d_unord_f32(uint32_t u);
@@ -60,7 +63,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 // n_builds = n_clouds * grids_per_cloud, the builds of a cloud are consecutive. No host input beyond sizes: the grid geometry, the
 // number of sort passes and the error state of every cloud are derived on the device.
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   float plane_ratio, int min_pts, float min_spread);
+                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread);
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // aggregate.hip
@@ -112,33 +115,36 @@ struct M3dMapArgs {
 };
 hipError_t m3d_launch_map_insert(hipStream_t s, const M3dMapArgs& A);
 
-// icp.hip
-// variant: 0 = fused, one thread per query; 1 = fused, wave-cooperative LDS-staged buckets;
-//          2 = split (default): k_nn_iter (classify + search, one int32 result per query), then k_accumulate_matches,
-//              whose last block per pair also solves and updates the pose
-struct M3dNnWork {               // variant-2 workspace, all per pair with the same stride (a whole number of 256-query blocks)
+// icp.hip: one Gauss-Newton iteration = k_nn_iter (classify + search / bin), k_nn_tiles (binned searches from LDS), k_accumulate_matches
+// (residuals + reduction; its last block per pair also solves and updates the pose)
+struct M3dNnWork {               // workspace of the batch, all per pair with the same stride (a whole number of 256-query blocks)
     int* match;                  // [n_pairs * stride] result of every query, kept between iterations (certified / seeds the next search)
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
     float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
-    int lane_min;                // a 256-query block with >= lane_min queries to search walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
+    int lane_min;                // a 256-query block with >= lane_min queries to search bins them / walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
     long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
     M3dPairState* states;        // [n_pairs] the batch's pair states (== jobs[pair].st)
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
     int rot;                     // XCD rotation of the block -> pair map: differs between handles, so concurrent batches do not stack their k-th pairs on one XCD
+    int tiles;                   // 1 = dense blocks bin their searches by target tile and k_nn_tiles answers them from LDS (M3DREG_TILES)
+    int ntile_max;               // tiles per pair the arrays below are laid out for
+    float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP + stride] query records
+    float* recd;                 // same layout: squared distance to the seed
+    unsigned long long rec_stride;
+    unsigned int* tcnt;          // [n_pairs][cnt_stride] records per tile, then (at ntile_max) records of the global-walk list; zero between iterations
+    int cnt_stride;
 };
 // k0/k1 (optional): events recorded immediately before / after the dominant kernel of the iteration (k_nn_iter)
 // seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of
 // host-mapped memory, may be null) so that the host can stop enqueuing iterations without synchronising
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
-                                    int variant, const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0,
-                                    hipEvent_t k1);
+                                    const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0, hipEvent_t k1);
 hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels);
 int m3d_ticket_words(int n_pairs, int max_n_src);
 int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
-hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int variant,
-                                      const M3dNnWork& w);
+hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

@@ -31,6 +31,9 @@ struct DevLevel {
     uint32_t* bigcum = nullptr;
     float4* cbox = nullptr;        // chunk boxes of the sorted points
     uint32_t* order = nullptr;     // the cloud's 256-point blocks, most crowded first
+    M3dTileHdr* thdr = nullptr;    // tile headers / images of the LDS-staged search (null for a source-only cloud)
+    uint8_t* timg = nullptr;
+    M3dTileImgMeta* timeta = nullptr;
     uint32_t bigcap = 0;
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
@@ -65,6 +68,7 @@ struct m3dreg_cloud {
     float leaf[M3DREG_MAX_LEVELS]{};
     bool has_normals = false;
     bool source_only = false;      // m3dreg_cloud_desc.source_only: sorted, but no hash table / chunk boxes / normals — never a target
+    bool has_tiles = false;        // the levels' tile images were built (k_tile_build): the LDS-staged search can use this cloud as a target
     float4* xyz = nullptr;         // coordinates in input order
     float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
@@ -112,7 +116,7 @@ struct m3dreg_handle {
     int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
     int lane_min = 96;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
-    int icp_variant = 2;               // 2 = split search/reduce kernels (default), 1 = fused LDS-staged, 0 = fused per-thread (M3DREG_ICP_VARIANT)
+    int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
     unsigned int* d_tickets = nullptr; // arrival counters of the reduction pass
@@ -122,6 +126,11 @@ struct m3dreg_handle {
     size_t match_pairs_cap = 0;
     int match_stride = 0;
     size_t match_pairs = 0;
+    float4* d_rec = nullptr;           // query records of the LDS-staged search: float4[rec_cap] then float[rec_cap] (seed distances)
+    size_t rec_cap = 0, rec_stride = 0;
+    unsigned int* d_tcnt = nullptr;    // records per tile / of the global-walk list
+    size_t tcnt_cap = 0;
+    int ntile_max = 0, cnt_stride = 0;
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
     int prof_every = 1;                // every n-th iteration is bracketed by events (m3dreg_profile_enable(h, n))
@@ -231,6 +240,12 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
         L.cbox = k.take<float4>(2 * ((n + M3D_CHUNK - 1) / M3D_CHUNK));
         L.order = k.take<uint32_t>((n + 255) / 256);
+        if (!c->source_only) {   // a cloud that can be a target: its tiles
+            const size_t nt = size_t(m3d_tiles_of(int(n))), ni = nt + size_t(m3d_tile_pool(int(nt)));
+            L.thdr = k.take<M3dTileHdr>(nt);
+            L.timg = k.take<uint8_t>(ni * M3D_TILE_IMG_BYTES);
+            L.timeta = k.take<M3dTileImgMeta>(ni);
+        } else { L.thdr = nullptr; L.timg = nullptr; L.timeta = nullptr; }
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
         L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
         L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
@@ -257,6 +272,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         cl[i] = c;
         c->n = int32_t(in[i].n);
         c->n_levels = P.n_levels;
+        c->source_only = in[i].src_only;
         for (int l = 0; l < P.n_levels; l++) c->leaf[l] = P.leaf[l];
         const size_t bytes = carve_cloud(c, nullptr, P);
         int rc = pool_get(h, bytes, c->block);
@@ -349,6 +365,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
     // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
+    bool any_tiles = false;
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
         const bool no_normals = in[i].src_only;   // a source-only cloud: sorted, no normal grid, no normals
@@ -374,6 +391,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
             if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
+            if (!is_ng && !no_normals && h->tiles) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; any_tiles = true; c->has_tiles = true; }
         }
     }
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
@@ -386,8 +404,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
     if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
     B_HIP(hipEventRecord(h->staged, h->stream));
-    B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, P.plane_ratio, P.normal_min_pts,
-                                  P.normal_min_spread));
+    B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, any_tiles, P.plane_ratio,
+                                  P.normal_min_pts, P.normal_min_spread));
     // One event behind the pipeline lets OTHER handles order their streams after it.
     BatchReady* br = new BatchReady();
     if (hipEventCreateWithFlags(&br->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(br->ev, h->stream) != hipSuccess) {
@@ -440,9 +458,10 @@ int finish_sync(m3dreg_handle* h, m3dreg_cloud** cl, size_t k) {
     return rc;
 }
 
-M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in) {
+M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in, bool tiles = false) {
     M3dLevelDev d{};
     d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.cbox = L.cbox; d.dyn = L.dyn; d.g = L.grid;
+    d.thdr = tiles ? L.thdr : nullptr; d.timg = tiles ? L.timg : nullptr; d.timeta = tiles ? L.timeta : nullptr;
     return d;
 }
 
@@ -485,7 +504,7 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
     return M3DREG_OK;
 }
 
-int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
+int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt) {
     // per-pair stride of the per-query arrays: a whole number of 256-query blocks, so that no block of one pair can ever touch
     // slots of the next (an earlier worklist layout raced across pairs with a 64-rounded stride: found with 64 identical
     // pairs giving different results; tests/test_gpu_parity.py::test_identical_pairs_in_one_batch_give_identical_results)
@@ -517,6 +536,29 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src) {
     }
     h->match_stride = int(stride);
     h->match_pairs = n_pairs;
+    if (h->tiles) {   // workspace of the LDS-staged search: per pair, query records per tile + the global-walk list, and their counters
+        const size_t ntile = size_t(m3d_tiles_of(max_n_tgt));
+        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;
+        const size_t cnt_stride = (ntile + 1 + 31) & ~size_t(31);
+        if (n_pairs * rec_stride > h->rec_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->d_rec) hipFree(h->d_rec);
+            h->d_rec = nullptr; h->rec_cap = 0;
+            const size_t cap = n_pairs * rec_stride + n_pairs * rec_stride / 8;
+            HIPCHK(h, hipMalloc((void**)&h->d_rec, (sizeof(float4) + sizeof(float)) * cap));
+            h->rec_cap = cap;
+        }
+        if (n_pairs * cnt_stride > h->tcnt_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->d_tcnt) hipFree(h->d_tcnt);
+            h->d_tcnt = nullptr; h->tcnt_cap = 0;
+            const size_t cap = n_pairs * cnt_stride + n_pairs * cnt_stride / 4;
+            HIPCHK(h, hipMalloc((void**)&h->d_tcnt, sizeof(unsigned int) * cap));
+            h->tcnt_cap = cap;
+            HIPCHK(h, hipMemsetAsync(h->d_tcnt, 0, sizeof(unsigned int) * cap, h->stream));   // once: every iteration leaves its counters at zero
+        }
+        h->ntile_max = int(ntile); h->rec_stride = rec_stride; h->cnt_stride = int(cnt_stride);
+    }
     return M3DREG_OK;
 }
 
@@ -529,6 +571,8 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
     w.rot = h->xcd_rot;
+    w.tiles = h->tiles; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
+    w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     return w;
 }
 
@@ -544,9 +588,9 @@ int validate_params(const m3dreg_params* p) {
 }
 
 // fill one job per (level, pair) + initial state
-int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& max_n_src) {
+int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& max_n_src, int& max_n_tgt) {
     const m3dreg_params& P = h->params;
-    max_n_src = 0;
+    max_n_src = 0; max_n_tgt = 0;
     for (size_t i = 0; i < n_pairs; i++) {
         const m3dreg_cloud* s = pairs[i].source;
         const m3dreg_cloud* t = pairs[i].target;
@@ -558,13 +602,14 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         for (const m3dreg_cloud* c : { s, t })   // a cloud bucketed on ANOTHER handle's stream: this stream waits for that pipeline
             if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
         if (s->n > max_n_src) max_n_src = s->n;   // launch geometry only (the finite count stays on the device; results do not depend on it)
+        if (t->n > max_n_tgt) max_n_tgt = t->n;
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
             J.src = s->lv[s->n_levels - 1].pts; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
             J.src_dyn = s->lv[s->n_levels - 1].dyn;
             J.src_order = s->lv[s->n_levels - 1].order; J.src_nblk = (s->n + 255) / 256;
-            J.tgt = level_dev(t->lv[l], t->nrm_in);
+            J.tgt = level_dev(t->lv[l], t->nrm_in, t->has_tiles && h->tiles);
             J.dmax = P.max_corr_dist[l];
             J.dmax2 = P.max_corr_dist[l] * P.max_corr_dist[l];
             J.min_corr = P.min_correspondences;
@@ -655,7 +700,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_LANE_MIN")) { int q = atoi(v); if (q >= 1 && q <= 257) h->lane_min = q; }
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
-    if (const char* v = getenv("M3DREG_ICP_VARIANT")) { int q = atoi(v); h->icp_variant = (q >= 0 && q <= 2) ? q : 2; }
+    if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return M3DREG_ERR_HIP; }
@@ -673,7 +718,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets }) if (p) hipFree(p);   // (the states live in the jobs' block)
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt }) if (p) hipFree(p);   // (the states live in the jobs' block)
     for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->staged) hipEventDestroy(h->staged);
@@ -784,10 +829,10 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_batch(h, n_pairs);
     if (rc) return rc;
-    int max_n_src = 0;
-    if ((rc = build_jobs(h, pairs, n_pairs, max_n_src))) return rc;
+    int max_n_src = 0, max_n_tgt = 0;
+    if ((rc = build_jobs(h, pairs, n_pairs, max_n_src, max_n_tgt))) return rc;
     const m3dreg_params& P = h->params;
-    if ((rc = ensure_match(h, n_pairs, max_n_src))) return rc;
+    if ((rc = ensure_match(h, n_pairs, max_n_src, max_n_tgt))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
     const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
@@ -810,7 +855,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                 prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
                 if (prev_sampled) { k0 = next_event(h); h->ev_kind.push_back(0); k1 = next_event(h); h->ev_kind.push_back(1); }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, h->icp_variant, nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             h->launched_iters++;
         }
     }
@@ -1510,14 +1555,14 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     m3dreg_pair p;
     p.source = source; p.target = target;
     memcpy(p.init_T, T, sizeof(float) * 16);
-    int max_n_src = 0;
-    if ((rc = build_jobs(h, &p, 1, max_n_src))) return rc;
-    if ((rc = ensure_match(h, 1, max_n_src))) return rc;
+    int max_n_src = 0, max_n_tgt = 0;
+    if ((rc = build_jobs(h, &p, 1, max_n_src, max_n_tgt))) return rc;
+    if ((rc = ensure_match(h, 1, max_n_src, max_n_tgt))) return rc;
     const M3dJob* hj = &h->h_jobs[size_t(level) * h->cap_pairs];
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, hj, sizeof(M3dJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, 1, int(h->cap_pairs), 1));
-    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, h->icp_variant, nn_work(h)));
+    HIPCHK(h, m3d_launch_accumulate_only(h->stream, h->d_jobs, 1, max_n_src, h->params.metric, nn_work(h)));
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const long long* raw = h->h_states[0].sums;

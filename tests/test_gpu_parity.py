@@ -188,20 +188,21 @@ def test_full_size_properties_config3(reg):
     assert np.array_equal(T4, T)
 
 
-def test_kernel_variants_are_bit_identical(reg, orc, monkeypatch):
-    """variant 0 (per-thread global walk) and variant 1 (wave-cooperative LDS-staged buckets) must agree
-    with each other and with the oracle on every bit, including chunks that overflow the LDS budget."""
-    src, tgt, Tgt = synth.hdl32_pair(900, 300, 301, dx=0.3, dy=-0.2, dyaw_deg=25.0)   # big yaw: many fallback chunks
+def test_tile_search_and_global_walk_are_bit_identical(reg, orc, monkeypatch):
+    """The LDS-staged tile search (k_nn_tiles, default) and the global walk (M3DREG_TILES=0) must agree with each other and
+    with the oracle on every bit; the big yaw leaves many queries without an occupied home bucket (global-walk list)."""
+    src, tgt, Tgt = synth.hdl32_pair(900, 300, 301, dx=0.3, dy=-0.2, dyaw_deg=25.0)
     p = _params(leaf=0.1, iterations=6, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
     T0 = synth.perturb(Tgt, np.random.default_rng(5), 1.0, 0.1)
     out = []
-    for variant in ("0", "1", "2"):
-        monkeypatch.setenv("M3DREG_ICP_VARIANT", variant)
+    for tiles in ("0", "1"):
+        monkeypatch.setenv("M3DREG_TILES", tiles)
         R = reg.Registrar(p)
         cs, ct = R.cloud(src), R.cloud(tgt)
         s, e = R.accumulate(cs, ct, T0)
         T, st = R.align(cs, ct, T0)
-        out.append((s, e, T, R.trace(), st))
+        out.append((s, e, T, R.trace(), st, R.counters()))
+    assert out[0][5][0] == 0 and out[1][5][0] > 0            # the tile path really ran in the second build (and only there)
     for o in out[1:]:
         assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1])
         assert np.array_equal(out[0][3], o[3]) and np.array_equal(out[0][2], o[2])
