@@ -341,6 +341,15 @@ __global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict_
         t[i] = (i & 1u) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
     const uint32_t nb = 8u * B.bigcap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) B.bigcum[i] = 0u;
+    if (B.occ) {   // occupancy bitmap of the bucket positions: one bit per bucket key, when the grid is small enough
+        const int kb = B.grid.cb[0] + B.grid.cb[1] + B.grid.cb[2];
+        const bool ok = kb <= M3D_OCC_BITS;
+        if (blockIdx.x == 0 && threadIdx.x == 0) B.dyn[7] = ok ? 1u : 0u;
+        if (ok) {
+            const uint32_t nw = kb > 5 ? (1u << (kb - 5)) : 1u;
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) B.occ[i] = 0u;
+        }
+    }
 }
 
 __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const float4& p) {
@@ -395,6 +404,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
             if (old == M3D_INVALID_KEY) { B.htab[h].start = (uint32_t)j; break; }
             h = (h + 1) & hmask;
         }
+        if (B.occ && B.grid.cb[0] + B.grid.cb[1] + B.grid.cb[2] <= M3D_OCC_BITS) atomicOr(&B.occ[bk >> 5], 1u << (bk & 31u));
     }
 }
 
@@ -506,6 +516,20 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     return off + incl - v;
 }
 
+#define M3D_TILE_CS 4096   // k_tile_build: slots of the candidate-position set (bucket positions around the own buckets, occupied or not)
+#ifdef M3D_TB_STAMPS   // diagnosis build: wall-clock stamps (100 MHz) at the phase boundaries of the first 4096 working workgroups
+__device__ unsigned long long g_tb_stamp[4096][10];
+__device__ unsigned int g_tb_n = 0;
+extern "C" hipError_t m3d_debug_read_tb(unsigned long long* out, unsigned int* n) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tb_stamp), sizeof(unsigned long long) * 4096 * 10);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_tb_n), sizeof(unsigned int));
+    unsigned int z = 0; if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tb_n), &z, sizeof(z));
+    return e;
+}
+#define TB_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && tb_slot < 4096u) g_tb_stamp[tb_slot][k] = wall_clock64(); } while (0)
+#else
+#define TB_STAMP(k) ((void)0)
+#endif
 __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.thdr || !B.htab) return;
@@ -513,9 +537,13 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     const int t = blockIdx.x, p0 = t * M3D_TILE_PTS;
     if (p0 >= nv) return;
     const int p1 = min(p0 + M3D_TILE_PTS, nv);
-    __shared__ uint32_t s_key[M3D_TILE_HS], s_gs[M3D_TILE_HS];
-    __shared__ uint32_t s_vk[M3D_TILE_VS], s_vv[M3D_TILE_VS];
+    // LDS: the candidate set is dead once the staged-bucket list exists: the voxel directory of the image being written lives there
+    __shared__ uint32_t s_a[M3D_TILE_CS];            // phase 2/3: candidate bucket keys | phase 6: voxel directory {keys[VS], values[VS]}
+    static_assert(M3D_TILE_CS >= 2 * M3D_TILE_VS, "the voxel directory re-uses the candidate set's LDS");
+    uint32_t* s_ck = s_a; uint32_t* s_vk = s_a; uint32_t* s_vv = s_a + M3D_TILE_VS;
+    __shared__ uint32_t s_lk[M3D_TILE_ECAP], s_lg[M3D_TILE_ECAP], s_lp[M3D_TILE_ECAP];   // staged buckets: key, slot in the level's table, points | voxels << 16 (later image | offset << 8)
     __shared__ uint32_t s_head[M3D_TILE_PTS];
+    __shared__ uint32_t s_src[M3D_TILE_PCAP];     // sorted position of every staged point of the image being written
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_ip[M3D_TILE_MAXIMG];   // points | voxels << 16 of every image
     __shared__ uint32_t s_cnt, s_over;
@@ -524,9 +552,18 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     const uint32_t hmask = B.dyn[1];
     const int hshift = (int)B.dyn[2];
     const uint32_t* skey = B.skey_out;
-    for (int i = tid; i < M3D_TILE_HS; i += 256) s_key[i] = M3D_INVALID_KEY;
+    const uint4* tab = reinterpret_cast<const uint4*>(B.htab);
+    const bool occ_ok = B.occ != nullptr && g.cb[0] + g.cb[1] + g.cb[2] <= M3D_OCC_BITS;
+#ifdef M3D_TB_STAMPS
+    __shared__ unsigned int s_tbslot;
+    if (threadIdx.x == 0) s_tbslot = atomicAdd(&g_tb_n, 1u);
+    __syncthreads();
+    const unsigned int tb_slot = s_tbslot;
+#endif
+    TB_STAMP(0);
+    for (int i = tid; i < M3D_TILE_CS; i += 256) s_ck[i] = M3D_INVALID_KEY;
     if (tid == 0) { s_cnt = 0u; s_over = 0u; }
-    // own bucket heads, in sorted order
+    // 1. own bucket heads, in sorted order; their bucket coordinates (one point load per head)
     uint32_t nheads = 0;
 #pragma unroll
     for (int r = 0; r < M3D_TILE_PTS / 256; r++) {
@@ -539,51 +576,91 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
         nheads += tot;
     }
     __syncthreads();
-    // the 27 bucket positions around every own bucket: probe the level's table, collect the occupied ones
+    for (uint32_t hd = (uint32_t)tid; hd < nheads; hd += 256u) {
+        const float4 p = B.pts[s_head[hd]];
+        s_head[hd] = (uint32_t)((int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1) | ((uint32_t)((int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1) << 11) |
+                     ((uint32_t)((int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1) << 22);
+    }
+    __syncthreads();
+    TB_STAMP(1);
+    // 2. the 27 bucket positions around every own bucket, as a set (LDS only: neighbouring own buckets share most of them)
     const int nb0 = (g.dims[0] + 1) >> 1, nb1 = (g.dims[1] + 1) >> 1, nb2 = (g.dims[2] + 1) >> 1;
     for (uint32_t item = (uint32_t)tid; item < nheads * 27u; item += 256u) {
         const uint32_t hd = item / 27u, d = item - hd * 27u;
-        const float4 p = B.pts[s_head[hd]];
-        const int cx = ((int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1) + (int)(d % 3u) - 1;
-        const int cy = ((int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1) + (int)((d / 3u) % 3u) - 1;
-        const int cz = ((int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1) + (int)(d / 9u) - 1;
+        const uint32_t c = s_head[hd];
+        const int cx = (int)(c & 2047u) + (int)(d % 3u) - 1, cy = (int)((c >> 11) & 2047u) + (int)((d / 3u) % 3u) - 1, cz = (int)(c >> 22) + (int)(d / 9u) - 1;
         if (cx < 0 || cy < 0 || cz < 0 || cx >= nb0 || cy >= nb1 || cz >= nb2) continue;
         const uint32_t key = m3d_bucket_key(g, cx, cy, cz);
-        uint4 lo;
-        const int gs = m3d_find_bucket(B.htab, hmask, hshift, key, lo);
-        if (gs < 0) continue;
-        uint32_t h = (key * 0x9E3779B1u) >> (32 - 10);
-        static_assert(M3D_TILE_HS == 1024, "staged-bucket set hash: 10 bits");
+        uint32_t h = (key * 0x9E3779B1u) >> (32 - 12);
+        static_assert(M3D_TILE_CS == 4096, "candidate set hash: 12 bits");
         int tries = 0;
-        for (; tries < M3D_TILE_HS; tries++) {
-            const uint32_t old = atomicCAS(&s_key[h], M3D_INVALID_KEY, key);
-            if (old == M3D_INVALID_KEY) { s_gs[h] = (uint32_t)gs; atomicAdd(&s_cnt, 1u); break; }
-            if (old == key) break;
-            h = (h + 1u) & (M3D_TILE_HS - 1u);
+        for (; tries < M3D_TILE_CS; tries++) {
+            const uint32_t old = atomicCAS(&s_ck[h], M3D_INVALID_KEY, key);
+            if (old == M3D_INVALID_KEY || old == key) break;
+            h = (h + 1u) & (M3D_TILE_CS - 1u);
         }
-        if (tries == M3D_TILE_HS) s_over = 1u;
+        if (tries == M3D_TILE_CS) s_over = 1u;
     }
     __syncthreads();
+    TB_STAMP(2);
+    // 3. the occupied candidate positions form the staged list. With the occupancy bitmap: sixteen 4-byte loads per thread answer
+    // "empty" for most candidates at once, the few occupied ones are then looked up in the level's table for their entry; without it
+    // (a grid of more than 2^23 bucket positions): one probe chain per candidate, four in flight.
+    if (occ_ok) {
+        uint32_t key[M3D_TILE_CS / 256], wbit[M3D_TILE_CS / 256];
+#pragma unroll
+        for (int r = 0; r < M3D_TILE_CS / 256; r++) { key[r] = s_ck[256 * r + tid]; wbit[r] = key[r] != M3D_INVALID_KEY ? B.occ[key[r] >> 5] : 0u; }
+#pragma unroll
+        for (int r = 0; r < M3D_TILE_CS / 256; r++) {
+            if (!((wbit[r] >> (key[r] & 31u)) & 1u)) continue;
+            uint32_t slot = m3d_hash_slot(key[r], hshift);
+            uint4 lo = tab[2 * (size_t)slot];
+            while (lo.x != key[r]) { slot = (slot + 1u) & hmask; lo = tab[2 * (size_t)slot]; }   // (the bucket exists)
+            const uint32_t e = atomicAdd(&s_cnt, 1u);
+            if (e < (uint32_t)M3D_TILE_ECAP) { s_lk[e] = key[r]; s_lg[e] = slot; }
+        }
+    } else {
+        for (int s0 = 0; s0 < M3D_TILE_CS; s0 += 1024) {
+            uint32_t key[4], slot[4]; uint4 lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                key[r] = s_ck[s0 + 256 * r + tid];
+                slot[r] = m3d_hash_slot(key[r], hshift);
+                lo[r] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
+                if (key[r] != M3D_INVALID_KEY) lo[r] = tab[2 * (size_t)slot[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (key[r] == M3D_INVALID_KEY) continue;
+                while (lo[r].x != key[r] && lo[r].x != M3D_INVALID_KEY) { slot[r] = (slot[r] + 1u) & hmask; lo[r] = tab[2 * (size_t)slot[r]]; }
+                if (lo[r].x != key[r]) continue;
+                const uint32_t e = atomicAdd(&s_cnt, 1u);
+                if (e < (uint32_t)M3D_TILE_ECAP) { s_lk[e] = key[r]; s_lg[e] = slot[r]; }
+            }
+        }
+    }
+    __syncthreads();
+    TB_STAMP(3);
     M3dTileHdr* H = B.thdr + t;
     const uint32_t n_e = s_cnt;
-    bool over = s_over != 0u || n_e > (uint32_t)M3D_TILE_ECAP;   // block-uniform
-    // populations of the staged buckets, in slot order (thread tid: slots SPT tid .. SPT tid + SPT - 1)
-    constexpr int SPT = M3D_TILE_HS / 256;
-    uint32_t kk[SPT], cnt[SPT], nvx[SPT]; uint4 lo[SPT], hi[SPT];
+    if (s_over != 0u || n_e > (uint32_t)M3D_TILE_ECAP) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }   // block-uniform
+    // 4. populations of the staged buckets (thread tid: entries tid and tid + 256)
+    constexpr int SPT = M3D_TILE_ECAP / 256;
+    uint32_t kk[SPT], cnt[SPT], nvx[SPT], gst[SPT]; uint4 hi[SPT];
     bool occ[SPT];
     bool anybig = false, crowd = false;
     uint32_t my_p = 0u, my_v = 0u;
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
-        const int sl = SPT * tid + q;
-        kk[q] = s_key[sl]; occ[q] = kk[q] != M3D_INVALID_KEY;
-        lo[q] = make_uint4(0u, 0u, 0u, 0u); hi[q] = lo[q]; cnt[q] = 0u; nvx[q] = 0u;
-        if (occ[q] && !over) {
-            const uint32_t gs = s_gs[sl];
-            lo[q] = reinterpret_cast<const uint4*>(B.htab)[2 * (size_t)gs];
-            hi[q] = reinterpret_cast<const uint4*>(B.htab)[2 * (size_t)gs + 1];
-            cnt[q] = lo[q].z;
-            anybig = anybig || lo[q].w != 0u || cnt[q] > (uint32_t)M3D_TILE_PCAP;
+        const uint32_t e = (uint32_t)(tid + 256 * q);
+        occ[q] = e < n_e; kk[q] = 0u; cnt[q] = 0u; nvx[q] = 0u; gst[q] = 0u; hi[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (occ[q]) {
+            kk[q] = s_lk[e];
+            const uint32_t gs = s_lg[e];
+            const uint4 lo = tab[2 * (size_t)gs];
+            hi[q] = tab[2 * (size_t)gs + 1];
+            cnt[q] = lo.z; gst[q] = lo.y;
+            anybig = anybig || lo.w != 0u || cnt[q] > (uint32_t)M3D_TILE_PCAP;
             const unsigned long long cumA = ((unsigned long long)hi[q].y << 32) | hi[q].x, cumB = ((unsigned long long)hi[q].w << 32) | hi[q].z;
             uint32_t c0 = 0u;
             for (int sub = 0; sub < 8; sub++) {
@@ -599,24 +676,27 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     __syncthreads();
     if (anybig) s_over = 1u;
     __syncthreads();
-    over = over || s_over != 0u;
-    if (over) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
-    // which image every staged bucket goes to, and where: one image when everything fits (nearly always); else a greedy cut in slot
+    if (s_over != 0u) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
+    TB_STAMP(4);
+    // 5. which image every staged bucket goes to, and where: one image when everything fits (nearly always); else a greedy cut in list
     // order by one thread (a crowded stretch: a few tiles per cloud)
     uint32_t im[SPT], off[SPT];
-    { uint32_t l = l0; for (int q = 0; q < SPT; q++) { im[q] = 0u; off[q] = l; l += cnt[q]; } }
+    {
+        uint32_t l = l0;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) { im[q] = 0u; off[q] = l; l += cnt[q]; }
+    }
     uint32_t n_img = 1u;
     if (tot_p > (uint32_t)M3D_TILE_PCAP || tot_v > (uint32_t)M3D_TILE_VCAP) {
-        // (s_vk is free here: [slot] = points | voxels << 16 in, image | offset << 8 out)
-        for (int q = 0; q < SPT; q++) s_vk[SPT * tid + q] = cnt[q] | (nvx[q] << 16);
+#pragma unroll
+        for (int q = 0; q < SPT; q++) if (occ[q]) s_lp[tid + 256 * q] = cnt[q] | (nvx[q] << 16);
         __syncthreads();
         if (tid == 0) {
             uint32_t img_i = 0u, p = 0u, v = 0u;
-            for (int sl = 0; sl < M3D_TILE_HS; sl++) {
-                const uint32_t w = s_vk[sl], bp = w & 0xFFFFu, bv = w >> 16;
-                if (bp == 0u) continue;
+            for (uint32_t e = 0; e < n_e; e++) {
+                const uint32_t w = s_lp[e], bp = w & 0xFFFFu, bv = w >> 16;
                 if (p + bp > (uint32_t)M3D_TILE_PCAP || v + bv > (uint32_t)M3D_TILE_VCAP) { s_ip[img_i < M3D_TILE_MAXIMG ? img_i : 0] = p | (v << 16); img_i++; p = 0u; v = 0u; }
-                s_vk[sl] = (img_i & 0xFFu) | (p << 8);
+                s_lp[e] = (img_i & 0xFFu) | (p << 8);
                 p += bp; v += bv;
             }
             s_ip[img_i < M3D_TILE_MAXIMG ? img_i : 0] = p | (v << 16);
@@ -624,7 +704,8 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
         }
         __syncthreads();
         n_img = s_cnt;
-        for (int q = 0; q < SPT; q++) { const uint32_t w = s_vk[SPT * tid + q]; im[q] = w & 0xFFu; off[q] = w >> 8; }
+#pragma unroll
+        for (int q = 0; q < SPT; q++) if (occ[q]) { const uint32_t w = s_lp[tid + 256 * q]; im[q] = w & 0xFFu; off[q] = w >> 8; }
         __syncthreads();
         if (n_img > (uint32_t)M3D_TILE_MAXIMG) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
         if (tid == 0) {   // the extra images come from the level's pool
@@ -634,15 +715,18 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
         __syncthreads();
         if (s_cnt == 0xFFFFFFFFu) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
     } else if (tid == 0) { s_ip[0] = tot_p | (tot_v << 16); s_cnt = 0u; }
-    if (crowd) s_over = 1u;   // (re-used: some voxel of the tile is crowded — every image of the tile then gets chunk boxes)
+    if (crowd) s_over = 1u;   // (re-used: some voxel of the tile is crowded: every image of the tile then gets chunk boxes)
     __syncthreads();
     const bool crowded = s_over != 0u;
     const uint32_t extra = s_cnt;
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
+    // 6. the images
+    TB_STAMP(5);
     for (uint32_t j = 0; j < n_img; j++) {
         const uint32_t image = j == 0u ? (uint32_t)t : extra + j - 1u;
         uint8_t* img = B.timg + (size_t)image * M3D_TILE_IMG_BYTES;
-        uint32_t* gidx = reinterpret_cast<uint32_t*>(img + M3D_TILE_VS * 8);
+        uint32_t* gidx = reinterpret_cast<uint32_t*>(img + M3D_TILE_IMG_GIDX);
+        float4* ipts = reinterpret_cast<float4*>(img + M3D_TILE_IMG_PTS);
         for (int i = tid; i < M3D_TILE_VS; i += 256) s_vk[i] = M3D_INVALID_KEY;
         __syncthreads();
         // the occupied voxels of this image's buckets into its directory; the sorted position of every staged point
@@ -665,15 +749,33 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
                 }
                 c0 = c1;
             }
-            for (uint32_t k = 0; k < cnt[q]; k++) gidx[off[q] + k] = lo[q].y + k;
+            for (uint32_t k = 0; k < cnt[q]; k++) s_src[off[q] + k] = gst[q] + k;   // (LDS: the copy below is then one coalesced pass of the whole workgroup)
         }
         __syncthreads();
+        if (j == 0u) TB_STAMP(6);
+        {
+            const uint32_t np = s_ip[j] & 0xFFFFu;
+            for (uint32_t q0 = 0; q0 < np; q0 += 1024u) {   // four independent gathers in flight per thread
+                uint32_t gsrc[4]; float4 pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; gsrc[r] = pp < np ? s_src[pp] : 0u; }
+#pragma unroll
+                for (int r = 0; r < 4; r++) pv[r] = B.pts[gsrc[r]];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; if (pp < np) { gidx[pp] = gsrc[r]; ipts[pp] = pv[r]; } }
+            }
+        }
+        if (j == 0u) TB_STAMP(7);
         uint2* vslots = reinterpret_cast<uint2*>(img);
         for (int i = tid; i < M3D_TILE_VS; i += 256) vslots[i] = make_uint2(s_vk[i], s_vv[i]);
         if (tid == 0) B.timeta[image] = M3dTileImgMeta{ s_ip[j] & 0xFFFFu, (s_ip[j] >> 16) | (crowded ? 0x80000000u : 0u) };
         __syncthreads();
     }
-    if (tid == 0) *H = M3dTileHdr{ extra, n_img, 0u, 0u };
+    TB_STAMP(8);
+    if (tid == 0) *H = M3dTileHdr{ extra, n_img, 0u, (s_ip[0] & 0xFFFFu) | (crowded ? 0x80000000u : 0u) };
+#ifdef M3D_TB_STAMPS
+    if (tid == 0 && tb_slot < 4096u) g_tb_stamp[tb_slot][9] = ((unsigned long long)n_img << 32) | n_e;
+#endif
 }
 
 // ---- a9: normals from the 27-voxel neighbourhood of the normal grid --------------------------------

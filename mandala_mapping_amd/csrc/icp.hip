@@ -64,9 +64,10 @@ extern "C" hipError_t m3d_debug_read_tile_blocks(unsigned long long* out) {
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_tblk), z, sizeof(z));
     return e;
 }
-#define M3D_TBT_BEGIN() const unsigned long long tb0 = wall_clock64(); unsigned long long tb_st = 0; const bool tb_on = st->iters == g_m3d_blk_iter && blockIdx.x < 16384
-#define M3D_TBT_STAGED() do { if (tb_on) tb_st = wall_clock64(); } while (0)
-#define M3D_TBT_END(kind, nrec, npts) do { if (tb_on) { __syncthreads(); if (threadIdx.x == 0) { unsigned long long* b = g_m3d_tblk[blockIdx.x]; b[0] = tb0; b[1] = wall_clock64(); \
+#define M3D_TBT_BEGIN() const unsigned long long tb0 = wall_clock64(); unsigned long long tb_st = 0, tb_t0 = 0; const unsigned int tb_i = blockIdx.x + gridDim.x * blockIdx.y; const bool tb_on = st->iters == g_m3d_blk_iter && tb_i < 16384
+#define M3D_TBT_STAGED() do { if (tb_on) tb_t0 = wall_clock64(); } while (0)
+#define M3D_TBT_SEARCHED() do { if (tb_on) { __syncthreads(); tb_st += wall_clock64() - tb_t0; } } while (0)
+#define M3D_TBT_END(kind, nrec, npts) do { if (tb_on) { __syncthreads(); if (threadIdx.x == 0) { unsigned long long* b = g_m3d_tblk[tb_i]; b[0] = tb0; b[1] = wall_clock64(); \
     b[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
     b[3] = (kind); b[4] = (nrec); b[5] = (npts); b[6] = tb_st; b[7] = (unsigned long long)pair; } } } while (0)
 #define M3D_BT_COUNT(W, f) ((W).f++)
@@ -85,6 +86,7 @@ extern "C" hipError_t m3d_debug_read_tile_blocks(unsigned long long* out) {
 #define M3D_BT_FLUSH(W) ((void)0)
 #define M3D_TBT_BEGIN() ((void)0)
 #define M3D_TBT_STAGED() ((void)0)
+#define M3D_TBT_SEARCHED() ((void)0)
 #define M3D_TBT_END(kind, nrec, npts) ((void)0)
 #endif
 
@@ -581,17 +583,44 @@ __device__ __forceinline__ m3d_u32x2 m3d_tile_find(m3d_lu2 vs, uint32_t key) {
 // (computed when the image was staged) first: the points of a voxel keep their firing order, which sweeps the surface strip by
 // strip, so once a good candidate is known all but the chunks around the query are provably farther and never read. A skipped
 // chunk's box distance bounds its points in `sec`, like a pruned voxel's.
+__device__ __forceinline__ float m3d_box_d2(m3d_lf4 boxes, uint32_t c, float ux, float uy, float uz) {
+    const float4 mn = m3d_ld(boxes, 2 * c), mx = m3d_ld(boxes, 2 * c + 1);
+    const float dx = fmaxf(fmaxf(mn.x - ux, ux - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - uy, uy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - uz, uz - mx.z), 0.f);
+    return dx * dx + dy * dy + dz * dz;
+}
 __device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, m3d_lf4 boxes, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, float& bound) {
     const uint32_t t = sv & 0xFFFFu, n = sv >> 16;
     if (boxes == nullptr || n <= (uint32_t)M3D_LONG_ROW) { m3d_tile_scan(sp, t, t + n, ux, uy, uz, bkey, best, sec); return; }
-    const uint32_t te = t + n, cl = (te - 1u) / M3D_CHUNK;
-    for (uint32_t c = t / M3D_CHUNK; c <= cl; c++) {
-        const float4 mn = m3d_ld(boxes, 2 * c), mx = m3d_ld(boxes, 2 * c + 1);
-        const float dx = fmaxf(fmaxf(mn.x - ux, ux - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - uy, uy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - uz, uz - mx.z), 0.f);
-        const float bd = dx * dx + dy * dy + dz * dz;
-        if (bd > bound) { sec = min(sec, __float_as_uint(bd)); continue; }
-        m3d_tile_scan(sp, max(t, c * M3D_CHUNK), min(te, (c + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
+    // A crowded voxel, walked so that the lanes of a wave stay together although every lane needs DIFFERENT chunks of a different
+    // voxel (a chunk-by-chunk loop with the scan inside ran the 16-candidate scan in nearly every trip — some lane always needed it:
+    // ~25 000 instructions per wave of 64 queries): (0) a query without a candidate yet finds its nearest chunk by the boxes alone and
+    // scans it: that leaves a bound of a centimetre or two; (1) box tests only, collecting the (few) chunks still within the bound,
+    // four at a time, in a register; (2) those are scanned, every lane its own k-th chunk in the same trip.
+    const uint32_t te = t + n, c0 = t / M3D_CHUNK, cl = (te - 1u) / M3D_CHUNK;
+    uint32_t cdone = 0xFFFFFFFFu;
+    if ((uint32_t)(bkey >> 32) == M3D_INF_BITS) {
+        float bmin = __uint_as_float(M3D_INF_BITS);
+        for (uint32_t c = c0; c <= cl; c++) { const float bd = m3d_box_d2(boxes, c, ux, uy, uz); if (bd < bmin) { bmin = bd; cdone = c; } }
+        if (bmin > bound) { sec = min(sec, __float_as_uint(bmin)); return; }   // every chunk is farther than the bound
+        m3d_tile_scan(sp, max(t, cdone * M3D_CHUNK), min(te, (cdone + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
         bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+    }
+    uint32_t c = c0;
+    while (c <= cl) {
+        uint32_t list = 0u; int nl = 0;
+        for (; c <= cl && nl < 4; c++) {
+            if (c == cdone) continue;
+            const float bd = m3d_box_d2(boxes, c, ux, uy, uz);
+            if (bd > bound) sec = min(sec, __float_as_uint(bd));
+            else { list |= (c - c0) << (8 * nl); nl++; }
+        }
+        for (int k = 0; k < nl; k++) {
+            const uint32_t cc = c0 + ((list >> (8 * k)) & 0xFFu);
+            const float bd = m3d_box_d2(boxes, cc, ux, uy, uz);   // (the bound may have shrunk since the chunk was listed)
+            if (bd > bound) { sec = min(sec, __float_as_uint(bd)); continue; }
+            m3d_tile_scan(sp, max(t, cc * M3D_CHUNK), min(te, (cc + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
+            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
+        }
     }
 }
 // phase 1 of the search, voxel B of the compile-time visiting order at offset (DX, DY, DZ): one unconditional directory probe (no
@@ -914,19 +943,28 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
                 const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;   // 0 or 1 each
                 const int hx = min(max((Q.ic[0] >> 1) - b0x, 0), nbx), hy = min(max((Q.ic[1] >> 1) - b0y, 0), nby), hz = min(max((Q.ic[2] >> 1) - b0z, 0), nbz);
-                {
-                    const uint32_t key = m3d_bucket_key(g, b0x + hx, b0y + hy, b0z + hz);
-                    uint32_t slot = m3d_hash_slot(key, g.hshift);
-                    uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
-                    while (lo.x != key && lo.x != M3D_INVALID_KEY) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }
-                    if (lo.x == key) tile = (int)(lo.y / (uint32_t)M3D_TILE_PTS);
-                }
-                if (tile < 0) {
+                const M3D_GLOBAL uint32_t* occ = (const M3D_GLOBAL uint32_t*)(const void M3D_GLOBAL*)J.tgt.occ;
+                uint32_t hkey = M3D_INVALID_KEY;   // an occupied bucket of the 2x2x2: the one whose table entry names the tile
+                bool none = false;
+                if (occ) {
+                    // occupancy bitmap: eight 4-byte loads from a table of a few hundred KB (the hash table's entries are 32 B in 1 MB)
+                    uint32_t key[8], wbit[8];
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
+                        key[b] = m3d_bucket_key(g, b0x + min(ox, nbx), b0y + min(oy, nby), b0z + min(oz, nbz));   // (an inactive offset repeats an active bucket)
+                        wbit[b] = occ[key[b] >> 5];
+                    }
+                    const uint32_t khome = m3d_bucket_key(g, b0x + hx, b0y + hy, b0z + hz);
+#pragma unroll
+                    for (int b = 7; b >= 0; b--) if ((wbit[b] >> (key[b] & 31u)) & 1u) hkey = (key[b] == khome || hkey != khome) ? key[b] : hkey;   // the home bucket when it is occupied
+                    none = hkey == M3D_INVALID_KEY;
+                } else {
                     uint32_t key[8], slot[8]; uint4 lo[8]; bool act[8];
 #pragma unroll
                     for (int b = 0; b < 8; b++) {
                         const int ox = b & 1, oy = (b >> 1) & 1, oz = b >> 2;
-                        act[b] = ox <= nbx && oy <= nby && oz <= nbz && !(ox == hx && oy == hy && oz == hz);
+                        act[b] = ox <= nbx && oy <= nby && oz <= nbz;
                         key[b] = m3d_bucket_key(g, b0x + ox, b0y + oy, b0z + oz);
                         slot[b] = m3d_hash_slot(key[b], g.hshift);
                         lo[b] = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
@@ -936,13 +974,18 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     for (int b = 0; b < 8; b++) {
                         if (!act[b]) continue;
                         while (lo[b].x != key[b] && lo[b].x != M3D_INVALID_KEY) { slot[b] = (slot[b] + 1) & g.hmask; lo[b] = m3d_ld(tab, 2 * (size_t)slot[b]); }
-                        if (lo[b].x == key[b] && tile < 0) tile = (int)(lo[b].y / (uint32_t)M3D_TILE_PTS);
+                        if (lo[b].x == key[b] && hkey == M3D_INVALID_KEY) hkey = key[b];
                     }
-                    if (tile < 0) {   // no occupied bucket around the query: answered here (what the walk would find: nothing, not even a point)
-                        tile = -2;
-                        if (cls == 1) out[i] = -1;   // (cannot happen: a seed lies in one of these buckets)
-                        else { out[i] = M3D_NN_NONE_CACHED; cache[i] = m3d_voxel_code(Q); }
-                    }
+                    none = hkey == M3D_INVALID_KEY;
+                }
+                if (none) {   // no occupied bucket around the query: answered here (what the walk would find: nothing, not even a point)
+                    if (cls == 1) out[i] = -1;   // (cannot happen: a seed lies in one of these buckets)
+                    else { out[i] = M3D_NN_NONE_CACHED; cache[i] = m3d_voxel_code(Q); }
+                } else {
+                    uint32_t slot = m3d_hash_slot(hkey, g.hshift);
+                    uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
+                    while (lo.x != hkey) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }   // (the bucket exists)
+                    tile = (int)(lo.y / (uint32_t)M3D_TILE_PTS);
                 }
             }
         }
@@ -1031,6 +1074,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 // Workgroups are dealt over the XCDs tile by tile, NOT pair by pair like the other kernels of the iteration: nothing here is read
 // twice (records, images and points stream through once), and a pair with crowded tiles then loads all XCDs instead of one.
 #define M3D_TILE_THREADS 512
+#define M3D_TILE_RSPLIT 3      // workgroups per tile (gridDim.y): workgroup r answers the records r, r + RSPLIT, ... x 512 (a crowded tile has a thousand and more)
 __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int n_pairs, int ntile, int first_of_level, M3dNnArgs A) {
     __shared__ m3d_f32x4 s_pts[M3D_TILE_PCAP];
     __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
@@ -1038,15 +1082,13 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
     __shared__ int s_kd[32];
     const int blk = (int)(blockIdx.x / (unsigned)n_pairs), pair = (int)((blockIdx.x + (unsigned)blk) % (unsigned)n_pairs);   // tile t of pair p: XCD (p - t) mod 8
     const int tid = (int)threadIdx.x;
-    unsigned int* tcnt = A.tcnt + (size_t)pair * A.cnt_stride;
-    const unsigned int qn_all = tcnt[blk];          // (uniform: every thread reads the same word)
-    if (qn_all == 0u) return;
+    const unsigned int qn_all = (A.tcnt + (size_t)pair * A.cnt_stride)[blk];          // (uniform: every thread reads the same word; the reduction pass zeroes it)
+    const unsigned int qn = min(qn_all, (unsigned int)M3D_TILE_QCAP);
+    if (blockIdx.y * M3D_TILE_THREADS >= qn) return;
     const M3dJob& J = jobs[pair];
     const M3dPairState* st = A.states + pair;
-    if (st->done || (!first_of_level && st->level_done)) return;   // (k_nn_iter then filed nothing: unreachable)
     M3D_TBT_BEGIN();
     const M3dGrid g = J.tgt.g;
-    const m3d_gf4 pts = m3d_as_global(J.tgt.pts);
     const float dmax2 = J.dmax2;
     const M3dTileHdr H = J.tgt.thdr[blk];
     M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
@@ -1057,14 +1099,14 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const int v = ord[tid], dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
         s_kd[tid] = dx + dy * (1 << (g.cb[0] + 1)) + dz * (1 << (g.cb[0] + g.cb[1] + 2));
     }
-    const unsigned int qn = min(qn_all, (unsigned int)M3D_TILE_QCAP);
     const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP);
     const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP;
     const m3d_lu2 vs = (m3d_lu2)s_vs;
     const m3d_lf4 sp = (m3d_lf4)s_pts;
-    unsigned int n_staged = 0;
+    unsigned int n_staged = 0, n_done = 0;
     bool crowded = false;
-    for (unsigned int q0 = 0; q0 < qn; q0 += M3D_TILE_THREADS) {
+    const unsigned int qstep = M3D_TILE_THREADS * M3D_TILE_RSPLIT;
+    for (unsigned int q0 = blockIdx.y * M3D_TILE_THREADS; q0 < qn; q0 += qstep) {
         const unsigned int q = q0 + (unsigned int)tid;
         const bool have = q < qn;
         // the record first: its loads are in flight while the image is staged
@@ -1077,24 +1119,20 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         for (unsigned int j = 0; j < H.n_img; j++) {
             const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
             const uint8_t* img = J.tgt.timg + (size_t)image * M3D_TILE_IMG_BYTES;
-            const m3d_gu32 gi = m3d_as_global(reinterpret_cast<const uint32_t*>(img + M3D_TILE_VS * 8));
-            if (j != 0u || q0 == 0u || H.n_img > 1u) {   // stage (a single-image tile with more than one round of records is staged once)
-                if (j != 0u || q0 != 0u) __syncthreads();   // everybody is done with the previous image
-                const M3dTileImgMeta IM = J.tgt.timeta[image];
-                const unsigned int n_points = IM.n_points;
-                crowded = (IM.n_voxels >> 31) != 0u;
+            if (j != 0u || q0 == blockIdx.y * M3D_TILE_THREADS || H.n_img > 1u) {   // stage (a single-image tile with several rounds of records is staged once)
+                if (n_staged != 0u) __syncthreads();   // everybody is done with the previous image
+                const uint32_t meta = j == 0u ? H.meta0 : (J.tgt.timeta[image].n_points | (J.tgt.timeta[image].n_voxels & 0x80000000u));
+                const unsigned int n_points = meta & 0x7FFFFFFFu;
+                crowded = (meta >> 31) != 0u;
                 const m3d_gu4 gs = m3d_as_global(reinterpret_cast<const uint4*>(img));
-                static_assert(M3D_TILE_VS * 8 == 2 * 16 * M3D_TILE_THREADS, "directory staging");
+                const m3d_gf4 gp = m3d_as_global(reinterpret_cast<const float4*>(img + M3D_TILE_IMG_PTS));
+                static_assert(M3D_TILE_VS * 8 == 2 * 16 * M3D_TILE_THREADS && M3D_TILE_PCAP == 4 * M3D_TILE_THREADS, "staging: two directory loads and four point loads per thread");
                 const uint4 v0 = m3d_ld(gs, (size_t)tid), v1 = m3d_ld(gs, (size_t)(tid + M3D_TILE_THREADS));
-                uint32_t gx[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); gx[r] = k < n_points ? gi[k] : 0u; }
-                static_assert(M3D_TILE_PCAP == 4 * M3D_TILE_THREADS, "point staging");
-                s_vs[2 * tid] = (m3d_u32x2){ v0.x, v0.y }; s_vs[2 * tid + 1] = (m3d_u32x2){ v0.z, v0.w };
-                s_vs[2 * (tid + M3D_TILE_THREADS)] = (m3d_u32x2){ v1.x, v1.y }; s_vs[2 * (tid + M3D_TILE_THREADS) + 1] = (m3d_u32x2){ v1.z, v1.w };
                 float4 pv[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) pv[r] = m3d_ld(pts, (size_t)gx[r]);
+                for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); pv[r] = k < n_points ? m3d_ld(gp, (size_t)k) : make_float4(0.f, 0.f, 0.f, 0.f); }
+                s_vs[2 * tid] = (m3d_u32x2){ v0.x, v0.y }; s_vs[2 * tid + 1] = (m3d_u32x2){ v0.z, v0.w };
+                s_vs[2 * (tid + M3D_TILE_THREADS)] = (m3d_u32x2){ v1.x, v1.y }; s_vs[2 * (tid + M3D_TILE_THREADS) + 1] = (m3d_u32x2){ v1.z, v1.w };
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); if (k < n_points) s_pts[k] = (m3d_f32x4){ pv[r].x, pv[r].y, pv[r].z, pv[r].w }; }
                 __syncthreads();
@@ -1125,8 +1163,9 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             if (have) {
                 if (j == 0u) m3d_tile_query(g, r4.x, r4.y, r4.z, dmax2, seeded, dseed, Q, code);
                 const int b = m3d_tile_search(g, vs, sp, crowded ? (m3d_lf4)s_box : (m3d_lf4)nullptr, s_kd, r4.x, r4.y, r4.z, Q);
-                if (b >= 0) m = (int)gi[b];   // LDS position -> sorted position
+                if (b >= 0) m = (int)reinterpret_cast<const uint32_t*>(img + M3D_TILE_IMG_GIDX)[b];   // LDS position -> sorted position
             }
+            M3D_TBT_SEARCHED();
         }
         if (have) {
             const int qi = (int)(w & 0x7FFFFFFFu);
@@ -1137,9 +1176,10 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
             if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, __uint_as_float(Q.sec) };
         }
+        n_done += min((unsigned int)M3D_TILE_THREADS, qn - q0);
     }
-    if (tid == 0) { tcnt[blk] = 0u; atomicAdd(&A.states[pair].ctr[0], qn); }   // the counter is zero again for the next iteration
-    M3D_TBT_END(0, qn, n_staged);
+    if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
+    M3D_TBT_END(0, n_done, n_staged);
 }
 
 // k_nn_gwalk: the pair's global-walk list (queries of flagged tiles and of full slabs: normally empty), the per-lane walk of k_nn_iter
@@ -1384,10 +1424,11 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
-                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride) {
+                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk, rot);
-    if (gw_cnt && blk == 0 && threadIdx.x == 0) gw_cnt[(size_t)pair * gw_stride] = 0u;   // k_nn_tiles' global-walk list: read by several of its workgroups, so zeroed one launch later
+    if (gw_cnt && blk == 0)   // the record counters of k_nn_tiles / k_nn_gwalk: each is read by several of their workgroups, so they are zeroed one launch later
+        for (int i = (int)threadIdx.x; i < gw_n; i += ICP_THREADS) gw_cnt[(size_t)pair * gw_stride + i] = 0u;
     const M3dJob& J = jobs[pair];
     M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
 
@@ -1483,16 +1524,16 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
     M3D_DBG(s, "k_nn_iter");
     if (w.tiles) {
-        hipLaunchKernelGGL(k_nn_tiles, dim3(w.ntile_max * n_pairs), dim3(M3D_TILE_THREADS), 0, s, d_jobs, n_pairs, w.ntile_max, first_of_level, A);   // block -> (pair, tile): tile-major
+        hipLaunchKernelGGL(k_nn_tiles, dim3(w.ntile_max * n_pairs, M3D_TILE_RSPLIT), dim3(M3D_TILE_THREADS), 0, s, d_jobs, n_pairs, w.ntile_max, first_of_level, A);   // block -> (pair, tile): tile-major
         M3D_DBG(s, "k_nn_tiles");
         hipLaunchKernelGGL(k_nn_gwalk, dim3(M3D_GWALK_BLOCKS * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, M3D_GWALK_BLOCKS, first_of_level, A);
         M3D_DBG(s, "k_nn_gwalk");
     }
     if (k1) (void)hipEventRecord(k1, s);
     const int bpp_a = m3d_acc_blocks(max_n_src);
-    unsigned int* gw = w.tiles ? w.tcnt + w.ntile_max : nullptr;   // the global-walk list's counter: zeroed here, behind its readers
-    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride);
-    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride);
+    unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' and the global-walk list's record counters: zeroed here, behind their readers
+    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1);
+    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1);
     M3D_DBG(s, "k_accumulate_matches");
 }
 
@@ -1510,6 +1551,7 @@ __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pai
     g.hmask = M->dyn[1];
     g.hshift = (int32_t)M->dyn[2];
     J.tgt.g = g;
+    if (M->dyn[7] == 0u) J.tgt.occ = nullptr;   // the grid has more bucket positions than the occupancy bitmap covers
     J.n_src = MS->g.n_valid;
     int32_t e[6]; float S[6];
     m3d_fixed_exps(M->lbound, J.dmax, e, S);

@@ -69,25 +69,29 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 //   vslots[M3D_TILE_VS]    open-addressing directory of the staged VOXELS: {voxel key, first LDS position | population << 16}
 //                          (all-ones key = empty); voxel key = ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2): a neighbour's key is
 //                          the query voxel's key plus a constant
-//   gidx[n_points]         sorted position (in the level's pts array) of every staged point, in LDS order
+//   pts[n_points]          the staged points themselves {x, y, z, bits(input index)}, in LDS order: staging an image is two coalesced
+//                          streams (directory, points) — no gather, no index indirection on the critical path
+//   gidx[n_points]         sorted position (in the level's pts array) of every staged point: read once per answered query
 // A staged set that exceeds one image's capacities (a crowded stretch: a surface a metre from the sensor) is cut, bucket by bucket,
 // into several images (the first is image t, the others come from a pool behind the tiles' own images); the workgroup then stages
 // them one after the other and carries every query's best-so-far across them. Only a single bucket beyond an image's capacity (or an
 // exhausted pool) flags the tile; its queries take the global walk instead.
 #define M3D_TILE_PTS 512
-#define M3D_TILE_HS 1024        // k_tile_build: slots of the staged-bucket set
 #define M3D_TILE_ECAP 512       // staged buckets per tile at most
 #define M3D_TILE_VS 2048        // slots of the voxel directory
 #define M3D_TILE_VCAP 1280      // staged voxels per tile at most
 #define M3D_TILE_PCAP 2048      // staged points per tile at most
 #define M3D_TILE_QCAP 2048      // query records a tile accepts per iteration (the rest takes the global walk)
 #define M3D_TILE_OVERSIZE 1u
+#define M3D_OCC_BITS 23         // the occupancy bitmap covers grids of up to 2^23 bucket positions (1 MiB per level)
 #define M3D_TILE_MAXIMG 32
-struct M3dTileHdr { uint32_t extra, n_img, flags, pad; };   // images of the tile: image t, then images extra .. extra + n_img - 2
+struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; meta0 = staged points of image t | crowded << 31
 struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points (k_nn_tiles then builds chunk boxes)
 static_assert(sizeof(M3dTileHdr) == 16 && sizeof(M3dTileImgMeta) == 8, "tile image layout");
 __host__ __device__ inline int m3d_tile_pool(int n_tiles) { return n_tiles / 2 + 8; }   // extra images per level
-#define M3D_TILE_IMG_BYTES (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 4)
+#define M3D_TILE_IMG_PTS (M3D_TILE_VS * 8)                               // byte offsets inside an image
+#define M3D_TILE_IMG_GIDX (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 16)
+#define M3D_TILE_IMG_BYTES (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 16 + M3D_TILE_PCAP * 4)
 __host__ __device__ inline int m3d_tiles_of(int n) { return (n + M3D_TILE_PTS - 1) / M3D_TILE_PTS; }
 
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
@@ -97,6 +101,9 @@ struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const M3dTileHdr* thdr;    // [m3d_tiles_of(n)] tile headers, or null (the level then has no tiles: every search walks global memory)
     const uint8_t* timg;       // [tiles + pool][M3D_TILE_IMG_BYTES] tile images
     const M3dTileImgMeta* timeta;   // [tiles + pool] staged points / voxels of every image
+    const uint32_t* occ;       // one bit per bucket POSITION (bit index = bucket key): set = occupied. k_nn_iter tests the 2x2x2 buckets around a
+                               // query with eight 4-byte loads from this small table instead of eight 16-byte hash probes; null when the grid
+                               // has more positions than M3D_OCC_BITS (k_patch_jobs clears the pointer; the search then probes the hash table)
     const M3dBucket* htab;
     const uint32_t* bigcum;   // [n_big][8] 32-bit cumulative populations of buckets with more than 65535 points
     const float4* cbox;       // [2 * ceil(n / 16)] exact AABB {min, max} of every 16 consecutive sorted points: lets the search skip most of a

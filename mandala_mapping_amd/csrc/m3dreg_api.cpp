@@ -34,6 +34,7 @@ struct DevLevel {
     M3dTileHdr* thdr = nullptr;    // tile headers / images of the LDS-staged search (null for a source-only cloud)
     uint8_t* timg = nullptr;
     M3dTileImgMeta* timeta = nullptr;
+    uint32_t* occ = nullptr;       // occupancy bitmap of the bucket positions
     uint32_t bigcap = 0;
     uint32_t* keys = nullptr;
     uint32_t* skey = nullptr;
@@ -245,7 +246,8 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
             L.thdr = k.take<M3dTileHdr>(nt);
             L.timg = k.take<uint8_t>(ni * M3D_TILE_IMG_BYTES);
             L.timeta = k.take<M3dTileImgMeta>(ni);
-        } else { L.thdr = nullptr; L.timg = nullptr; L.timeta = nullptr; }
+            L.occ = k.take<uint32_t>(size_t(1) << (M3D_OCC_BITS - 5));
+        } else { L.thdr = nullptr; L.timg = nullptr; L.timeta = nullptr; L.occ = nullptr; }
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
         L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
         L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
@@ -391,7 +393,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
             if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
-            if (!is_ng && !no_normals && h->tiles) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; any_tiles = true; c->has_tiles = true; }
+            if (!is_ng && !no_normals && h->tiles) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = true; c->has_tiles = true; }
         }
     }
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
@@ -461,7 +463,7 @@ int finish_sync(m3dreg_handle* h, m3dreg_cloud** cl, size_t k) {
 M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in, bool tiles = false) {
     M3dLevelDev d{};
     d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.cbox = L.cbox; d.dyn = L.dyn; d.g = L.grid;
-    d.thdr = tiles ? L.thdr : nullptr; d.timg = tiles ? L.timg : nullptr; d.timeta = tiles ? L.timeta : nullptr;
+    d.thdr = tiles ? L.thdr : nullptr; d.timg = tiles ? L.timg : nullptr; d.timeta = tiles ? L.timeta : nullptr; d.occ = tiles ? L.occ : nullptr;
     return d;
 }
 

@@ -9,7 +9,7 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pk_$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pk_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 --queue-depth 1 --no-events > $R/gpurun_out/pk_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pk_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 --queue-depth 1 --no-events $BENCH_ARGS > $R/gpurun_out/pk_$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections

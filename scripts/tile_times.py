@@ -37,7 +37,7 @@ for it in iters:
     s, e = (t0 - base) / 100.0, (t1 - base) / 100.0
     d = e - s
     kind, nrec, npts, pair = a[:, 3].astype(int), a[:, 4].astype(int), a[:, 5].astype(int), a[:, 7].astype(int)
-    stg = np.where(a[:, 6] > 0, (a[:, 6].astype(np.int64) - t0) / 100.0, 0.0)
+    stg = a[:, 6].astype(np.int64) / 100.0   # time between 'image staged' and 'every wave done searching it', summed over the passes
     xcc = (a[:, 2] >> np.uint64(32)).astype(np.int64) & 0xF
     print(f"--- iteration {it}: {len(a)} workgroups with work, span {e.max():.1f} us; sum of durations / span = {d.sum() / e.max():.0f} in flight on average")
     for k, name in ((0, 'tile'), (1, 'global walk')):
@@ -45,9 +45,9 @@ for it in iters:
         if not m.any():
             continue
         print(f"    {name:11s}: {m.sum():5d} workgroups, {nrec[m].sum():7d} records; duration mean {d[m].mean():.1f} p50 {np.median(d[m]):.1f} p90 {np.percentile(d[m], 90):.1f} max {d[m].max():.1f} us; start p50 {np.median(s[m]):.1f} max {s[m].max():.1f}; last end {e[m].max():.1f}"
-              + (f"; staging mean {stg[m].mean():.1f} max {stg[m].max():.1f} us, staged points mean {npts[m].mean():.0f} max {npts[m].max()}, records mean {nrec[m].mean():.0f} max {nrec[m].max()}" if k == 0 else ""))
+              + (f"; search (slowest wave, summed over passes) mean {stg[m].mean():.1f} max {stg[m].max():.1f} us, staged points mean {npts[m].mean():.0f} max {npts[m].max()}, records mean {nrec[m].mean():.0f} max {nrec[m].max()}" if k == 0 else ""))
     o = np.argsort(-e)[:6]
-    print("    last to end: " + ", ".join(f"{'T' if kind[j] == 0 else 'G'} pair {pair[j]} xcc {xcc[j]} {d[j]:.0f}us (start {s[j]:.0f}) rec {nrec[j]} pts {npts[j]}" for j in o))
+    print("    last to end: " + ", ".join(f"{'T' if kind[j] == 0 else 'G'} pair {pair[j]} xcc {xcc[j]} {d[j]:.0f}us (start {s[j]:.0f}) rec {nrec[j]} pts {npts[j]} search {stg[j]:.0f}us" for j in o))
     for p in sorted(set(pair)):
         m = pair == p
         print(f"    pair {p}: {m.sum():4d} wgs, records tile {nrec[m & (kind == 0)].sum():6d} gw {nrec[m & (kind == 1)].sum():6d}, xcc {sorted(set(xcc[m]))}, first start {s[m].min():6.1f} last end {e[m].max():6.1f}, busy sum {d[m].sum():7.0f} us")
