@@ -346,6 +346,8 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 // While a query stays in the same voxel its neighbourhood is the same set of (static) target voxels, so
 // "-2" is answered again without a single probe. Exact: a changed voxel simply re-runs the full search.
 #define M3D_NN_NONE_CACHED (-2)
+#define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread)
+#define M3D_TILE_CHUNK_CROWDED 64     // ... of a tile with crowded voxels (one per eighth lane)
 #define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
 __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
     return (long long)(Q.ic[0] + 1) | ((long long)(Q.ic[1] + 1) << 16) | ((long long)(Q.ic[2] + 1) << 32);
@@ -548,10 +550,11 @@ __device__ __forceinline__ int m3d_nn27_walk(const M3dGrid& g, m3d_gu4 tab, m3d_
 // Returns the LDS position of the match, -1, or M3D_NN_NONE_CACHED; sec = squared lower bound of every non-winning candidate.
 typedef uint32_t m3d_u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) m3d_u32x2* m3d_lu2;
-// candidates [t, t1) of the staged points, two per trip (a repeated last point counts as +inf)
-__device__ __forceinline__ void m3d_tile_scan(m3d_lf4 sp, uint32_t t, const uint32_t t1, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec) {
-    for (; t < t1; t += 2) {
-        const uint32_t tb = min(t + 1u, t1 - 1u);
+// candidates t, t + step, ... < t1 of the staged points, two per trip (a repeated last one counts as +inf)
+__device__ __forceinline__ void m3d_tile_scan(m3d_lf4 sp, uint32_t t, const uint32_t t1, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec,
+                                              const uint32_t step = 1u) {
+    for (; t < t1; t += 2u * step) {
+        const uint32_t tb = (t + step < t1) ? t + step : t;
         const float4 ca = m3d_ld(sp, t), cb = m3d_ld(sp, tb);
         {
             const float ex = ux - ca.x, ey = uy - ca.y, ez = uz - ca.z;
@@ -578,50 +581,11 @@ __device__ __forceinline__ m3d_u32x2 m3d_tile_find(m3d_lu2 vs, uint32_t key) {
     while (s.x != key && s.x != M3D_INVALID_KEY) { h = (h + 1u) & (M3D_TILE_VS - 1u); s = vs[h]; }
     return s;
 }
-// one staged voxel {first LDS position | population << 16} against the query. A crowded voxel (a surface close to the sensor puts a
-// hundred and more points into one 10 cm voxel) is walked chunk by chunk — M3D_CHUNK consecutive LDS positions, their exact box
-// (computed when the image was staged) first: the points of a voxel keep their firing order, which sweeps the surface strip by
-// strip, so once a good candidate is known all but the chunks around the query are provably farther and never read. A skipped
-// chunk's box distance bounds its points in `sec`, like a pruned voxel's.
-__device__ __forceinline__ float m3d_box_d2(m3d_lf4 boxes, uint32_t c, float ux, float uy, float uz) {
-    const float4 mn = m3d_ld(boxes, 2 * c), mx = m3d_ld(boxes, 2 * c + 1);
-    const float dx = fmaxf(fmaxf(mn.x - ux, ux - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - uy, uy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - uz, uz - mx.z), 0.f);
-    return dx * dx + dy * dy + dz * dz;
-}
-__device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, m3d_lf4 boxes, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, float& bound) {
+// one staged voxel {first LDS position | population << 16} against the query: lane `sub` of the `step` lanes that share the query
+// scans every step-th point of it
+__device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, const uint32_t sub, const uint32_t step) {
     const uint32_t t = sv & 0xFFFFu, n = sv >> 16;
-    if (boxes == nullptr || n <= (uint32_t)M3D_LONG_ROW) { m3d_tile_scan(sp, t, t + n, ux, uy, uz, bkey, best, sec); return; }
-    // A crowded voxel, walked so that the lanes of a wave stay together although every lane needs DIFFERENT chunks of a different
-    // voxel (a chunk-by-chunk loop with the scan inside ran the 16-candidate scan in nearly every trip — some lane always needed it:
-    // ~25 000 instructions per wave of 64 queries): (0) a query without a candidate yet finds its nearest chunk by the boxes alone and
-    // scans it: that leaves a bound of a centimetre or two; (1) box tests only, collecting the (few) chunks still within the bound,
-    // four at a time, in a register; (2) those are scanned, every lane its own k-th chunk in the same trip.
-    const uint32_t te = t + n, c0 = t / M3D_CHUNK, cl = (te - 1u) / M3D_CHUNK;
-    uint32_t cdone = 0xFFFFFFFFu;
-    if ((uint32_t)(bkey >> 32) == M3D_INF_BITS) {
-        float bmin = __uint_as_float(M3D_INF_BITS);
-        for (uint32_t c = c0; c <= cl; c++) { const float bd = m3d_box_d2(boxes, c, ux, uy, uz); if (bd < bmin) { bmin = bd; cdone = c; } }
-        if (bmin > bound) { sec = min(sec, __float_as_uint(bmin)); return; }   // every chunk is farther than the bound
-        m3d_tile_scan(sp, max(t, cdone * M3D_CHUNK), min(te, (cdone + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
-        bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
-    }
-    uint32_t c = c0;
-    while (c <= cl) {
-        uint32_t list = 0u; int nl = 0;
-        for (; c <= cl && nl < 4; c++) {
-            if (c == cdone) continue;
-            const float bd = m3d_box_d2(boxes, c, ux, uy, uz);
-            if (bd > bound) sec = min(sec, __float_as_uint(bd));
-            else { list |= (c - c0) << (8 * nl); nl++; }
-        }
-        for (int k = 0; k < nl; k++) {
-            const uint32_t cc = c0 + ((list >> (8 * k)) & 0xFFu);
-            const float bd = m3d_box_d2(boxes, cc, ux, uy, uz);   // (the bound may have shrunk since the chunk was listed)
-            if (bd > bound) { sec = min(sec, __float_as_uint(bd)); continue; }
-            m3d_tile_scan(sp, max(t, cc * M3D_CHUNK), min(te, (cc + 1u) * M3D_CHUNK), ux, uy, uz, bkey, best, sec);
-            bound = fminf(bound, m3d_key_d2(bkey) * 1.0001f);
-        }
-    }
+    m3d_tile_scan(sp, t + sub, t + n, ux, uy, uz, bkey, best, sec, step);
 }
 // phase 1 of the search, voxel B of the compile-time visiting order at offset (DX, DY, DZ): one unconditional directory probe (no
 // branch: 26 of them are in flight together); the voxel enters the lane's work mask when it exists, is not provably farther than
@@ -665,16 +629,23 @@ __device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float
     Q.bound = dmax2 * 1.0001f;
     if (seeded) Q.bound = fminf(Q.bound, dseed * 1.0001f);   // the previous match lies within these 27 voxels: it bounds the search before the first probe
 }
-// one staged image: returns the LDS position of a NEW best candidate, or -1 when the best so far stands
-__device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d_lf4 sp, m3d_lf4 boxes, const int* kdelta, float ux, float uy, float uz, M3dTileQ& Q) {
+// one staged image: returns the LDS position of a NEW best candidate, or -1 when the best so far stands.
+// step > 1: `step` consecutive lanes (a power of two, at most 8) answer ONE query together — a query in a crowded stretch compares
+// against a thousand and more candidates while the scans are still centimetres apart (no box is provably farther than a
+// neighbour that far away): every lane scans its share of each voxel, the group agrees on the bound after the home voxel and on
+// the result at the end (xor-shuffles). All lanes of a group enter with the same Q and leave with the same Q.
+__device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d_lf4 sp, const int* kdelta, float ux, float uy, float uz, M3dTileQ& Q,
+                                               const uint32_t sub = 0u, const uint32_t step = 1u) {
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     int best = -1;
+    const unsigned long long bkey0 = Q.bkey;
     // home voxel: every lane, no divergence; leaves the bound that prunes most of the other 26
     if (Q.G[0][1] + Q.G[1][1] + Q.G[2][1] == 0.f) {
         const m3d_u32x2 s = m3d_tile_find(vs, Q.key0);
-        if (s.x == Q.key0) m3d_tile_voxel(sp, boxes, s.y, ux, uy, uz, Q.bkey, best, Q.sec, Q.bound);
+        if (s.x == Q.key0) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
         Q.bound = fminf(Q.bound, m3d_key_d2(Q.bkey) * 1.0001f);
     }
+    if (step > 1u) for (uint32_t o = 1u; o < step; o <<= 1) Q.bound = fminf(Q.bound, __shfl_xor(Q.bound, (int)o));
     uint32_t mask = 0u;
 #define M3D_P(b, dx, dy, dz) m3d_tile_probe<b, dx, dy, dz>(vs, Q.G, Q.key0, sh1, sh2, Q.bound, Q.sec, mask)
     M3D_P(1, -1, 0, 0); M3D_P(2, 1, 0, 0); M3D_P(3, 0, -1, 0); M3D_P(4, 0, 1, 0); M3D_P(5, 0, 0, -1); M3D_P(6, 0, 0, 1);
@@ -690,7 +661,17 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
         mask &= mask - 1u;
         const uint32_t key = Q.key0 + (uint32_t)kdelta[b];
         const m3d_u32x2 s = m3d_tile_find(vs, key);
-        if (s.x == key) m3d_tile_voxel(sp, boxes, s.y, ux, uy, uz, Q.bkey, best, Q.sec, Q.bound);
+        if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
+    }
+    if (step > 1u) {
+        // the group's result: the smallest key; every other lane's NEW key lost to it (the old best, where a lane kept it, was
+        // already counted as a loser by the lane that beat it)
+        unsigned long long kmin = Q.bkey;
+        for (uint32_t o = 1u; o < step; o <<= 1) { const unsigned long long ok = __shfl_xor(kmin, (int)o); kmin = ok < kmin ? ok : kmin; }
+        uint32_t secg = (Q.bkey != kmin && Q.bkey != bkey0) ? min(Q.sec, (uint32_t)(Q.bkey >> 32)) : Q.sec;
+        int bestg = (Q.bkey == kmin && Q.bkey != bkey0) ? best : -1;
+        for (uint32_t o = 1u; o < step; o <<= 1) { secg = min(secg, (uint32_t)__shfl_xor((int)secg, (int)o)); bestg = max(bestg, __shfl_xor(bestg, (int)o)); }
+        Q.bkey = kmin; Q.sec = secg; best = bestg;
     }
     Q.bound = fminf(Q.bound, m3d_key_d2(Q.bkey) * 1.0001f);
     return best;
@@ -714,8 +695,11 @@ struct M3dNnArgs {
                                        //   tiles, then the records that take the global walk (home bucket empty, tile flagged, slab full)
     float* recd;                       // same layout: squared distance to the seed (the previous match)
     unsigned long long rec_stride;     // records per pair
-    unsigned int* tcnt;                // per pair [ntile_max + 1]: records per tile, then records of the global-walk list (zero between iterations)
+    unsigned int* tcnt;                // per pair [ntile_max]: records per tile (zero between iterations)
     int cnt_stride;
+    uint2* witems;                     // [wcap] work items of k_nn_tiles {pair, tile | record chunk << 20}, published by k_nn_iter
+    unsigned int* wcount;              // items published (zero between iterations)
+    int wcap;
 };
 
 #define NN_SETUP()                                                                                          \
@@ -997,7 +981,22 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             const int t0 = __shfl(tile, leader);
             const unsigned long long same = __ballot(tile == t0);
             uint32_t base = 0xFFFFFFFFu;
-            if (lane == leader && thdr[t0].flags == 0u) base = atomicAdd(&tcnt[t0], (unsigned int)__popcll(same));
+            if (lane == leader) {
+                const M3dTileHdr H = thdr[t0];
+                if (H.flags == 0u) {
+                    const uint32_t cnt = (uint32_t)__popcll(same);
+                    base = atomicAdd(&tcnt[t0], cnt);
+                    // work items of k_nn_tiles: one per chunk of the tile's records (512, or 64 for a tile with crowded voxels, whose
+                    // queries cost ten times as much: they are spread over more workgroups); the append that covers a chunk's first
+                    // record publishes it
+                    const uint32_t cs = (H.meta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
+                    const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
+                    for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
+                        const uint32_t w = atomicAdd(A.wcount, 1u);
+                        if (w < (uint32_t)A.wcap) A.witems[w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
+                    }
+                }
+            }
             base = (uint32_t)__shfl((int)base, leader);
             if (tile == t0) {
                 pos = base + (uint32_t)__popcll(same & lt);
@@ -1005,18 +1004,17 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             }
             todo &= ~same;
         }
-        const unsigned long long om = __ballot(tile == -1);
-        if (om) {
-            const int leader = (int)__ffsll((long long)om) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&tcnt[A.ntile_max], (unsigned int)__popcll(om));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (tile == -1) pos = base + (uint32_t)__popcll(om & lt);
-        }
-        if (tile >= -1) {
-            const size_t r = (size_t)pair * A.rec_stride + (size_t)(tile >= 0 ? tile : A.ntile_max) * M3D_TILE_QCAP + pos;
+        if (tile >= 0) {
+            const size_t r = (size_t)pair * A.rec_stride + (size_t)tile * M3D_TILE_QCAP + pos;
             A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
             A.recd[r] = dseed;
+        } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab: walked here, in global memory (rare)
+            long long code = 0; float sec = 0.f;
+            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
+            out[i] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+            if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+            atomicAdd(&A.states[pair].ctr[1], 1u);
         }
         M3D_BT_END(nW);
         return;
@@ -1074,41 +1072,46 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 // Workgroups are dealt over the XCDs tile by tile, NOT pair by pair like the other kernels of the iteration: nothing here is read
 // twice (records, images and points stream through once), and a pair with crowded tiles then loads all XCDs instead of one.
 #define M3D_TILE_THREADS 512
-#define M3D_TILE_RSPLIT 3      // workgroups per tile (gridDim.y): workgroup r answers the records r, r + RSPLIT, ... x 512 (a crowded tile has a thousand and more)
-__global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int n_pairs, int ntile, int first_of_level, M3dNnArgs A) {
+#define M3D_TILE_GRID 2048     // workgroups of k_nn_tiles: they stride over the work items k_nn_iter published (an empty list costs one word read each)
+__global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int first_of_level, M3dNnArgs A) {
     __shared__ m3d_f32x4 s_pts[M3D_TILE_PCAP];
     __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
-    __shared__ m3d_f32x4 s_box[2 * (M3D_TILE_PCAP / M3D_CHUNK)];   // exact {min, max} of every M3D_CHUNK staged points (images with crowded voxels only)
     __shared__ int s_kd[32];
-    const int blk = (int)(blockIdx.x / (unsigned)n_pairs), pair = (int)((blockIdx.x + (unsigned)blk) % (unsigned)n_pairs);   // tile t of pair p: XCD (p - t) mod 8
+    const unsigned int n_items = min(*A.wcount, (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counter)
     const int tid = (int)threadIdx.x;
-    const unsigned int qn_all = (A.tcnt + (size_t)pair * A.cnt_stride)[blk];          // (uniform: every thread reads the same word; the reduction pass zeroes it)
-    const unsigned int qn = min(qn_all, (unsigned int)M3D_TILE_QCAP);
-    if (blockIdx.y * M3D_TILE_THREADS >= qn) return;
-    const M3dJob& J = jobs[pair];
-    const M3dPairState* st = A.states + pair;
-    M3D_TBT_BEGIN();
-    const M3dGrid g = J.tgt.g;
-    const float dmax2 = J.dmax2;
-    const M3dTileHdr H = J.tgt.thdr[blk];
-    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
-    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
-    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
-    if (tid < 27) {   // key offset of voxel b of the visiting order (m3d_tile_search): dx + dy * 2^sh1 + dz * 2^sh2
-        const int ord[27] = { 13, 12, 14, 10, 16, 4, 22, 9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26 };   // index = (dx+1) + 3 (dy+1) + 9 (dz+1)
-        const int v = ord[tid], dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
-        s_kd[tid] = dx + dy * (1 << (g.cb[0] + 1)) + dz * (1 << (g.cb[0] + g.cb[1] + 2));
-    }
-    const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP);
-    const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP;
     const m3d_lu2 vs = (m3d_lu2)s_vs;
     const m3d_lf4 sp = (m3d_lf4)s_pts;
-    unsigned int n_staged = 0, n_done = 0;
-    bool crowded = false;
-    const unsigned int qstep = M3D_TILE_THREADS * M3D_TILE_RSPLIT;
-    for (unsigned int q0 = blockIdx.y * M3D_TILE_THREADS; q0 < qn; q0 += qstep) {
-        const unsigned int q = q0 + (unsigned int)tid;
+    bool first_item = true;
+    for (unsigned int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint2 item = A.witems[it];
+        const int pair = (int)item.x, blk = (int)(item.y & 0xFFFFFu);
+        const unsigned int chunk = item.y >> 20;
+        const M3dJob& J = jobs[pair];
+        const M3dPairState* st = A.states + pair;
+        (void)st;
+        M3D_TBT_BEGIN();
+        const M3dGrid g = J.tgt.g;
+        const float dmax2 = J.dmax2;
+        const M3dTileHdr H = J.tgt.thdr[blk];
+        const unsigned int qn = min((A.tcnt + (size_t)pair * A.cnt_stride)[blk], (unsigned int)M3D_TILE_QCAP);
+        const bool sparse = (H.meta0 >> 31) != 0u;   // a tile with crowded voxels: 64 records per item, eight lanes per record (m3d_tile_search)
+        const unsigned int cs = sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)M3D_TILE_CHUNK;
+        const unsigned int lstride = M3D_TILE_THREADS / cs;
+        M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+        M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+        M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+        if (!first_item) __syncthreads();   // everybody is done with the previous item's LDS
+        if (tid < 27) {   // key offset of voxel b of the visiting order (m3d_tile_search): dx + dy * 2^sh1 + dz * 2^sh2
+            const int ord[27] = { 13, 12, 14, 10, 16, 4, 22, 9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26 };   // index = (dx+1) + 3 (dy+1) + 9 (dz+1)
+            const int v = ord[tid], dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
+            s_kd[tid] = dx + dy * (1 << (g.cb[0] + 1)) + dz * (1 << (g.cb[0] + g.cb[1] + 2));
+        }
+        const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP);
+        const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP;
+        unsigned int n_staged = 0;
+        const unsigned int q = chunk * cs + (unsigned int)tid / lstride;
         const bool have = q < qn;
+        const uint32_t sub = (uint32_t)tid % lstride;   // (lstride lanes share a record: a whole number of groups per wave, idle groups only at the end of the item)
         // the record first: its loads are in flight while the image is staged
         const float4 r4 = have ? m3d_ld(rec, (size_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float dseed = have ? recd[q] : 0.f;
@@ -1119,11 +1122,10 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         for (unsigned int j = 0; j < H.n_img; j++) {
             const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
             const uint8_t* img = J.tgt.timg + (size_t)image * M3D_TILE_IMG_BYTES;
-            if (j != 0u || q0 == blockIdx.y * M3D_TILE_THREADS || H.n_img > 1u) {   // stage (a single-image tile with several rounds of records is staged once)
-                if (n_staged != 0u) __syncthreads();   // everybody is done with the previous image
+            {   // stage
+                if (j != 0u) __syncthreads();   // everybody is done with the previous image
                 const uint32_t meta = j == 0u ? H.meta0 : (J.tgt.timeta[image].n_points | (J.tgt.timeta[image].n_voxels & 0x80000000u));
                 const unsigned int n_points = meta & 0x7FFFFFFFu;
-                crowded = (meta >> 31) != 0u;
                 const m3d_gu4 gs = m3d_as_global(reinterpret_cast<const uint4*>(img));
                 const m3d_gf4 gp = m3d_as_global(reinterpret_cast<const float4*>(img + M3D_TILE_IMG_PTS));
                 static_assert(M3D_TILE_VS * 8 == 2 * 16 * M3D_TILE_THREADS && M3D_TILE_PCAP == 4 * M3D_TILE_THREADS, "staging: two directory loads and four point loads per thread");
@@ -1136,38 +1138,17 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); if (k < n_points) s_pts[k] = (m3d_f32x4){ pv[r].x, pv[r].y, pv[r].z, pv[r].w }; }
                 __syncthreads();
-                if (crowded) {   // chunk boxes: four lanes per chunk, four points each, xor-shuffle merge (every lane of a wave takes part)
-                    static_assert(M3D_TILE_THREADS * 4 == M3D_TILE_PCAP && M3D_CHUNK == 16, "one box lane per four staged points");
-                    const float inf = __uint_as_float(M3D_INF_BITS);
-                    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const unsigned int pi = (unsigned int)(tid >> 2) * M3D_CHUNK + 4u * k + (unsigned int)(tid & 3);
-                        if (pi < n_points) {
-                            const m3d_f32x4 pq = s_pts[pi];
-                            mnx = fminf(mnx, pq.x); mny = fminf(mny, pq.y); mnz = fminf(mnz, pq.z);
-                            mxx = fmaxf(mxx, pq.x); mxy = fmaxf(mxy, pq.y); mxz = fmaxf(mxz, pq.z);
-                        }
-                    }
-#pragma unroll
-                    for (int o = 1; o < 4; o <<= 1) {
-                        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
-                        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
-                    }
-                    if ((tid & 3) == 0) { s_box[2 * (tid >> 2)] = (m3d_f32x4){ mnx, mny, mnz, 0.f }; s_box[2 * (tid >> 2) + 1] = (m3d_f32x4){ mxx, mxy, mxz, 0.f }; }
-                    __syncthreads();
-                }
                 n_staged += n_points;
                 M3D_TBT_STAGED();
             }
             if (have) {
                 if (j == 0u) m3d_tile_query(g, r4.x, r4.y, r4.z, dmax2, seeded, dseed, Q, code);
-                const int b = m3d_tile_search(g, vs, sp, crowded ? (m3d_lf4)s_box : (m3d_lf4)nullptr, s_kd, r4.x, r4.y, r4.z, Q);
+                const int b = m3d_tile_search(g, vs, sp, s_kd, r4.x, r4.y, r4.z, Q, sub, lstride);
                 if (b >= 0) m = (int)reinterpret_cast<const uint32_t*>(img + M3D_TILE_IMG_GIDX)[b];   // LDS position -> sorted position
             }
             M3D_TBT_SEARCHED();
         }
-        if (have) {
+        if (have && sub == 0u) {
             const int qi = (int)(w & 0x7FFFFFFFu);
             const float d2 = m3d_key_d2(Q.bkey);
             // "nothing at all in the 27 voxels" may be cached only when every existing voxel was looked up and found empty
@@ -1176,39 +1157,11 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
             if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, __uint_as_float(Q.sec) };
         }
-        n_done += min((unsigned int)M3D_TILE_THREADS, qn - q0);
+        const unsigned int n_done = min(cs, qn - min(qn, chunk * cs));
+        if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
+        M3D_TBT_END(0, n_done, n_staged);
+        first_item = false;
     }
-    if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
-    M3D_TBT_END(0, n_done, n_staged);
-}
-
-// k_nn_gwalk: the pair's global-walk list (queries of flagged tiles and of full slabs: normally empty), the per-lane walk of k_nn_iter
-// over records. A few workgroups per pair stride over the list; the reduction pass zeroes its counter.
-#define M3D_GWALK_BLOCKS 32
-__global__ __launch_bounds__(256) void k_nn_gwalk(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
-    NN_SETUP();
-    (void)src; (void)R; (void)tt; (void)n;
-    const unsigned int on = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
-    if ((unsigned int)blk * 256u >= on) return;
-    const size_t rbase = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
-    const float4* rec = A.rec + rbase;
-    const float* recd = A.recd + rbase;
-    unsigned int done = 0;
-    for (unsigned int q0 = (unsigned int)blk * 256u; q0 < on; q0 += (unsigned int)bpp * 256u) {
-        const unsigned int q = q0 + threadIdx.x;
-        if (q < on) {
-            const float4 r4 = rec[q];
-            const uint32_t w = __float_as_uint(r4.w);
-            const int qi = (int)(w & 0x7FFFFFFFu);
-            long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, r4.x, r4.y, r4.z, dmax2, (w >> 31) != 0u, recd[q], code, sec, 0);
-            out[qi] = m;
-            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
-            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
-        }
-        done += min(256u, on - q0);
-    }
-    if (threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], done);
 }
 
 // point-to-point: expand the 17 transported sums into the spec's 29 slots (exact integer identities:
@@ -1424,11 +1377,13 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
-                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n) {
+                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n, unsigned int* __restrict__ wcount) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk, rot);
-    if (gw_cnt && blk == 0)   // the record counters of k_nn_tiles / k_nn_gwalk: each is read by several of their workgroups, so they are zeroed one launch later
+    if (gw_cnt && blk == 0) {   // the record counters of k_nn_tiles: each is read by several of its workgroups, so they are zeroed one launch later
         for (int i = (int)threadIdx.x; i < gw_n; i += ICP_THREADS) gw_cnt[(size_t)pair * gw_stride + i] = 0u;
+        if (pair == 0 && threadIdx.x == 0) *wcount = 0u;
+    }
     const M3dJob& J = jobs[pair];
     M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it
 
@@ -1520,20 +1475,19 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
     M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
+    A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
     hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
     M3D_DBG(s, "k_nn_iter");
     if (w.tiles) {
-        hipLaunchKernelGGL(k_nn_tiles, dim3(w.ntile_max * n_pairs, M3D_TILE_RSPLIT), dim3(M3D_TILE_THREADS), 0, s, d_jobs, n_pairs, w.ntile_max, first_of_level, A);   // block -> (pair, tile): tile-major
+        hipLaunchKernelGGL(k_nn_tiles, dim3(M3D_TILE_GRID), dim3(M3D_TILE_THREADS), 0, s, d_jobs, first_of_level, A);
         M3D_DBG(s, "k_nn_tiles");
-        hipLaunchKernelGGL(k_nn_gwalk, dim3(M3D_GWALK_BLOCKS * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, M3D_GWALK_BLOCKS, first_of_level, A);
-        M3D_DBG(s, "k_nn_gwalk");
     }
     if (k1) (void)hipEventRecord(k1, s);
     const int bpp_a = m3d_acc_blocks(max_n_src);
-    unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' and the global-walk list's record counters: zeroed here, behind their readers
-    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1);
-    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1);
+    unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' record counters and the work-item counter: zeroed here, behind their readers
+    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);
+    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);
     M3D_DBG(s, "k_accumulate_matches");
 }
 

@@ -135,8 +135,11 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP + stride] query records
     float* recd;                 // same layout: squared distance to the seed
     unsigned long long rec_stride;
-    unsigned int* tcnt;          // [n_pairs][cnt_stride] records per tile, then (at ntile_max) records of the global-walk list; zero between iterations
+    unsigned int* tcnt;          // [n_pairs][cnt_stride] records per tile; zero between iterations
     int cnt_stride;
+    uint2* witems;               // [wcap] work items of k_nn_tiles
+    unsigned int* wcount;        // items published this iteration; zero between iterations
+    int wcap;
 };
 // k0/k1 (optional): events recorded immediately before / after the dominant kernel of the iteration (k_nn_iter)
 // seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of

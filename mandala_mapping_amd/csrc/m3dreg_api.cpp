@@ -129,8 +129,10 @@ struct m3dreg_handle {
     size_t match_pairs = 0;
     float4* d_rec = nullptr;           // query records of the LDS-staged search: float4[rec_cap] then float[rec_cap] (seed distances)
     size_t rec_cap = 0, rec_stride = 0;
-    unsigned int* d_tcnt = nullptr;    // records per tile / of the global-walk list
+    unsigned int* d_tcnt = nullptr;    // records per tile
     size_t tcnt_cap = 0;
+    uint2* d_witems = nullptr;         // work items of k_nn_tiles (the first 256 bytes: their counter)
+    size_t witems_cap = 0;
     int ntile_max = 0, cnt_stride = 0;
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
@@ -540,7 +542,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     h->match_pairs = n_pairs;
     if (h->tiles) {   // workspace of the LDS-staged search: per pair, query records per tile + the global-walk list, and their counters
         const size_t ntile = size_t(m3d_tiles_of(max_n_tgt));
-        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;
+        const size_t rec_stride = ntile * M3D_TILE_QCAP;
         const size_t cnt_stride = (ntile + 1 + 31) & ~size_t(31);
         if (n_pairs * rec_stride > h->rec_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -559,6 +561,15 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
             h->tcnt_cap = cap;
             HIPCHK(h, hipMemsetAsync(h->d_tcnt, 0, sizeof(unsigned int) * cap, h->stream));   // once: every iteration leaves its counters at zero
         }
+        const size_t wcap = n_pairs * (stride / 64 + 2 * ntile + 16);   // work items: at most one per 64 records plus one per tile
+        if (wcap > h->witems_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->d_witems) hipFree(h->d_witems);
+            h->d_witems = nullptr; h->witems_cap = 0;
+            HIPCHK(h, hipMalloc((void**)&h->d_witems, sizeof(uint2) * (wcap + wcap / 4) + 256));
+            h->witems_cap = wcap + wcap / 4;
+            HIPCHK(h, hipMemsetAsync(h->d_witems, 0, 256, h->stream));   // the first 256 bytes hold the item counter
+        }
         h->ntile_max = int(ntile); h->rec_stride = rec_stride; h->cnt_stride = int(cnt_stride);
     }
     return M3DREG_OK;
@@ -575,6 +586,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.rot = h->xcd_rot;
     w.tiles = h->tiles; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
+    w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 32 : nullptr; w.wcap = int(h->witems_cap);
     return w;
 }
 
@@ -720,7 +732,7 @@ int m3dreg_destroy(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt }) if (p) hipFree(p);   // (the states live in the jobs' block)
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt, (void*)h->d_witems }) if (p) hipFree(p);   // (the states live in the jobs' block)
     for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->staged) hipEventDestroy(h->staged);
