@@ -973,36 +973,50 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 }
             }
         }
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        uint32_t pos = 0;
-        unsigned long long todo = __ballot(tile >= 0);
-        while (todo) {   // wave-uniform: one trip per distinct tile of the wave (neighbouring queries: a handful)
-            const int leader = (int)__ffsll((long long)todo) - 1;
-            const int t0 = __shfl(tile, leader);
-            const unsigned long long same = __ballot(tile == t0);
+        // A record's slot: ONE returning atomic per (workgroup, tile) — the queries of a workgroup are neighbours, they fall into a
+        // handful of tiles. The lanes count themselves per tile in a small LDS table (rank inside the workgroup), one thread per
+        // distinct tile then reserves the workgroup's records in the tile's slab (all those atomics are in flight together: a
+        // per-wave loop over its distinct tiles waited for each in turn) and publishes the tile's new work items.
+        __shared__ int s_tk[64];
+        __shared__ unsigned int s_tn[64], s_tb[64];
+        if (tid < 64) { s_tk[tid] = -1; s_tn[tid] = 0u; }
+        __syncthreads();
+        int slot = -1; uint32_t rank = 0;
+        if (tile >= 0) {
+            uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> 26;
+            for (int tries = 0; tries < 64; tries++) {
+                const int old = atomicCAS(&s_tk[h], -1, tile);
+                if (old == -1 || old == tile) { slot = (int)h; break; }
+                h = (h + 1u) & 63u;
+            }
+            if (slot >= 0) rank = atomicAdd(&s_tn[slot], 1u);
+        }
+        __syncthreads();
+        if (tid < 64 && s_tk[tid] >= 0) {
+            const int t0 = s_tk[tid];
+            const M3dTileHdr H = thdr[t0];
             uint32_t base = 0xFFFFFFFFu;
-            if (lane == leader) {
-                const M3dTileHdr H = thdr[t0];
-                if (H.flags == 0u) {
-                    const uint32_t cnt = (uint32_t)__popcll(same);
-                    base = atomicAdd(&tcnt[t0], cnt);
-                    // work items of k_nn_tiles: one per chunk of the tile's records (512, or 64 for a tile with crowded voxels, whose
-                    // queries cost ten times as much: they are spread over more workgroups); the append that covers a chunk's first
-                    // record publishes it
-                    const uint32_t cs = (H.meta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
-                    const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
-                    for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
-                        const uint32_t w = atomicAdd(A.wcount, 1u);
-                        if (w < (uint32_t)A.wcap) A.witems[w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
-                    }
+            if (H.flags == 0u) {
+                const uint32_t cnt = s_tn[tid];
+                base = atomicAdd(&tcnt[t0], cnt);
+                // work items of k_nn_tiles: one per chunk of the tile's records (512, or 64 for a tile with crowded voxels, whose
+                // queries cost ten times as much: they are spread over more workgroups); the append that covers a chunk's first
+                // record publishes it
+                const uint32_t cs = (H.meta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
+                const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
+                for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
+                    const uint32_t w = atomicAdd(A.wcount, 1u);
+                    if (w < (uint32_t)A.wcap) A.witems[w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
                 }
             }
-            base = (uint32_t)__shfl((int)base, leader);
-            if (tile == t0) {
-                pos = base + (uint32_t)__popcll(same & lt);
-                if (base == 0xFFFFFFFFu || pos >= (uint32_t)M3D_TILE_QCAP) tile = -1;
-            }
-            todo &= ~same;
+            s_tb[tid] = base;
+        }
+        __syncthreads();
+        uint32_t pos = 0;
+        if (tile >= 0) {
+            const uint32_t base = slot >= 0 ? s_tb[slot] : 0xFFFFFFFFu;   // (more than 64 distinct tiles in one workgroup: the rest is walked below)
+            pos = base + rank;
+            if (base == 0xFFFFFFFFu || pos >= (uint32_t)M3D_TILE_QCAP) tile = -1;
         }
         if (tile >= 0) {
             const size_t r = (size_t)pair * A.rec_stride + (size_t)tile * M3D_TILE_QCAP + pos;
@@ -1474,12 +1488,16 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
     M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
-    A.tiles = w.tiles; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
+    A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
     A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
+    // first_of_level: 1 = first iteration of a level, 0 = a later one, -1 = a late one: the searches that are left (a few per cent
+    // of the queries, in blocks that are mostly certified) no longer go through the tiles, and k_nn_tiles is not launched
+    const int late = first_of_level < 0;
+    if (late) first_of_level = 0;
     hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
     M3D_DBG(s, "k_nn_iter");
-    if (w.tiles) {
+    if (w.tiles && !late) {
         hipLaunchKernelGGL(k_nn_tiles, dim3(M3D_TILE_GRID), dim3(M3D_TILE_THREADS), 0, s, d_jobs, first_of_level, A);
         M3D_DBG(s, "k_nn_tiles");
     }

@@ -115,9 +115,10 @@ struct m3dreg_handle {
     uint64_t launched_iters = 0, skipped_iters = 0;
     int certify = 1;
     int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
-    int lane_min = 96;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
+    int lane_min = 48;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
+    int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
     unsigned int* d_tickets = nullptr; // arrival counters of the reduction pass
@@ -715,6 +716,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return M3DREG_ERR_HIP; }
@@ -869,7 +871,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                 prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
                 if (prev_sampled) { k0 = next_event(h); h->ev_kind.push_back(0); k1 = next_event(h); h->ev_kind.push_back(1); }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : 0, nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? -1 : 0), nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             h->launched_iters++;
         }
     }
