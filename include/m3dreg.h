@@ -35,8 +35,11 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 2   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
-                                     M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch */
+#define M3DREG_ABI_VERSION 3   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+                                     M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
+                                  3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
+                                     exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
+                                     m3dreg_debug_accumulate / _trace refuse to run while a batch is pending */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -48,7 +51,8 @@ typedef enum m3dreg_error {
     M3DREG_ERR_GRID_TOO_LARGE = -4, /* voxel key needs more than 31 bits: coarsen leaf or crop cloud */
     M3DREG_ERR_EMPTY_CLOUD = -5,    /* no finite point in the cloud */
     M3DREG_ERR_NO_TARGET = -6,      /* m3dreg_align before m3dreg_set_target_xyz */
-    M3DREG_ERR_LEVEL_MISMATCH = -7  /* cloud was bucketed with other leaf sizes than the handle's */
+    M3DREG_ERR_LEVEL_MISMATCH = -7, /* cloud was bucketed with other leaf sizes than the handle's */
+    M3DREG_ERR_OUT_OF_MEMORY = -8   /* a host allocation failed inside the library (std::bad_alloc caught at the boundary); the handle stays usable */
 } m3dreg_error;
 
 typedef enum m3dreg_metric {
@@ -127,7 +131,13 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
                  size_t off_y, size_t off_z, const float init_T[16], float out_T[16],
                  m3dreg_stats* stats);
 
-/* ---- resident clouds (loop-closure batches, scan-to-scan chains, benchmarks) ---------------- */
+/* ---- resident clouds (loop-closure batches, scan-to-scan chains, benchmarks) ----------------
+ * Ownership and lifetime. A cloud belongs to the handle that bucketed it (its OWNER): its device block comes from the owner's pool
+ * and returns there, whichever handle is passed to m3dreg_cloud_destroy. A cloud may be used by ANY handle of the same device
+ * (source or target of its registrations, m3dmap_insert): the using handle's stream waits for the owner's bucketing, and the
+ * owner's stream waits for the last such use before the block is handed out again, so a cloud may be destroyed as soon as the
+ * call that uses it has returned (also the enqueue-only m3dreg_align_batch_async). An owner handle outlives its clouds:
+ * m3dreg_destroy only marks it closed while clouds of it are alive; the last m3dreg_cloud_destroy then releases it. */
 /* `data_is_device`: 0 = host payload, 1 = `data` is a device pointer on the handle's device (no PCIe copy); the single-cloud calls
  * (m3dreg_cloud_create, m3dreg_cloud_create_pc2) also take it as a flag word: | M3DREG_CLOUD_SOURCE_ONLY = the cloud will only ever be
  * a source (see m3dreg_cloud_desc.source_only). */
@@ -187,6 +197,23 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
 int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats);
 int m3dreg_synchronize(m3dreg_handle* h);
 void* m3dreg_get_stream(m3dreg_handle* h);
+
+/* ---- one process, several GPUs (SURVEY.md §8 rows b / e) ------------------------------------------------------------
+ * The consumer of this library is ONE process (m3d_husky_bringup.launch:13 starts one gpu_6dslam_node): a loop-closure batch is
+ * spread over the devices it names, without torchrun and without a collective — the pairs are independent. m3dreg_multi_align
+ * takes the raw payloads (a cloud lives on ONE device, so the sharding must come before the upload), assigns the pairs to the
+ * devices longest-processing-time-first by their point counts (n_source + n_target, at most ceil(n_pairs / n_devices) pairs per
+ * device), uploads and buckets every shard on its own device and stream (sources source-only), enqueues all registrations, and
+ * only then waits: the devices run concurrently, the results are gathered into the caller's arrays in PAIR order (a few hundred
+ * bytes per pair over PCIe: no RCCL inside one process). `devices` may name a device more than once (several streams on it).
+ * Results are bit-identical to m3dreg_align_batch on any one of the devices. */
+typedef struct m3dreg_multi m3dreg_multi;
+typedef struct m3dreg_pair_desc { m3dreg_cloud_desc source, target; float init_T[16]; } m3dreg_pair_desc;   /* source.source_only is implied */
+int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_devices, m3dreg_multi** out);
+int m3dreg_multi_destroy(m3dreg_multi* m);
+int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_pairs, float* out_T /* 16 * n_pairs */,
+                       m3dreg_stats* stats /* n_pairs, may be NULL */, int32_t* device_of_pair /* n_pairs, may be NULL: where each pair ran */);
+const char* m3dreg_multi_last_error(const m3dreg_multi* m);
 
 /* ---- aggregation on the device ---------------------------------------------
  * The step m3d_aggregator performs before publishing a cloud (m3d/m3d_aggregator/src/m3d_aggregator.cpp):
@@ -258,14 +285,18 @@ int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out);  
 int m3dmap_clear(m3dmap* m);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration of the handle is bracketed by three hipEvents on
- * its stream: before and after the dominant kernel (`k_nn_iter`: certificate check + exact 27-voxel NN search of
- * every query of every pair of the batch) and at the end of the iteration (search + reduction + solve), so
- * bench.py can report that kernel's average launch duration from inside its timed region. (An event record is
- * a barrier packet on the queue: bracketing every iteration cost 4 % of the throughput it measured.) */
+/* Per-stage device times of the path ("ms per stage"). on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration
+ * of the handle is bracketed by three hipEvents on its stream: before and after the correspondence step (`k_nn_iter`: certificate
+ * check, binning / sparse search of every query of every pair of the batch; `k_nn_tiles`: the binned searches from LDS) and at
+ * the end of the iteration (reduction + solve), and every bucketing batch by two, so bench.py can report the stage durations
+ * from inside its timed region. (An event record is a barrier packet on the queue: bracketing every iteration cost 4 % of the
+ * throughput it measured.) With M3DREG_ROCTX=1 in the environment the same stages are also marked as roctx ranges
+ * ("m3dreg:bucketing", "m3dreg:iteration") for rocprofv3 --marker-trace. */
 int m3dreg_profile_enable(m3dreg_handle* h, int on);
-#define M3DREG_PROFILE_ITERATION 0
-#define M3DREG_PROFILE_DOMINANT_KERNEL 1
+#define M3DREG_PROFILE_ITERATION 0        /* one Gauss-Newton iteration of the batch: correspondence step + reduction + solve */
+#define M3DREG_PROFILE_DOMINANT_KERNEL 1  /* its correspondence step (a6) */
+#define M3DREG_PROFILE_BUCKETING 2        /* one bucketing batch (a2-a4, a9, tiles): m3dreg_cloud_create* */
+#define M3DREG_PROFILE_REDUCE_SOLVE 3     /* a7 + a8 of the bracketed iterations (= ITERATION - DOMINANT_KERNEL) */
 /* Synchronises the stream, returns the number of bracketed launches of kind `what` and the sum of their
  * durations since the last reset; `reset` != 0 clears that kind's counters. */
 int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset);
@@ -306,10 +337,14 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
 /* Per-iteration pose trace of the most recent m3dreg_align/align_clouds on this handle:
  * column-major double[16] after each executed iteration; returns count via *n_out (<= cap). */
 int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out);
-/* Diagnostics of the first pair of the most recent batch (default kernel variant), summed over the
- * iterations after the first of each level: out[0] = queries that needed the full 27-voxel search,
- * out[1] = queries that needed the seeded search; all others were answered by an NN certificate. */
+/* Diagnostics of the first pair of the most recent batch: out[0] = searches answered from LDS-staged tiles (k_nn_tiles),
+ * out[1] = searches of flagged tiles / full slabs walked in global memory instead. */
 int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]);
+/* Test hooks of the exception guard: the n-th host allocation of the library from now on throws std::bad_alloc (0 = off);
+ * m3dreg_debug_throw runs a guarded body that throws (kind 0: std::bad_alloc, else: something else) and returns what the
+ * boundary made of it (M3DREG_ERR_OUT_OF_MEMORY / M3DREG_ERR_HIP). Neither needs a device. */
+int m3dreg_debug_fail_alloc(int nth);
+int m3dreg_debug_throw(int kind);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ HIP library and to the CPU oracle in the parity tests.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LEVELS = 4
 NSUMS = 29
 
@@ -18,11 +18,12 @@ ERR_GRID_TOO_LARGE = -4
 ERR_EMPTY_CLOUD = -5
 ERR_NO_TARGET = -6
 ERR_LEVEL_MISMATCH = -7
+ERR_OUT_OF_MEMORY = -8
 ERROR_NAMES = {
     OK: "M3DREG_OK", ERR_INVALID_ARG: "M3DREG_ERR_INVALID_ARG", ERR_NO_DEVICE: "M3DREG_ERR_NO_DEVICE",
     ERR_HIP: "M3DREG_ERR_HIP", ERR_GRID_TOO_LARGE: "M3DREG_ERR_GRID_TOO_LARGE",
     ERR_EMPTY_CLOUD: "M3DREG_ERR_EMPTY_CLOUD", ERR_NO_TARGET: "M3DREG_ERR_NO_TARGET",
-    ERR_LEVEL_MISMATCH: "M3DREG_ERR_LEVEL_MISMATCH",
+    ERR_LEVEL_MISMATCH: "M3DREG_ERR_LEVEL_MISMATCH", ERR_OUT_OF_MEMORY: "M3DREG_ERR_OUT_OF_MEMORY",
 }
 
 # m3dreg_metric
@@ -126,6 +127,10 @@ class PointField(C.Structure):   # m3dreg_point_field
 
 class Pair(C.Structure):
     _fields_ = [("source", C.c_void_p), ("target", C.c_void_p), ("init_T", C.c_float * 16)]
+
+
+class PairDesc(C.Structure):   # m3dreg_pair_desc (m3dreg_multi_align)
+    _fields_ = [("source", CloudDesc), ("target", CloudDesc), ("init_T", C.c_float * 16)]
 
 
 class M3dregError(RuntimeError):

@@ -33,6 +33,8 @@ EXPORTS = [
     "m3dagg_download",
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
+    "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error",
+    "m3dreg_debug_fail_alloc", "m3dreg_debug_throw",
 ]
 
 
@@ -104,6 +106,13 @@ def lib():
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
+    L.m3dreg_multi_create.argtypes = [C.POINTER(abi.Params), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.m3dreg_multi_destroy.argtypes = [vp]
+    L.m3dreg_multi_align.argtypes = [vp, C.POINTER(abi.PairDesc), sz, f32p, C.POINTER(abi.Stats), i32p]
+    L.m3dreg_multi_last_error.argtypes = [vp]
+    L.m3dreg_multi_last_error.restype = C.c_char_p
+    L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
+    L.m3dreg_debug_throw.argtypes = [C.c_int]
     if L.m3dreg_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libm3dreg.so ABI version mismatch")
     _lib = L
@@ -358,6 +367,57 @@ class Registrar:
         self._check(lib().m3dreg_debug_trace(self._h, _ptr(buf, C.c_double), cap, C.byref(n)), "debug_trace")
         k = min(n.value, cap)
         return np.stack([colmajor16_to_T(buf[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))
+
+
+class MultiRegistrar:
+    """m3dreg_multi: ONE process, several devices (or several streams of one). Pairs are given as raw PointCloud2 payloads
+    (numpy (n, 3) float32 arrays are encoded the aggregator's way); the library shards, uploads, registers and gathers."""
+
+    def __init__(self, params=None, devices=(0,)):
+        self._m = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        dev = (C.c_int * len(devices))(*devices)
+        rc = lib().m3dreg_multi_create(C.byref(self.params), dev, len(devices), C.byref(self._m))
+        if rc != 0:
+            self._m = None
+            raise abi.M3dregError(rc, "m3dreg_multi_create")
+        self.devices = tuple(devices)
+
+    def close(self):
+        if self._m:
+            lib().m3dreg_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def align(self, pairs):
+        """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (poses [n, 4, 4], stats list, device of every pair)"""
+        from .pointcloud2 import encode_xyz
+        n = len(pairs)
+        descs = (abi.PairDesc * n)()
+        keep = []
+        for i, (src, tgt, T0) in enumerate(pairs):
+            for d, xyz in ((descs[i].source, src), (descs[i].target, tgt)):
+                msg = encode_xyz(np.ascontiguousarray(xyz, np.float32))
+                buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+                keep.append(buf)
+                d.data = C.cast(buf, C.c_void_p); d.n = msg.n; d.point_step = msg.point_step
+                d.off_x, d.off_y, d.off_z = 0, 4, 8
+                d.data_is_device = 0; d.source_only = 0
+            t0 = T_to_colmajor16(np.eye(4) if T0 is None else T0)
+            for k in range(16):
+                descs[i].init_T[k] = float(t0[k])
+        out = np.zeros(16 * n, np.float32)
+        st = (abi.Stats * n)()
+        dev = np.zeros(n, np.int32)
+        rc = lib().m3dreg_multi_align(self._m, descs, n, _ptr(out, C.c_float), st, _ptr(dev, C.c_int32))
+        if rc != 0:
+            raise abi.M3dregError(rc, "m3dreg_multi_align", lib().m3dreg_multi_last_error(self._m).decode())
+        return np.stack([colmajor16_to_T(out[16 * i:16 * i + 16]) for i in range(n)]), list(st), dev
 
 
 class Aggregator:

@@ -9,6 +9,9 @@
 #include "../../include/m3dreg.h"
 #include "m3d_kernels.h"
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -77,12 +80,15 @@ struct m3dreg_cloud {
     Block block;                   // ONE device allocation holds every array of the cloud
     m3dreg_handle* owner = nullptr;    // the handle whose stream bucketed it
     struct BatchReady* ready = nullptr;   // event recorded behind the bucketing of the batch this cloud came from (shared, ref-counted)
+    hipEvent_t last_use = nullptr;     // recorded on ANOTHER handle's stream behind its last use of this cloud: the owner's stream waits for it before the block is re-used
     bool meta_ready = false;           // geometry / counts / error state read back to the host (lazily: grid_info, export, debug_nn, the synchronous entry points)
     int err = 0;                       // valid once meta_ready: 0 or the m3dreg_error the device found (no finite point, grid too large)
 };
 struct BatchReady { hipEvent_t ev = nullptr; int refs = 0; };
 
 struct m3dreg_handle {
+    int live_clouds = 0;               // clouds this handle owns: it is only released once they are gone (a cloud's block returns to ITS pool)
+    bool closed = false;               // m3dreg_destroy was called
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -141,8 +147,8 @@ struct m3dreg_handle {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_kind;          // per recorded event: 0 = before the dominant kernel (= start of an iteration), 1 = after it, 2 = end of the batch
     size_t ev_used = 0;
-    uint64_t prof_launches[2] = { 0, 0 };
-    double prof_ms[2] = { 0.0, 0.0 };
+    uint64_t prof_launches[4] = { 0, 0, 0, 0 };   // M3DREG_PROFILE_*: iteration, correspondence step, bucketing batch, reduce + solve
+    double prof_ms[4] = { 0.0, 0.0, 0.0, 0.0 };
 };
 
 namespace {
@@ -164,6 +170,18 @@ int fail(m3dreg_handle* h, int code, const char* where, hipError_t e = hipSucces
     } while (0)
 
 static_assert(M3D_ERR_GRID_TOO_LARGE == M3DREG_ERR_GRID_TOO_LARGE && M3D_ERR_EMPTY_CLOUD == M3DREG_ERR_EMPTY_CLOUD, "device error codes");
+
+// No exception crosses the C boundary (include/m3dreg.h): every exported function runs its body inside this guard. The library
+// itself throws nothing; what can throw underneath it is the host allocator (new, std::vector, std::string).
+template <class F> int m3d_guarded(m3dreg_handle* h, const char* where, F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { try { return fail(h, M3DREG_ERR_OUT_OF_MEMORY, where); } catch (...) { return M3DREG_ERR_OUT_OF_MEMORY; } }
+    catch (...) { try { return fail(h, M3DREG_ERR_HIP, where); } catch (...) { return M3DREG_ERR_HIP; } }
+}
+// test hook (m3dreg_debug_fail_alloc): the n-th host allocation from now on throws std::bad_alloc
+std::atomic<int> g_fail_alloc{0};
+inline void alloc_point() { int v = g_fail_alloc.load(); if (v > 0 && g_fail_alloc.fetch_sub(1) == 1) throw std::bad_alloc(); }
+
 
 const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
 
@@ -220,11 +238,30 @@ int ensure_ws(m3dreg_handle* h, size_t dev_bytes, size_t host_bytes) {
     return M3DREG_OK;
 }
 
+void release_handle(m3dreg_handle* h);
+// The block goes back to the OWNER's pool (whichever handle asked): every later use of it is enqueued on the owner's stream, which
+// first waits for the last use another handle's stream made of the cloud.
 void free_cloud(m3dreg_handle* h, m3dreg_cloud* c) {
     if (!c) return;
+    m3dreg_handle* o = c->owner ? c->owner : h;
     if (c->ready && --c->ready->refs == 0) { hipEventDestroy(c->ready->ev); delete c->ready; }
-    pool_put(h, c->block);
+    if (c->last_use) {
+        if (o) { hipSetDevice(o->device); hipStreamWaitEvent(o->stream, c->last_use, 0); }
+        hipEventDestroy(c->last_use);
+    }
+    if (o) pool_put(o, c->block); else if (c->block.p) hipFree(c->block.p);
+    const bool counted = c->owner != nullptr;
     delete c;
+    if (counted && --o->live_clouds == 0 && o->closed) release_handle(o);
+}
+
+// a handle other than the owner has just enqueued work that reads the cloud: remember where that work ends
+int note_foreign_use(m3dreg_handle* h, const m3dreg_cloud* cc) {
+    m3dreg_cloud* c = const_cast<m3dreg_cloud*>(cc);
+    if (!c->owner || c->owner == h) return M3DREG_OK;
+    if (!c->last_use) HIPCHK(h, hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(c->last_use, h->stream));
+    return M3DREG_OK;
 }
 
 uint32_t table_cap(size_t n) { uint32_t hs = 16; while (hs < 2u * uint32_t(n)) hs <<= 1; return hs; }
@@ -258,6 +295,10 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     return (k.off + 255) & ~size_t(255);
 }
 
+hipEvent_t next_event(m3dreg_handle* h);
+void roctx_push(const char* name);
+void roctx_pop();
+
 struct CloudInput { const void* data; size_t n, step, ox, oy, oz; bool is_device; bool aligned; bool src_only = false;
                     bool generic = false; size_t width = 0, row_step = 0, data_bytes = 0; bool f64[3] = { false, false, false }; bool bigendian = false; };
 
@@ -273,6 +314,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     auto cleanup = [&]() { hipStreamSynchronize(h->stream); for (m3dreg_cloud* c : cl) free_cloud(h, c); };
     size_t max_n = 0;
     for (size_t i = 0; i < k; i++) {
+        alloc_point();
         m3dreg_cloud* c = new m3dreg_cloud();
         cl[i] = c;
         c->n = int32_t(in[i].n);
@@ -406,12 +448,18 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         if (size_t(reinterpret_cast<uint8_t*>(h_aabb0 + 8 * k) - reinterpret_cast<uint8_t*>(h_dec)) != span) { cleanup(); return fail(h, M3DREG_ERR_HIP, "descriptor staging layout"); }
         B_HIP(hipMemcpyAsync(d_dec, h_dec, span, hipMemcpyHostToDevice, h->stream));
     }
+    roctx_push("m3dreg:bucketing");
+    hipEvent_t pb0 = nullptr;
+    if (h->profiling) { pb0 = next_event(h); if (pb0) { h->ev_kind.push_back(3); (void)hipEventRecord(pb0, h->stream); } }
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
     if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
     B_HIP(hipEventRecord(h->staged, h->stream));
     B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, any_tiles, P.plane_ratio,
                                   P.normal_min_pts, P.normal_min_spread));
+    if (pb0) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(4); (void)hipEventRecord(e, h->stream); } }
+    roctx_pop();
     // One event behind the pipeline lets OTHER handles order their streams after it.
+    alloc_point();
     BatchReady* br = new BatchReady();
     if (hipEventCreateWithFlags(&br->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(br->ev, h->stream) != hipSuccess) {
         if (br->ev) hipEventDestroy(br->ev);
@@ -419,7 +467,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     }
 #undef B_HIP
     for (size_t i = 0; i < k; i++) {
-        cl[i]->owner = h; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false; cl[i]->err = 0;
+        cl[i]->owner = h; h->live_clouds++; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false; cl[i]->err = 0;
         out[i] = cl[i];
     }
     return M3DREG_OK;
@@ -657,17 +705,55 @@ hipEvent_t next_event(m3dreg_handle* h) {
 // iteration (search + reduction + solve) — two event records per iteration instead of four (each one is a barrier packet
 // on the queue and cost ~4 us of the ~60 us iterations it was measuring).
 void drain_events(m3dreg_handle* h) {
-    hipEvent_t k0 = nullptr;
-    for (size_t i = 0; i < h->ev_used; i++) {
+    hipEvent_t k0 = nullptr, k1 = nullptr, b0 = nullptr;
+    for (size_t i = 0; i < h->ev_used && i < h->ev_kind.size(); i++) {
         float ms = 0.f;
         const int kind = h->ev_kind[i];
         hipEvent_t e = h->ev_pool[i];
-        if (kind == 1) { if (k0 && hipEventElapsedTime(&ms, k0, e) == hipSuccess) { h->prof_ms[1] += double(ms); h->prof_launches[1]++; } continue; }
+        if (kind == 3) { b0 = e; continue; }   // bucketing batch: begin / end
+        if (kind == 4) { if (b0 && hipEventElapsedTime(&ms, b0, e) == hipSuccess) { h->prof_ms[2] += double(ms); h->prof_launches[2]++; } b0 = nullptr; continue; }
+        if (kind == 1) { k1 = e; if (k0 && hipEventElapsedTime(&ms, k0, e) == hipSuccess) { h->prof_ms[1] += double(ms); h->prof_launches[1]++; } continue; }
+        // kind 0 (start of a bracketed iteration) or 2 (end of one): both close the iteration that k0 opened
         if (k0 && hipEventElapsedTime(&ms, k0, e) == hipSuccess) { h->prof_ms[0] += double(ms); h->prof_launches[0]++; }
-        k0 = (kind == 0) ? e : nullptr;
+        if (k0 && k1 && hipEventElapsedTime(&ms, k1, e) == hipSuccess) { h->prof_ms[3] += double(ms); h->prof_launches[3]++; }
+        k0 = (kind == 0) ? e : nullptr; k1 = nullptr;
     }
     h->ev_used = 0;
     h->ev_kind.clear();
+}
+
+// roctx ranges around the stages (M3DREG_ROCTX=1): libroctx64 is looked up at run time, the library does not link it
+void roctx_push(const char* name) {
+    static int (*push)(const char*) = [] {
+        const char* v = getenv("M3DREG_ROCTX");
+        if (!v || !atoi(v)) return (int (*)(const char*))nullptr;
+        void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        return lib ? (int (*)(const char*))dlsym(lib, "roctxRangePushA") : nullptr;
+    }();
+    if (push) push(name);
+}
+void roctx_pop() {
+    static int (*pop)() = [] {
+        const char* v = getenv("M3DREG_ROCTX");
+        if (!v || !atoi(v)) return (int (*)())nullptr;
+        void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        return lib ? (int (*)())dlsym(lib, "roctxRangePop") : nullptr;
+    }();
+    if (pop) pop();
+}
+
+void release_handle(m3dreg_handle* h) {
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (Block& b : h->pool) hipFree(b.p);
+    if (h->ws.p) hipFree(h->ws.p);
+    if (h->h_ws) hipHostFree(h->h_ws);
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt, (void*)h->d_witems }) if (p) hipFree(p);   // (the states live in the jobs' block)
+    for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->staged) hipEventDestroy(h->staged);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
 }
 
 void stats_from_state(const M3dPairState& S, m3dreg_stats* st) {
@@ -688,6 +774,7 @@ const char* m3dreg_backend_name(void) { return "hip-gfx950"; }
 const char* m3dreg_last_error(const m3dreg_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 int m3dreg_default_params(m3dreg_params* p) {
+    return m3d_guarded(nullptr, "m3dreg_default_params", [&]() -> int {
     if (!p) return M3DREG_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));
     p->n_levels = 1; p->leaf[0] = 0.1f; p->iterations[0] = 30; p->max_corr_dist[0] = 0.5f;
@@ -695,9 +782,11 @@ int m3dreg_default_params(m3dreg_params* p) {
     p->eps_rot = 1e-5; p->eps_trans = 1e-5; p->pivot_rel_tol = 1e-9;
     p->plane_ratio = 0.25f; p->normal_min_pts = 5; p->normal_leaf = 0.4f; p->normal_min_spread = 0.25f;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_handle** out) {
+    return m3d_guarded(nullptr, "m3dreg_create", [&]() -> int {
     if (!out) return M3DREG_ERR_INVALID_ARG;
     *out = nullptr;
     int rc = validate_params(params);
@@ -708,6 +797,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return M3DREG_ERR_NO_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return M3DREG_ERR_NO_DEVICE;  // the code object is gfx950-only
+    alloc_point();
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
@@ -724,31 +814,29 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     }
     *out = h;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_destroy(m3dreg_handle* h) {
-    if (!h) return M3DREG_ERR_INVALID_ARG;
+    return m3d_guarded(nullptr, "m3dreg_destroy", [&]() -> int {
+    if (!h || h->closed) return M3DREG_ERR_INVALID_ARG;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    free_cloud(h, h->target);
-    for (Block& b : h->pool) hipFree(b.p);
-    if (h->ws.p) hipFree(h->ws.p);
-    if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt, (void*)h->d_witems }) if (p) hipFree(p);   // (the states live in the jobs' block)
-    for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
-    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-    if (h->staged) hipEventDestroy(h->staged);
-    if (h->own_stream) hipStreamDestroy(h->stream);
-    delete h;
+    if (h->target) { m3dreg_cloud* t = h->target; h->target = nullptr; free_cloud(h, t); }
+    h->closed = true;
+    if (h->live_clouds == 0) release_handle(h);   // else: the last m3dreg_cloud_destroy of a cloud it owns releases it
     return M3DREG_OK;
+    });
 }
 
 void* m3dreg_get_stream(m3dreg_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
 int m3dreg_synchronize(m3dreg_handle* h) {
+    return m3d_guarded(h, "m3dreg_synchronize", [&]() -> int {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return M3DREG_OK;
+    });
 }
 
 static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput& ci) {
@@ -766,31 +854,39 @@ static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput&
 }
 
 int m3dreg_cloud_create_batch_async(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
+    return m3d_guarded(h, "m3dreg_cloud_create_batch_async", [&]() -> int {
     if (!h || !descs || !out || n_clouds == 0 || n_clouds > 4096) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_batch: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<CloudInput> in(n_clouds);
     for (size_t i = 0; i < n_clouds; i++) { out[i] = nullptr; int rc = check_input(h, descs[i], in[i]); if (rc) return rc; }
     return create_clouds(h, in.data(), n_clouds, out);
+    });
 }
 
 int m3dreg_cloud_create_batch(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
+    return m3d_guarded(h, "m3dreg_cloud_create_batch", [&]() -> int {
     const int rc = m3dreg_cloud_create_batch_async(h, descs, n_clouds, out);
     return rc ? rc : finish_sync(h, out, n_clouds);
+    });
 }
 
 int m3dreg_cloud_status(m3dreg_handle* h, const m3dreg_cloud* c) {
+    return m3d_guarded(h, "m3dreg_cloud_status", [&]() -> int {
     if (!h || !c) return M3DREG_ERR_INVALID_ARG;
     return fetch_meta(h, const_cast<m3dreg_cloud*>(c));
+    });
 }
 
 int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                         int data_is_device, m3dreg_cloud** out) {
+    return m3d_guarded(h, "m3dreg_cloud_create", [&]() -> int {
     if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create: bad argument");
     m3dreg_cloud_desc d;
     d.data = data; d.n = n; d.point_step = point_step; d.off_x = off_x; d.off_y = off_y; d.off_z = off_z;
     d.data_is_device = (data_is_device & M3DREG_CLOUD_DEVICE) ? 1 : 0;
     d.source_only = (data_is_device & M3DREG_CLOUD_SOURCE_ONLY) ? 1 : 0;
     return m3dreg_cloud_create_batch(h, &d, 1, out);
+    });
 }
 
 // the whole sensor_msgs/PointCloud2 layout contract (what pcl::fromPCLPointCloud2 resolves by field name,
@@ -798,6 +894,7 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
 int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_bytes, uint32_t width, uint32_t height, uint32_t point_step,
                             uint32_t row_step, const m3dreg_point_field* fields, size_t n_fields, int is_bigendian, int data_is_device,
                             m3dreg_cloud** out) {
+    return m3d_guarded(h, "m3dreg_cloud_create_pc2", [&]() -> int {
     if (!h || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: bad argument");
     *out = nullptr;
     if (!data || !fields || width == 0 || height == 0 || point_step == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_pc2: empty message");
@@ -831,15 +928,19 @@ int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_byte
     HIPCHK(h, hipSetDevice(h->device));
     const int rc = create_clouds(h, &ci, 1, out);
     return rc ? rc : finish_sync(h, out, 1);
+    });
 }
 
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
+    return m3d_guarded(h, "m3dreg_cloud_destroy", [&]() -> int {
     if (!h || !c) return M3DREG_ERR_INVALID_ARG;
     free_cloud(h, c);   // the block returns to the handle's cache; later users are ordered on the same stream
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
+    return m3d_guarded(h, "m3dreg_align_batch_async", [&]() -> int {
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
     if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch_async: a batch is pending on this handle (a handle holds the state of ONE batch: call m3dreg_batch_wait, or use another handle on the same stream)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -865,24 +966,36 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                 }
             }
             h->seq++;
+            roctx_push("m3dreg:iteration");
             hipEvent_t k0 = nullptr, k1 = nullptr;
             if (h->profiling) {   // every prof_every-th iteration is bracketed: {k0, k1, end of the iteration}
-                if (prev_sampled) { hipEvent_t e = next_event(h); h->ev_kind.push_back(2); if (e) (void)hipEventRecord(e, h->stream); }
+                if (prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
                 prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
-                if (prev_sampled) { k0 = next_event(h); h->ev_kind.push_back(0); k1 = next_event(h); h->ev_kind.push_back(1); }
+                if (prev_sampled) {
+                    k0 = next_event(h); if (k0) h->ev_kind.push_back(0);
+                    k1 = k0 ? next_event(h) : nullptr; if (k1) h->ev_kind.push_back(1);
+                    if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
+                }
             }
             HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? -1 : 0), nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            roctx_pop();
             h->launched_iters++;
         }
     }
-    if (h->profiling && prev_sampled) { hipEvent_t e = next_event(h); h->ev_kind.push_back(2); if (e) (void)hipEventRecord(e, h->stream); }
+    if (h->profiling && prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
+    for (size_t i = 0; i < n_pairs; i++) {   // clouds of other handles: their owners' streams wait for this batch before the blocks are re-used
+        if ((rc = note_foreign_use(h, pairs[i].source))) return rc;
+        if ((rc = note_foreign_use(h, pairs[i].target))) return rc;
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
+    return m3d_guarded(h, "m3dreg_batch_wait", [&]() -> int {
     if (!h || h->pending_pairs == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "batch_wait: nothing pending");
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->ev_used) drain_events(h);
@@ -895,24 +1008,30 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
     h->pending_pairs = 0;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T, m3dreg_stats* stats) {
+    return m3d_guarded(h, "m3dreg_align_batch", [&]() -> int {
     int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
     if (rc) return rc;
     return m3dreg_batch_wait(h, out_T, stats);
+    });
 }
 
 int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target, const float init_T[16], float out_T[16],
                         m3dreg_stats* stats) {
+    return m3d_guarded(h, "m3dreg_align_clouds", [&]() -> int {
     if (!h || !source || !target || !init_T || !out_T) return fail(h, M3DREG_ERR_INVALID_ARG, "align_clouds: bad argument");
     m3dreg_pair p;
     p.source = source; p.target = target;
     memcpy(p.init_T, init_T, sizeof(float) * 16);
     return m3dreg_align_batch(h, &p, 1, out_T, stats);
+    });
 }
 
 int m3dreg_set_target_xyz(m3dreg_handle* h, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z) {
+    return m3d_guarded(h, "m3dreg_set_target_xyz", [&]() -> int {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     m3dreg_cloud* c = nullptr;
     int rc = m3dreg_cloud_create(h, data, n, point_step, off_x, off_y, off_z, 0, &c);
@@ -920,10 +1039,12 @@ int m3dreg_set_target_xyz(m3dreg_handle* h, const void* data, size_t n, size_t p
     if (h->target) free_cloud(h, h->target);
     h->target = c;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
                  const float init_T[16], float out_T[16], m3dreg_stats* stats) {
+    return m3d_guarded(h, "m3dreg_align", [&]() -> int {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     if (!h->target) return fail(h, M3DREG_ERR_NO_TARGET, "m3dreg_align before m3dreg_set_target_xyz");
     m3dreg_cloud* s = nullptr;
@@ -932,6 +1053,7 @@ int m3dreg_align(m3dreg_handle* h, const void* src, size_t n, size_t point_step,
     rc = m3dreg_align_clouds(h, s, h->target, init_T, out_T, stats);
     m3dreg_cloud_destroy(h, s);
     return rc;
+    });
 }
 
 // ---- aggregation on the device --------------------------------------------------------
@@ -1041,6 +1163,7 @@ int agg_add(m3dagg* a, M3dAggArgs& A, const void* host_payload, size_t payload_b
 extern "C" {
 
 int m3dagg_create(m3dreg_handle* h, const double bbox[6], size_t capacity, m3dagg** out) {
+    return m3d_guarded(h, "m3dagg_create", [&]() -> int {
     if (!h || !bbox || !out || capacity == 0 || capacity >= 0x7FFFFFFFull) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dagg_create: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
     m3dagg* a = new m3dagg();
@@ -1052,34 +1175,42 @@ int m3dagg_create(m3dreg_handle* h, const double bbox[6], size_t capacity, m3dag
     if (e != hipSuccess) { if (a->d_pts) hipFree(a->d_pts); if (a->d_count) hipFree(a->d_count); delete a; return fail(h, M3DREG_ERR_HIP, "m3dagg_create", e); }
     *out = a;
     return M3DREG_OK;
+    });
 }
 
 int m3dagg_destroy(m3dagg* a) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_destroy", [&]() -> int {
     if (!a) return M3DREG_ERR_INVALID_ARG;
     hipSetDevice(a->h->device);
     hipStreamSynchronize(a->h->stream);
     for (void* p : { (void*)a->d_pts, (void*)a->d_count, (void*)a->d_blocks, (void*)a->d_stage }) if (p) hipFree(p);
     delete a;
     return M3DREG_OK;
+    });
 }
 
 int m3dagg_add_cloud(m3dagg* a, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z, const double tf7[7]) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_add_cloud", [&]() -> int {
     if (!a || !data || !tf7 || n == 0 || n >= 0x7FFFFFFFull) return M3DREG_ERR_INVALID_ARG;
     if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step || (point_step % 4) || (off_x % 4) || (off_y % 4) || (off_z % 4))
         return fail(a->h, M3DREG_ERR_INVALID_ARG, "m3dagg_add_cloud: FLOAT32 fields must be 4-byte aligned inside point_step");
     M3dAggArgs A{};
     A.mode = 0; A.n = int(n); A.step = int(point_step); A.ox = int(off_x); A.oy = int(off_y); A.oz = int(off_z);
     return agg_add(a, A, data, n * point_step, tf7);
+    });
 }
 
 int m3dagg_add_scan(m3dagg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf7[7]) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_add_scan", [&]() -> int {
     if (!a || !ranges || !tf7 || n == 0 || n >= 0x7FFFFFFFull) return M3DREG_ERR_INVALID_ARG;
     M3dAggArgs A{};
     A.mode = 1; A.n = int(n); A.angle_min = angle_min; A.angle_inc = angle_increment;
     return agg_add(a, A, ranges, n * sizeof(float), tf7);
+    });
 }
 
 int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t* n_points) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_status", [&]() -> int {
     if (!a) return M3DREG_ERR_INVALID_ARG;
     if (progress) *progress = a->creating ? 0.1 * std::floor(a->current_angle * 1000.0 / a->angular_distance) : -1.0;   // :119-124
     if (ready) *ready = a->current_angle > a->angular_distance ? 1 : 0;                                                  // :95-103
@@ -1092,16 +1223,20 @@ int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t
         *n_points = c[0];
     }
     return M3DREG_OK;
+    });
 }
 
 int m3dagg_restart(m3dagg* a) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_restart", [&]() -> int {
     if (!a) return M3DREG_ERR_INVALID_ARG;
     HIPCHK(a->h, hipMemsetAsync(a->d_count, 0, sizeof(uint32_t) * 2, a->h->stream));
     a->current_angle = 0.0; a->first_scan = true; a->creating = true;
     return M3DREG_OK;
+    });
 }
 
 int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_take_cloud", [&]() -> int {
     if (!a || !out) return M3DREG_ERR_INVALID_ARG;
     size_t n = 0;
     int rc = m3dagg_status(a, nullptr, nullptr, nullptr, &n);
@@ -1110,9 +1245,11 @@ int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out) {
     rc = m3dreg_cloud_create(a->h, a->d_pts, n, 16, 0, 4, 8, 1, out);   // bucketed in place: no PCIe transfer of the sweep
     if (rc) return rc;
     return m3dagg_restart(a);
+    });
 }
 
 int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_download", [&]() -> int {
     if (!a || !n_out) return M3DREG_ERR_INVALID_ARG;
     size_t n = 0;
     int rc = m3dagg_status(a, nullptr, nullptr, nullptr, &n);
@@ -1124,6 +1261,7 @@ int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out) {
         HIPCHK(a->h, hipStreamSynchronize(a->h->stream));
     }
     return M3DREG_OK;
+    });
 }
 
 // ---- calibration cost on the device --------------------------------------------------
@@ -1201,14 +1339,17 @@ int cal_eval1(m3dcal* c, const float p6[6], float* err) {
 extern "C" {
 
 int m3dcal_create(m3dreg_handle* h, int laser_up_axis, m3dcal** out) {
+    return m3d_guarded(h, "m3dcal_create", [&]() -> int {
     if (!h || !out || laser_up_axis < 0 || laser_up_axis > 2) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dcal_create: bad argument");
     m3dcal* c = new m3dcal();
     c->h = h; c->axis = laser_up_axis;
     *out = c;
     return M3DREG_OK;
+    });
 }
 
 int m3dcal_destroy(m3dcal* c) {
+    return m3d_guarded((c ? c->h : nullptr), "m3dcal_destroy", [&]() -> int {
     if (!c) return M3DREG_ERR_INVALID_ARG;
     hipSetDevice(c->h->device);
     hipStreamSynchronize(c->h->stream);
@@ -1216,9 +1357,11 @@ int m3dcal_destroy(m3dcal* c) {
     for (void* p : { (void*)c->h_mm, (void*)c->h_result, (void*)c->h_status }) if (p) hipHostFree(p);
     delete c;
     return M3DREG_OK;
+    });
 }
 
 int m3dcal_add_segment(m3dcal* c, const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z, const float T[16]) {
+    return m3d_guarded((c ? c->h : nullptr), "m3dcal_add_segment", [&]() -> int {
     if (!c || !T || (n && !data)) return M3DREG_ERR_INVALID_ARG;
     if (off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step) return fail(c->h, M3DREG_ERR_INVALID_ARG, "m3dcal_add_segment: field offsets outside point_step");
     if (c->pts.size() / 4 + n >= 0x3FFFFFFFull) return fail(c->h, M3DREG_ERR_INVALID_ARG, "m3dcal_add_segment: too many points");
@@ -1234,9 +1377,11 @@ int m3dcal_add_segment(m3dcal* c, const void* data, size_t n, size_t point_step,
     }
     c->dirty = true;
     return M3DREG_OK;
+    });
 }
 
 int m3dcal_evaluate(m3dcal* c, const float* params, size_t k, int64_t* counts, int64_t* voxels) {
+    return m3d_guarded((c ? c->h : nullptr), "m3dcal_evaluate", [&]() -> int {
     if (!c || !params || !counts || k == 0 || k > 4096) return M3DREG_ERR_INVALID_ARG;
     m3dreg_handle* h = c->h;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1284,11 +1429,13 @@ int m3dcal_evaluate(m3dcal* c, const float* params, size_t k, int64_t* counts, i
         }
     }
     return M3DREG_OK;
+    });
 }
 
 // m3d_calibration_twiddle.cpp:330-396. p and dp are std::vector<float> (:514); `p[i] - 2.0 * dp[i]` and `dp[i] * 1.1` are
 // double expressions rounded back to float on assignment, exactly as written here.
 int m3dcal_twiddle(m3dcal* c, int max_sweeps, float p_out[5], float* best_error_out, int* sweeps, int* evaluations) {
+    return m3d_guarded((c ? c->h : nullptr), "m3dcal_twiddle", [&]() -> int {
     if (!c || !p_out) return M3DREG_ERR_INVALID_ARG;
     float p[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, dp[5] = { 0.01f, 0.01f, 0.01f, 0.01f, 0.01f };
     int evals = 0, rc;
@@ -1320,10 +1467,12 @@ int m3dcal_twiddle(m3dcal* c, int max_sweeps, float p_out[5], float* best_error_
     if (sweeps) *sweeps = n;
     if (evaluations) *evaluations = evals;
     return M3DREG_OK;
+    });
 }
 
 // m3d_calibration_sa.cpp:280-356
 int m3dcal_anneal(m3dcal* c, unsigned int seed, float p[5], float* best_error_out, int* evaluations) {
+    return m3d_guarded((c ? c->h : nullptr), "m3dcal_anneal", [&]() -> int {
     if (!c || !p) return M3DREG_ERR_INVALID_ARG;
     srand(seed);                                                  // :289 (time(0) there)
     auto m_rand = []() { return -1.0f + 2 * ((float)rand()) / ((float)RAND_MAX); };   // :280-283
@@ -1347,6 +1496,7 @@ int m3dcal_anneal(m3dcal* c, unsigned int seed, float p[5], float* best_error_ou
     if (best_error_out) *best_error_out = best_error;
     if (evaluations) *evaluations = evals;
     return M3DREG_OK;
+    });
 }
 
 // ---- persistent map in HBM -----------------------------------------------------------
@@ -1383,6 +1533,7 @@ int map_clear_device(m3dmap* m) {
 extern "C" {
 
 int m3dmap_create(m3dreg_handle* h, float dedup_leaf, size_t capacity, m3dmap** out) {
+    return m3d_guarded(h, "m3dmap_create", [&]() -> int {
     if (!h || !out || !(dedup_leaf > 0.f) || !std::isfinite(dedup_leaf) || capacity == 0 || capacity > 0x0FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "m3dmap_create: bad argument (at most 2^28 - 1 points)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1401,20 +1552,24 @@ int m3dmap_create(m3dreg_handle* h, float dedup_leaf, size_t capacity, m3dmap** 
     if (rc) { m3dmap_destroy(m); return rc; }
     *out = m;
     return M3DREG_OK;
+    });
 }
 
 int m3dmap_destroy(m3dmap* m) {
+    return m3d_guarded((m ? m->h : nullptr), "m3dmap_destroy", [&]() -> int {
     if (!m) return M3DREG_ERR_INVALID_ARG;
     hipSetDevice(m->h->device);
     hipStreamSynchronize(m->h->stream);
     for (void* p : { (void*)m->d_pts, (void*)m->d_count, (void*)m->d_flags, (void*)m->d_keys, (void*)m->d_epoch, (void*)m->d_owner, (void*)m->d_slot_of, (void*)m->d_blocks }) if (p) hipFree(p);
     delete m;
     return M3DREG_OK;
+    });
 }
 
 int m3dmap_clear(m3dmap* m) { return m ? map_clear_device(m) : M3DREG_ERR_INVALID_ARG; }
 
 int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t* n_added) {
+    return m3d_guarded((m ? m->h : nullptr), "m3dmap_insert", [&]() -> int {
     if (!m || !scan || !T) return M3DREG_ERR_INVALID_ARG;
     m3dreg_handle* h = m->h;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1443,6 +1598,7 @@ int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t
     A.slot_of = m->d_slot_of; A.block_counts = m->d_blocks; A.out = m->d_pts; A.count = m->d_count; A.capacity = uint32_t(m->capacity); A.flags = m->d_flags;
     HIPCHK(h, hipMemsetAsync(m->d_flags, 0, sizeof(uint32_t) * 4, h->stream));
     HIPCHK(h, m3d_launch_map_insert(h->stream, A));
+    { int rcf = note_foreign_use(h, scan); if (rcf) return rcf; }
     uint32_t host[5];
     HIPCHK(h, hipMemcpyAsync(host, m->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(host + 1, m->d_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1452,21 +1608,27 @@ int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t
     if (host[1] || host[4]) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dmap_insert: map capacity exceeded (points beyond it were dropped)");
     if (host[2]) return fail(h, M3DREG_ERR_GRID_TOO_LARGE, "m3dmap_insert: points beyond +-2^20 dedup voxels were dropped");
     return M3DREG_OK;
+    });
 }
 
 int m3dmap_size(m3dmap* m, size_t* n) {
+    return m3d_guarded((m ? m->h : nullptr), "m3dmap_size", [&]() -> int {
     if (!m || !n) return M3DREG_ERR_INVALID_ARG;
     *n = m->n_host;
     return M3DREG_OK;
+    });
 }
 
 int m3dmap_as_cloud(m3dmap* m, m3dreg_cloud** out) {
+    return m3d_guarded((m ? m->h : nullptr), "m3dmap_as_cloud", [&]() -> int {
     if (!m || !out) return M3DREG_ERR_INVALID_ARG;
     if (m->n_host == 0) return fail(m->h, M3DREG_ERR_EMPTY_CLOUD, "m3dmap_as_cloud: the map is empty");
     return m3dreg_cloud_create(m->h, m->d_pts, m->n_host, 16, 0, 4, 8, 1, out);   // bucketed in place: no PCIe transfer of the map
+    });
 }
 
 int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out) {
+    return m3d_guarded((m ? m->h : nullptr), "m3dmap_download", [&]() -> int {
     if (!m || !n_out) return M3DREG_ERR_INVALID_ARG;
     *n_out = m->n_host;
     const size_t k = m->n_host < cap_points ? m->n_host : cap_points;
@@ -1475,30 +1637,36 @@ int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out) {
         HIPCHK(m->h, hipStreamSynchronize(m->h->stream));
     }
     return M3DREG_OK;
+    });
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------
 int m3dreg_profile_enable(m3dreg_handle* h, int on) {
+    return m3d_guarded(h, "m3dreg_profile_enable", [&]() -> int {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     h->profiling = on != 0;
     h->prof_every = on > 1 ? on : 1;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset) {
-    if (!h || what < 0 || what > 1) return M3DREG_ERR_INVALID_ARG;
+    return m3d_guarded(h, "m3dreg_profile_read", [&]() -> int {
+    if (!h || what < 0 || what > 3) return M3DREG_ERR_INVALID_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drain_events(h);
     if (n_launches) *n_launches = h->prof_launches[what];
     if (total_ms) *total_ms = h->prof_ms[what];
     if (reset) { h->prof_launches[what] = 0; h->prof_ms[what] = 0.0; }
     return M3DREG_OK;
+    });
 }
 
 // ---- introspection ------------------------------------------------------------------------------------
 int m3dreg_cloud_levels(const m3dreg_cloud* c) { return c ? c->n_levels : M3DREG_ERR_INVALID_ARG; }
 
 int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m3dreg_grid_info* out) {
+    return m3d_guarded(h, "m3dreg_cloud_grid_info", [&]() -> int {
     if (!h || !c || !out || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "grid_info: bad argument");
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
     const DevLevel& L = c->lv[level];
@@ -1510,10 +1678,12 @@ int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m
     }
     out->leaf = L.grid.leaf; out->inv_leaf = L.grid.inv_leaf; out->lbound = L.lbound; out->has_normals = c->has_normals ? 1 : 0;
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint32_t* keys, uint32_t* sorted_keys, int32_t* perm,
                         float* sorted_xyz, float* normals) {
+    return m3d_guarded(h, "m3dreg_cloud_export", [&]() -> int {
     if (!h || !c || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: bad argument");
     if (normals && !c->has_normals) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: cloud has no normals");
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
@@ -1537,10 +1707,12 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, const float* queries_xyz, size_t nq, float max_corr_dist,
                     int32_t* out_idx, float* out_d2) {
+    return m3d_guarded(h, "m3dreg_debug_nn", [&]() -> int {
     if (!h || !target || !queries_xyz || !out_idx || !out_d2 || level < 0 || level >= target->n_levels || nq == 0 || nq >= 0x7FFFFFFFull)
         return fail(h, M3DREG_ERR_INVALID_ARG, "debug_nn: bad argument");
     if (target->source_only) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "debug_nn: a source-only cloud has no bucket table");
@@ -1559,12 +1731,15 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
     if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_nn", e);
     if (e2 != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_nn", e2);
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target, int level, const float T[16],
                             int64_t sums[M3DREG_NSUMS], int32_t exps[6]) {
+    return m3d_guarded(h, "m3dreg_debug_accumulate", [&]() -> int {
     if (!h || !source || !target || !T || !sums || !exps || level < 0 || level >= h->params.n_levels)
         return fail(h, M3DREG_ERR_INVALID_ARG, "debug_accumulate: bad argument");
+    if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "debug_accumulate: a batch is pending on this handle (it uses the same job / state slots: call m3dreg_batch_wait first)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_batch(h, 1);
     if (rc) return rc;
@@ -1600,16 +1775,21 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     float S[6];
     m3d_fixed_exps(target->lv[level].lbound, h->params.max_corr_dist[level], exps, S);
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]) {
+    return m3d_guarded(h, "m3dreg_debug_counters", [&]() -> int {
     if (!h || !out || !h->h_states) return M3DREG_ERR_INVALID_ARG;
     out[0] = h->h_states[0].ctr[0]; out[1] = h->h_states[0].ctr[1];
     return M3DREG_OK;
+    });
 }
 
 int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_out) {
+    return m3d_guarded(h, "m3dreg_debug_trace", [&]() -> int {
     if (!h || !n_out) return M3DREG_ERR_INVALID_ARG;
+    if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "debug_trace: a batch is pending on this handle (call m3dreg_batch_wait first)");
     size_t k = h->last_trace_n < cap ? h->last_trace_n : cap;
     if (poses && k) {
         HIPCHK(h, hipSetDevice(h->device));
@@ -1619,6 +1799,137 @@ int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_ou
     }
     *n_out = h->last_trace_n;
     return M3DREG_OK;
+    });
+}
+
+int m3dreg_debug_fail_alloc(int nth) { g_fail_alloc.store(nth > 0 ? nth : 0); return M3DREG_OK; }
+int m3dreg_debug_throw(int kind) {
+    return m3d_guarded(nullptr, "m3dreg_debug_throw", [&]() -> int {
+        if (kind == 0) throw std::bad_alloc();
+        throw 42;
+    });
+}
+
+}  // extern "C"
+
+// ---- one process, several devices (SURVEY.md §8 rows b / e) ------------------------------------------------------
+struct m3dreg_multi {
+    std::vector<m3dreg_handle*> handles;   // one per entry of `devices` (a device may appear more than once: several streams on it)
+    std::vector<int> devices;
+    std::string err;
+};
+
+namespace {
+// Longest-processing-time-first with a capacity per device (what mandala_mapping_amd/sharding.py lpt_assign does for the ranks of a
+// torchrun job): heaviest pair first, onto the least loaded device that still has room; ties to the lower index.
+void lpt_assign(const std::vector<double>& cost, int n_dev, size_t capacity, std::vector<int>& dev_of) {
+    std::vector<size_t> order(cost.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::vector<double> load(size_t(n_dev), 0.0);
+    std::vector<size_t> count(size_t(n_dev), 0);
+    dev_of.assign(cost.size(), 0);
+    for (size_t i : order) {
+        int best = -1;
+        for (int d = 0; d < n_dev; d++)
+            if (count[size_t(d)] < capacity && (best < 0 || load[size_t(d)] < load[size_t(best)])) best = d;
+        dev_of[i] = best;
+        load[size_t(best)] += cost[i];
+        count[size_t(best)]++;
+    }
+}
+int mfail(m3dreg_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
+}  // namespace
+
+extern "C" {
+
+const char* m3dreg_multi_last_error(const m3dreg_multi* m) { return m ? m->err.c_str() : "null context"; }
+
+int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_devices, m3dreg_multi** out) {
+    return m3d_guarded(nullptr, "m3dreg_multi_create", [&]() -> int {
+    if (!out) return M3DREG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!params || !devices || n_devices < 1 || n_devices > 64) return M3DREG_ERR_INVALID_ARG;
+    alloc_point();
+    m3dreg_multi* m = new m3dreg_multi();
+    for (int d = 0; d < n_devices; d++) {
+        m3dreg_handle* h = nullptr;
+        const int rc = m3dreg_create(params, devices[d], nullptr, &h);
+        if (rc != M3DREG_OK) { for (m3dreg_handle* g : m->handles) m3dreg_destroy(g); delete m; return rc; }
+        m->handles.push_back(h);
+        m->devices.push_back(devices[d]);
+    }
+    *out = m;
+    return M3DREG_OK;
+    });
+}
+
+int m3dreg_multi_destroy(m3dreg_multi* m) {
+    return m3d_guarded(nullptr, "m3dreg_multi_destroy", [&]() -> int {
+    if (!m) return M3DREG_ERR_INVALID_ARG;
+    for (m3dreg_handle* h : m->handles) m3dreg_destroy(h);
+    delete m;
+    return M3DREG_OK;
+    });
+}
+
+int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_pairs, float* out_T, m3dreg_stats* stats, int32_t* device_of_pair) {
+    return m3d_guarded(nullptr, "m3dreg_multi_align", [&]() -> int {
+    if (!m || !pairs || !out_T || n_pairs == 0 || n_pairs > 65535) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: bad argument");
+    const int n_dev = int(m->handles.size());
+    alloc_point();
+    std::vector<double> cost(n_pairs);
+    for (size_t i = 0; i < n_pairs; i++) cost[i] = double(pairs[i].source.n) + double(pairs[i].target.n);
+    std::vector<int> dev_of;
+    lpt_assign(cost, n_dev, (n_pairs + size_t(n_dev) - 1) / size_t(n_dev), dev_of);
+    struct Shard { std::vector<size_t> idx; std::vector<m3dreg_cloud*> clouds; std::vector<m3dreg_pair> pr; bool enqueued = false; };
+    std::vector<Shard> sh{ static_cast<size_t>(n_dev) };
+    for (size_t i = 0; i < n_pairs; i++) sh[size_t(dev_of[i])].idx.push_back(i);
+    int rc = M3DREG_OK;
+    std::string msg;
+    // enqueue everything, device after device: nothing here waits for a device (bucketing and registration are enqueue-only)
+    for (int d = 0; d < n_dev && rc == M3DREG_OK; d++) {
+        Shard& S = sh[size_t(d)];
+        if (S.idx.empty()) continue;
+        m3dreg_handle* h = m->handles[size_t(d)];
+        std::vector<m3dreg_cloud_desc> descs(2 * S.idx.size());
+        for (size_t k = 0; k < S.idx.size(); k++) {
+            descs[2 * k] = pairs[S.idx[k]].source; descs[2 * k].source_only = 1;
+            descs[2 * k + 1] = pairs[S.idx[k]].target; descs[2 * k + 1].source_only = 0;
+        }
+        S.clouds.assign(descs.size(), nullptr);
+        rc = m3dreg_cloud_create_batch_async(h, descs.data(), descs.size(), S.clouds.data());
+        if (rc != M3DREG_OK) { msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; break; }
+        S.pr.resize(S.idx.size());
+        for (size_t k = 0; k < S.idx.size(); k++) {
+            S.pr[k].source = S.clouds[2 * k]; S.pr[k].target = S.clouds[2 * k + 1];
+            memcpy(S.pr[k].init_T, pairs[S.idx[k]].init_T, sizeof(float) * 16);
+        }
+        rc = m3dreg_align_batch_async(h, S.pr.data(), S.pr.size());
+        if (rc != M3DREG_OK) { msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; break; }
+        S.enqueued = true;
+    }
+    // wait and gather in pair order
+    std::vector<float> T; std::vector<m3dreg_stats> st;
+    for (int d = 0; d < n_dev; d++) {
+        Shard& S = sh[size_t(d)];
+        m3dreg_handle* h = m->handles[size_t(d)];
+        if (S.enqueued) {
+            T.assign(16 * S.idx.size(), 0.f); st.assign(S.idx.size(), m3dreg_stats{});
+            const int rw = m3dreg_batch_wait(h, T.data(), st.data());
+            if (rw != M3DREG_OK && rc == M3DREG_OK) { rc = rw; msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; }
+            if (rw == M3DREG_OK)
+                for (size_t k = 0; k < S.idx.size(); k++) {
+                    memcpy(out_T + 16 * S.idx[k], T.data() + 16 * k, sizeof(float) * 16);
+                    if (stats) stats[S.idx[k]] = st[k];
+                    if (device_of_pair) device_of_pair[S.idx[k]] = m->devices[size_t(d)];
+                }
+        } else if (!S.idx.empty()) m3dreg_synchronize(h);   // (host payloads of a half-enqueued shard must be consumed before we return)
+        for (m3dreg_cloud* c : S.clouds) if (c) m3dreg_cloud_destroy(h, c);
+    }
+    if (rc != M3DREG_OK) return mfail(m, rc, msg);
+    return M3DREG_OK;
+    });
 }
 
 }  // extern "C"

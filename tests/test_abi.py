@@ -79,3 +79,12 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "libm3d_oracle" not in txt and "import orc" not in txt and "from oracle" not in txt, f
+
+
+def test_no_exception_crosses_the_boundary():
+    """Every exported function runs inside the guard of m3dreg_api.cpp: a std::bad_alloc raised underneath comes back as
+    M3DREG_ERR_OUT_OF_MEMORY, anything else as M3DREG_ERR_HIP — never as a C++ exception through ctypes (no device needed)."""
+    L = binding.lib()
+    assert L.m3dreg_debug_throw(0) == abi.ERR_OUT_OF_MEMORY
+    assert L.m3dreg_debug_throw(1) == abi.ERR_HIP
+    assert L.m3dreg_debug_fail_alloc(0) == 0

@@ -1,0 +1,159 @@
+"""GPU tests of the boundary itself (SURVEY.md §8 rows b / e): the one-process multi-device entry, the exception guard with a real
+handle, cloud lifetime across handles, per-stage timers, and the torch.distributed host path with the HIP kernels underneath."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from mandala_mapping_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(n, az=500):
+    out = []
+    for k in range(n):
+        src, tgt, Tgt = synth.hdl32_pair(az + 37 * k, 400 + k, 500 + k, dx=0.2 + 0.02 * k, dy=0.1, dyaw_deg=1.5 + 0.2 * k)
+        out.append((src, tgt, synth.perturb(Tgt, np.random.default_rng(k), 0.5, 0.05)))
+    return out
+
+
+def test_multi_context_equals_single_handle_batch(reg, orc):
+    """m3dreg_multi_align over devices {0, 0} (two handles, two streams, LPT shards) returns exactly what m3dreg_align_batch
+    returns on one handle, which is exactly what the oracle returns."""
+    p = abi.Params.make(leaf=0.2, iterations=8, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    pairs = _pairs(5)
+    M = reg.MultiRegistrar(p, devices=(0, 0))
+    Tm, stm, dev = M.align(pairs)
+    R = reg.Registrar(p)
+    cl = R.clouds([a for s, t, _ in pairs for a in (s, t)], source_only=[i % 2 == 0 for i in range(2 * len(pairs))])
+    Tb, stb = R.align_batch([(cl[2 * i], cl[2 * i + 1], pairs[i][2]) for i in range(len(pairs))])
+    assert np.array_equal(Tm, Tb)
+    for a, b in zip(stm, stb):
+        assert (a.status, a.iterations, a.n_corr, a.rms) == (b.status, b.iterations, b.n_corr, b.rms)
+    assert list(dev) == [0] * len(pairs)
+    for i in (0, 3):
+        To, sto, _ = orc.align(p, orc.Cloud(p, pairs[i][0]), orc.Cloud(p, pairs[i][1]), pairs[i][2])
+        assert np.array_equal(Tm[i], To)
+    # twice in a row on the same context (pooled blocks, counters back at zero), and a one-pair batch
+    Tm2, _, _ = M.align(pairs)
+    assert np.array_equal(Tm2, Tm)
+    T1, _, _ = M.align(pairs[:1])
+    assert np.array_equal(T1[0], Tm[0])
+    M.close()
+
+
+def test_allocation_failure_is_an_error_code_not_an_exception(reg):
+    """std::bad_alloc inside m3dreg_cloud_create_batch comes back as M3DREG_ERR_OUT_OF_MEMORY; the handle stays usable."""
+    p = abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    src, tgt, _ = synth.config1(2000)
+    L = reg.lib()
+    T_ok, _ = R.align(R.cloud(src), R.cloud(tgt))
+    for nth in (1, 2, 3):
+        L.m3dreg_debug_fail_alloc(nth)
+        try:
+            with pytest.raises(abi.M3dregError) as e:
+                R.clouds([src, tgt, src])
+            assert e.value.code == abi.ERR_OUT_OF_MEMORY
+        finally:
+            L.m3dreg_debug_fail_alloc(0)
+    T2, _ = R.align(R.cloud(src), R.cloud(tgt))
+    assert np.array_equal(T2, T_ok)
+
+
+def test_cloud_freed_right_after_a_foreign_handle_enqueued_its_use(reg, orc):
+    """A's clouds are registered on B's stream (enqueue only), freed at once and A buckets new clouds into the recycled blocks:
+    A's stream must wait for B's reads (last-use event), or B would register against half-overwritten clouds."""
+    p = abi.Params.make(leaf=0.2, iterations=10, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    A, B = reg.Registrar(p), reg.Registrar(p)
+    ref = {}
+    for seed in range(3):
+        src, tgt, _ = synth.hdl32_pair(700, 30 + seed, 40 + seed, dx=0.2, dy=0.1, dyaw_deg=2.0)
+        ref[seed] = (src, tgt, orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt))[0])
+    for rep in range(3):
+        for seed in range(3):
+            src, tgt, To = ref[seed]
+            cs, ct = A.clouds([src, tgt], wait=False)
+            arr = B._pairs([(cs, ct, None)])
+            B.align_batch_async(arr, 1)
+            cs.free(); ct.free()                                   # blocks go back to A's pool while B's batch is in flight
+            junk = A.clouds([ref[(seed + 1) % 3][1], ref[(seed + 2) % 3][0]], wait=False)   # same sizes: the pool hands the blocks out again
+            T, st = B.batch_wait(1)
+            assert np.array_equal(T[0], To), (rep, seed)
+            A.synchronize()                                        # (junk's host payloads must outlive their copies)
+            del junk
+    # destroying through the other handle returns the block to its owner all the same; the owner may close first
+    cs, ct = A.clouds([ref[0][0], ref[0][1]])
+    reg.lib().m3dreg_cloud_destroy(B._h, cs._p); cs._p = None
+    A.close()
+    g = abi.GridInfo()
+    assert reg.lib().m3dreg_cloud_grid_info(B._h, ct._p, 0, C.byref(g)) == 0 and g.n_valid > 0   # A lives on until its last cloud is gone
+    assert reg.lib().m3dreg_cloud_destroy(B._h, ct._p) == 0; ct._p = None
+
+
+def test_stage_timers(reg):
+    p = abi.Params.make(leaf=0.2, iterations=6, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    R.profile_enable(True, every=1)
+    src, tgt, _ = synth.hdl32_pair(700, 1, 2)
+    cs, ct = R.clouds([src, tgt])
+    R.align(cs, ct)
+    n = {}; ms = {}
+    for what in range(4):
+        n[what], ms[what] = R.profile_read(what=what, reset=True)
+    assert n[0] == 6 and n[1] == 6 and n[3] == 6 and n[2] == 1
+    assert all(ms[w] > 0 for w in range(4))
+    assert abs((ms[1] + ms[3]) - ms[0]) < 0.05 * ms[0] + 0.05     # correspondence step + reduce/solve = iteration
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mandala_mapping_amd import binding, sharding
+    p = abi.Params.make(leaf=0.2, iterations=8, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    pairs = _pairs(5)
+    R = binding.Registrar(p, device=0)          # every rank shares GPU 0 (one-GPU box): the HIP path under a process group
+
+    def local(idx):
+        cl = R.clouds([a for i in idx for a in (pairs[i][0], pairs[i][1])], source_only=[j % 2 == 0 for j in range(2 * len(idx))])
+        T, st = R.align_batch([(cl[2 * j], cl[2 * j + 1], pairs[i][2]) for j, i in enumerate(idx)])
+        return T, [s.status for s in st]
+
+    costs = [len(s) + len(t) for s, t, _ in pairs]
+    T, st = sharding.register_sharded(pairs, costs, local, dist)
+    q.put((rank, T, st, sharding.lpt_assign(costs, world)[rank]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hip_path_under_a_two_rank_process_group(reg, orc):
+    """sharding.register_sharded with Registrar.align_batch per rank, two ranks over gloo sharing the one GPU: the N > 1 host path
+    with the real kernels underneath (the 8-GPU run differs only in the backend name and the device index)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    (_, T0, st0, m0), (_, T1, st1, m1) = res
+    assert np.array_equal(T0, T1) and sorted(m0 + m1) == list(range(5)) and m0 and m1
+    p = abi.Params.make(leaf=0.2, iterations=8, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    pairs = _pairs(5)
+    for i in (1, 4):
+        To, _, _ = orc.align(p, orc.Cloud(p, pairs[i][0]), orc.Cloud(p, pairs[i][1]), pairs[i][2])
+        assert np.array_equal(T0[i], To)
