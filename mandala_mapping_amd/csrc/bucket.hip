@@ -117,7 +117,13 @@ __global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int g
         M3dBuild& B = B0[gi];
         M3dLevelMeta* M = reinterpret_cast<M3dLevelMeta*>(B.dyn);
         M->err = err;
-        if (err) { B.n = 0; B.ntiles = 0; B.sort_passes = 0; B.grid.n_valid = 0; M->g.n_valid = 0; }
+        if (err) {   // a cloud in error: every word of the meta is still defined (k_patch_jobs and fetch_meta copy it as it stands)
+            B.n = 0; B.ntiles = 0; B.sort_passes = 0; B.grid.n_valid = 0;
+            M3dGrid z; memset(&z, 0, sizeof(z)); z.leaf = B.grid.leaf;
+            M->g = z; M->lbound = 0.f;
+            for (int a = 0; a < 3; a++) { M->mx[a] = 0.f; M->bits[a] = 0; }
+            for (int k = 0; k < 8; k++) M->dyn[k] = 0u;
+        }
     }
 }
 

@@ -1306,13 +1306,13 @@ __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ j
                                                     unsigned long long* __restrict__ progress) {
     if (!progress) return;   // nobody listens (fixed iteration counts): skip the device-scope atomics
     M3dPairState* g0 = jobs[0].st;
-    if (still_active) {
-        __hip_atomic_fetch_add(&g0->gsync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const unsigned int t = __hip_atomic_fetch_add(&g0->gsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t != (unsigned int)n_pairs - 1u) return;
-    const unsigned int active = __hip_atomic_exchange(&g0->gsync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE read-modify-write per pair carries both the arrival (low half) and "still active" (high half): the last arriver reads
+    // the number of active pairs out of the value its own add returned — no second counter whose increment could land late
+    // (n_pairs <= 65535).
+    const unsigned int add = still_active ? 0x10001u : 1u;
+    const unsigned int t = __hip_atomic_fetch_add(&g0->gsync[0], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+    if ((t & 0xFFFFu) != (unsigned int)n_pairs) return;
+    const unsigned int active = t >> 16;
     __hip_atomic_store(&g0->gsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (progress) {
         __threadfence_system();

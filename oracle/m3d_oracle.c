@@ -583,14 +583,17 @@ void orc_cloud_destroy(orc_cloud* c) {
     free(c->nrm_in); free(c->xyz); free(c);
 }
 
-int orc_cloud_create(const orc_params* p, const void* data, size_t n, size_t step, size_t ox, size_t oy, size_t oz, orc_cloud** out) {
+/* source_only: what m3dreg_cloud_desc.source_only asks of the HIP side — the cloud is sorted along every level's curve (its points
+ * are the queries of a registration, streamed in that order) but gets no normal-estimation grid and no normals; it cannot be a
+ * target of a point-to-plane registration. bench.py's cpu_baseline uses it so that both legs do the same work. */
+static int cloud_create(const orc_params* p, const void* data, size_t n, size_t step, size_t ox, size_t oy, size_t oz, int source_only, orc_cloud** out) {
     if (!p || !data || !out || n == 0 || n > 0x7FFFFFFFu || p->n_levels < 1 || p->n_levels > ORC_MAX_LEVELS) return ORC_ERR_INVALID_ARG;
     if (ox + 4 > step || oy + 4 > step || oz + 4 > step) return ORC_ERR_INVALID_ARG;
     orc_cloud* c = (orc_cloud*)calloc(1, sizeof(orc_cloud));
     c->n = (int32_t)n; c->n_levels = p->n_levels;
     c->xyz = (float*)malloc(sizeof(float) * 3 * n);
     decode_xyz((const uint8_t*)data, n, step, ox, oy, oz, c->xyz);
-    if (p->metric == ORC_PT2PLANE) {
+    if (p->metric == ORC_PT2PLANE && !source_only) {
         int rc = level_build(&c->ng, c->xyz, c->n, p->normal_leaf);
         if (rc != ORC_OK) { orc_cloud_destroy(c); return rc; }
         c->nrm_in = (float*)calloc(3 * n, sizeof(float));
@@ -599,7 +602,7 @@ int orc_cloud_create(const orc_params* p, const void* data, size_t n, size_t ste
     for (int l = 0; l < p->n_levels; l++) {
         int rc = level_build(&c->lv[l], c->xyz, c->n, p->leaf[l]);
         if (rc != ORC_OK) { orc_cloud_destroy(c); return rc; }
-        if (p->metric == ORC_PT2PLANE) { /* per-level copy of the normals in that level's sorted order */
+        if (p->metric == ORC_PT2PLANE && !source_only) { /* per-level copy of the normals in that level's sorted order */
             orc_level* L = &c->lv[l];
             L->nrm = (float*)malloc(sizeof(float) * 3 * n);
             for (size_t j = 0; j < n; j++) memcpy(&L->nrm[3 * j], &c->nrm_in[3 * (size_t)L->perm[j]], 12);
@@ -608,6 +611,12 @@ int orc_cloud_create(const orc_params* p, const void* data, size_t n, size_t ste
     }
     *out = c;
     return ORC_OK;
+}
+int orc_cloud_create(const orc_params* p, const void* data, size_t n, size_t step, size_t ox, size_t oy, size_t oz, orc_cloud** out) {
+    return cloud_create(p, data, n, step, ox, oy, oz, 0, out);
+}
+int orc_cloud_create_source(const orc_params* p, const void* data, size_t n, size_t step, size_t ox, size_t oy, size_t oz, orc_cloud** out) {
+    return cloud_create(p, data, n, step, ox, oy, oz, 1, out);
 }
 
 int orc_cloud_grid_info(const orc_cloud* c, int level, orc_grid_info* out) {

@@ -36,5 +36,13 @@ for k, v in out.items():
         v["hbm_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0.0)
     if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
         v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+# per Gauss-Newton ITERATION (k_nn_tiles is launched in the first iterations of a level only, k_nn_iter in every one): what bench.py's
+# roofline.traffic sums over the two kernels of the correspondence step
+it = out.get("k_nn_iter", {}).get("launches_FETCH_SIZE", 0)
+for k in ("k_nn_iter", "k_nn_tiles"):
+    v = out.get(k, {})
+    if "hbm_bytes_per_launch" in v and it:
+        v["hbm_bytes_per_iteration"] = v["hbm_bytes_per_launch"] * v.get("launches_FETCH_SIZE", 0) / it
+        v["hbm_bytes_per_iteration_uncorrected"] = (v.get("FETCH_SIZE", 0.0) * 1024.0 + v.get("hbm_write_bytes_per_launch", 0.0)) * v.get("launches_FETCH_SIZE", 0) / it
 json.dump(out, open(os.path.join("profiles", "pmc_summary.json"), "w"), indent=1, sort_keys=True)
-print(json.dumps({k: {c: out[k][c] for c in out[k] if c in ("hbm_bytes_per_launch", "l2_hit_rate", "FETCH_SIZE", "WRITE_SIZE")} for k in out}, indent=1))
+print(json.dumps({k: {c: out[k][c] for c in out[k] if c in ("hbm_bytes_per_launch", "hbm_bytes_per_iteration", "l2_hit_rate", "FETCH_SIZE", "WRITE_SIZE")} for k in out}, indent=1))
