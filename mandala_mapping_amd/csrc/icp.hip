@@ -994,19 +994,27 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         __syncthreads();
         if (tid < 64 && s_tk[tid] >= 0) {
             const int t0 = s_tk[tid];
-            const M3dTileHdr H = thdr[t0];
-            uint32_t base = 0xFFFFFFFFu;
-            if (H.flags == 0u) {
-                const uint32_t cnt = s_tn[tid];
-                base = atomicAdd(&tcnt[t0], cnt);
+            // the reservation does not wait for the tile's header (both round trips are in flight together): a flagged tile's records
+            // are never looked at (no work item names them), its queries are walked below
+            const M3D_GLOBAL uint32_t* hw = (const M3D_GLOBAL uint32_t*)(const void M3D_GLOBAL*)(thdr + t0);
+            const uint32_t hflags = hw[2], hmeta0 = hw[3];
+            const uint32_t cnt = s_tn[tid];
+            uint32_t base = atomicAdd(&tcnt[t0], cnt);
+            if (hflags != 0u) base = 0xFFFFFFFFu;
+            else {
                 // work items of k_nn_tiles: one per chunk of the tile's records (512, or 64 for a tile with crowded voxels, whose
                 // queries cost ten times as much: they are spread over more workgroups); the append that covers a chunk's first
-                // record publishes it
-                const uint32_t cs = (H.meta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
+                // record publishes it — into one of M3D_TILE_LISTS lists (each with its counter on its own 128-B line): 2000
+                // returning atomics on ONE word were 8 us of the first iteration's 30. (Lists chosen per workgroup, or no lists at
+                // all — k_nn_tiles testing every (tile, chunk) against the counters itself — made k_nn_iter as fast and k_nn_tiles
+                // 12-25 us slower: whatever clumps the items of a crowded tile, or hands a workgroup 3 items and its neighbour none,
+                // shows up as the tail of that kernel.)
+                const uint32_t cs = (hmeta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
                 const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
                 for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
-                    const uint32_t w = atomicAdd(A.wcount, 1u);
-                    if (w < (uint32_t)A.wcap) A.witems[w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
+                    const uint32_t wl = ((uint32_t)t0 + c + (uint32_t)pair) & (uint32_t)(M3D_TILE_LISTS - 1);   // (per item, not per workgroup: a crowded tile's chunks spread over all lists)
+                    const uint32_t w = atomicAdd(A.wcount + 32u * wl, 1u);
+                    if (w < (uint32_t)A.wcap) A.witems[(size_t)wl * (size_t)A.wcap + w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
                 }
             }
             s_tb[tid] = base;
@@ -1086,18 +1094,21 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 // Workgroups are dealt over the XCDs tile by tile, NOT pair by pair like the other kernels of the iteration: nothing here is read
 // twice (records, images and points stream through once), and a pair with crowded tiles then loads all XCDs instead of one.
 #define M3D_TILE_THREADS 512
-#define M3D_TILE_GRID 2048     // workgroups of k_nn_tiles: they stride over the work items k_nn_iter published (an empty list costs one word read each)
+#define M3D_TILE_GRID 2048     // workgroups of k_nn_tiles: 256 per list, they stride over the work items k_nn_iter published there (an empty list costs one word read each)
+static_assert(M3D_TILE_GRID % M3D_TILE_LISTS == 0, "every list is served by the same number of workgroups");
 __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int first_of_level, M3dNnArgs A) {
     __shared__ m3d_f32x4 s_pts[M3D_TILE_PCAP];
     __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
     __shared__ int s_kd[32];
-    const unsigned int n_items = min(*A.wcount, (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counter)
+    const unsigned int wl = blockIdx.x & (unsigned int)(M3D_TILE_LISTS - 1);   // this workgroup's list of work items
+    const unsigned int n_items = min(A.wcount[32u * wl], (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counters)
+    const uint2* witems = A.witems + (size_t)wl * (size_t)A.wcap;
     const int tid = (int)threadIdx.x;
     const m3d_lu2 vs = (m3d_lu2)s_vs;
     const m3d_lf4 sp = (m3d_lf4)s_pts;
     bool first_item = true;
-    for (unsigned int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint2 item = A.witems[it];
+    for (unsigned int it = blockIdx.x / (unsigned int)M3D_TILE_LISTS; it < n_items; it += gridDim.x / (unsigned int)M3D_TILE_LISTS) {
+        const uint2 item = witems[it];
         const int pair = (int)item.x, blk = (int)(item.y & 0xFFFFFu);
         const unsigned int chunk = item.y >> 20;
         const M3dJob& J = jobs[pair];
@@ -1396,7 +1407,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     m3d_map_block(n_pairs, bpp, pair, blk, rot);
     if (gw_cnt && blk == 0) {   // the record counters of k_nn_tiles: each is read by several of its workgroups, so they are zeroed one launch later
         for (int i = (int)threadIdx.x; i < gw_n; i += ICP_THREADS) gw_cnt[(size_t)pair * gw_stride + i] = 0u;
-        if (pair == 0 && threadIdx.x == 0) *wcount = 0u;
+        if (pair == 0 && threadIdx.x < M3D_TILE_LISTS) wcount[32u * threadIdx.x] = 0u;
     }
     const M3dJob& J = jobs[pair];
     M3dPairState* st = states ? states + pair : J.st;   // == J.st, addressed from the kernel argument when the caller has it

@@ -85,6 +85,7 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 #define M3D_TILE_OVERSIZE 1u
 #define M3D_OCC_BITS 23         // the occupancy bitmap covers grids of up to 2^23 bucket positions (1 MiB per level)
 #define M3D_TILE_MAXIMG 32
+#define M3D_TILE_LISTS 8      // work-item lists of k_nn_tiles (one counter per list, each on its own 128-B line; list l is served by the workgroups with blockIdx & 7 == l)
 struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; meta0 = staged points of image t | crowded << 31
 struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points (k_nn_tiles then builds chunk boxes)
 static_assert(sizeof(M3dTileHdr) == 16 && sizeof(M3dTileImgMeta) == 8, "tile image layout");

@@ -121,7 +121,7 @@ struct m3dreg_handle {
     uint64_t launched_iters = 0, skipped_iters = 0;
     int certify = 1;
     int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
-    int lane_min = 48;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency)
+    int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
     int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
@@ -138,7 +138,7 @@ struct m3dreg_handle {
     size_t rec_cap = 0, rec_stride = 0;
     unsigned int* d_tcnt = nullptr;    // records per tile
     size_t tcnt_cap = 0;
-    uint2* d_witems = nullptr;         // work items of k_nn_tiles (the first 256 bytes: their counter)
+    uint2* d_witems = nullptr;         // work items of k_nn_tiles: M3D_TILE_LISTS counters (128 B apart), then the lists (witems_cap items each)
     size_t witems_cap = 0;
     int ntile_max = 0, cnt_stride = 0;
     // measurement: event pairs around the dominant kernel
@@ -615,9 +615,11 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (h->d_witems) hipFree(h->d_witems);
             h->d_witems = nullptr; h->witems_cap = 0;
-            HIPCHK(h, hipMalloc((void**)&h->d_witems, sizeof(uint2) * (wcap + wcap / 4) + 256));
+            // M3D_TILE_LISTS lists, each able to hold every item (which workgroups of k_nn_iter publish is data dependent); the
+            // first 128 * M3D_TILE_LISTS bytes hold the lists' counters, one per 128-B line
+            HIPCHK(h, hipMalloc((void**)&h->d_witems, sizeof(uint2) * (wcap + wcap / 4) * M3D_TILE_LISTS + 128 * M3D_TILE_LISTS));
             h->witems_cap = wcap + wcap / 4;
-            HIPCHK(h, hipMemsetAsync(h->d_witems, 0, 256, h->stream));   // the first 256 bytes hold the item counter
+            HIPCHK(h, hipMemsetAsync(h->d_witems, 0, 128 * M3D_TILE_LISTS, h->stream));
         }
         h->ntile_max = int(ntile); h->rec_stride = rec_stride; h->cnt_stride = int(cnt_stride);
     }
@@ -635,7 +637,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.rot = h->xcd_rot;
     w.tiles = h->tiles; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
-    w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 32 : nullptr; w.wcap = int(h->witems_cap);
+    w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
     return w;
 }
 
