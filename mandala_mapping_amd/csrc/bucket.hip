@@ -159,7 +159,10 @@ __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { retu
 // of its voxel heads (first sorted position of every occupied voxel) there
 __device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return (B.sort_passes & 1) ? B.ka : B.kb; }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass) {
+// (fused = the batch's clouds are small enough — at most RS_FUSED_TILES tiles — for every scatter workgroup to scan the counters it
+// needs itself: no k_rs_scan launch, counters stored [tile][digit] so that those reads coalesce)
+#define RS_FUSED_TILES 128
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused) {
     const M3dBuild& B = builds[blockIdx.y];
     if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restri
         if (i < n) atomicAdd(&h[(kin[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    B.hist[threadIdx.x * B.ntiles + blockIdx.x] = h[threadIdx.x];
+    if (fused) B.hist[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    else B.hist[threadIdx.x * B.ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // one workgroup per build: exclusive scan of its 256 * ntiles counters
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_rs_scan(const M3dBuild* __restrict__ b
     for (int i = b; i < e; i++) { uint32_t v = hist[i]; hist[i] = run; run += v; }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused) {
     const M3dBuild& B = builds[blockIdx.y];
     if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
@@ -211,8 +215,32 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
     const uint32_t* scanned = B.hist;
     __shared__ uint32_t cnt[RS_ROUNDS * RS_WAVES][256];   // 32 KiB: per (round, wave) digit counts
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t goff;   // where this tile's keys of digit t go: after all keys of smaller digits and this digit's keys of the tiles before
+    __shared__ uint32_t wsum[RS_WAVES];
+    uint32_t total = 0, inc = 0;
+    if (fused) {
+        // the scan a separate single-workgroup launch did (10 us per pass, launch gap included), redone by every workgroup for its own
+        // tile: digit t's counters of all tiles (coalesced, eight independent loads per trip), then a scan of the 256 digit totals
+        // (shuffles inside a wave, the four wave sums through LDS at the barrier below)
+        uint32_t before = 0;
+        int j = 0;
+        for (; j + 8 <= ntiles; j += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = scanned[(j + k) * 256 + t];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { total += v[k]; before += (j + k < (int)blockIdx.x) ? v[k] : 0u; }
+        }
+        for (; j < ntiles; j++) { const uint32_t v = scanned[j * 256 + t]; total += v; before += (j < (int)blockIdx.x) ? v : 0u; }
+        inc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        goff = before;
+    } else goff = scanned[t * ntiles + blockIdx.x];
     for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
     __syncthreads();
+    if (fused) { for (int w = 0; w < wave; w++) goff += wsum[w]; goff += inc - total; }
     const int base = blockIdx.x * RS_TILE;
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rank[RS_ROUNDS];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -236,7 +264,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
     }
     __syncthreads();
     {   // thread t owns digit t: exclusive scan over the (round, wave) slots, seeded with the global offset
-        uint32_t run = scanned[t * ntiles + blockIdx.x];
+        uint32_t run = goff;
         for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) { uint32_t v = cnt[s][t]; cnt[s][t] = run; run += v; }
     }
     __syncthreads();
@@ -805,6 +833,10 @@ __device__ __forceinline__ double sym3_maxabs(const double m[6]) {
     for (int i = 0; i < 6; i++) { double v = fabs(m[i]); if (v > a) a = v; }
     return a;
 }
+__device__ __forceinline__ double pow2_recip(double x) {   // spec §Normals v2: 2^-e, e = binary exponent of x (positive, normal): an exact scale factor
+    const unsigned long long b = (unsigned long long)(2046u - (unsigned)((((unsigned long long)__double_as_longlong(x)) >> 52) & 0x7FFull)) << 52;
+    return __longlong_as_double((long long)b);
+}
 __device__ __forceinline__ double det_rsqrt(double x) {   // spec: bit-trick seed + 5 Newton steps, no sqrt
     unsigned long long b = (unsigned long long)__double_as_longlong(x);
     b = 0x5FE6EB50C7B537A9ull - (b >> 1);
@@ -956,20 +988,25 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
                         (double)q3 * inv - m1 * m1, (double)q4 * inv - m1 * m2, (double)q5 * inv - m2 * m2 };
         const double cm = sym3_maxabs(c);
         if (!(cm > 0.0)) break;
+        const double sc = pow2_recip(cm);
 #pragma unroll
-        for (int i = 0; i < 6; i++) c[i] = c[i] / cm;
+        for (int i = 0; i < 6; i++) c[i] = c[i] * sc;
         const double a[6] = { c[3] * c[5] - c[4] * c[4], c[2] * c[4] - c[1] * c[5], c[1] * c[4] - c[2] * c[3],
                               c[0] * c[5] - c[2] * c[2], c[1] * c[2] - c[0] * c[4], c[0] * c[3] - c[1] * c[1] };
         const double am = sym3_maxabs(a);
         if (!(am > 1e-12)) break;
         double p[6], t2[6];
+        {
+            const double sa = pow2_recip(am);
 #pragma unroll
-        for (int i = 0; i < 6; i++) p[i] = a[i] / am;
+            for (int i = 0; i < 6; i++) p[i] = a[i] * sa;
+        }
         for (int it = 0; it < 5; it++) {
             sym3_square(p, t2);
             const double tm = sym3_maxabs(t2);
+            const double st = pow2_recip(tm);
 #pragma unroll
-            for (int i = 0; i < 6; i++) p[i] = t2[i] / tm;
+            for (int i = 0; i < 6; i++) p[i] = t2[i] * st;
         }
         double v0, v1, v2;
         if (p[0] >= p[3] && p[0] >= p[5]) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
@@ -988,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
         const double mth = l3 / (double)plane_ratio;
         if (!((mth <= 0.5 * sm) && ((mth * mth - sm * mth) + pr >= 0.0))) break;
         const double spread_q = (double)min_spread * 65536.0;
-        const double mw = (spread_q * spread_q) / cm;
+        const double mw = (spread_q * spread_q) * sc;   // the threshold in the units c was scaled to
         if (!((mw <= 0.5 * sm) && ((mw * mw - sm * mw) + pr >= 0.0))) break;
         int im = 0;
         double vm = fabs(v0);
@@ -1065,11 +1102,14 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     hipLaunchKernelGGL(k_voxel_keys, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_voxel_keys");
     for (int pass = 0; pass < max_passes; pass++) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+        const int fused = ntiles <= RS_FUSED_TILES ? 1 : 0;   // (ntiles = the batch's largest cloud)
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused);
         M3D_DBG(s, "k_rs_hist");
-        hipLaunchKernelGGL(k_rs_scan, dim3(n_builds), dim3(1024), 0, s, d_builds, pass);
-        M3D_DBG(s, "k_rs_scan");
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass);
+        if (!fused) {
+            hipLaunchKernelGGL(k_rs_scan, dim3(n_builds), dim3(1024), 0, s, d_builds, pass);
+            M3D_DBG(s, "k_rs_scan");
+        }
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused);
         M3D_DBG(s, "k_rs_scatter");
     }
     HIP_TRY(hipGetLastError());
