@@ -105,9 +105,16 @@ def test_hip_aggregator_laserscan_path(reg, orc):
     assert sa["angle"] == so["angle"] and sa["ready"] == so["ready"] and sa["progress"] == so["progress"]
     pa, po = a.points(), o.points()
     assert abs(len(pa) - len(po)) <= 2                                       # a point within 1 ulp of a box face may flip
-    if len(pa) == len(po):
-        # device cosf/sinf vs glibc: <= 2 ulp of 1.0 on the unit vector, times ranges of up to 25 m
-        assert np.abs(pa - po).max() <= 4 * 1.2e-7 * 25.0 * 1.5
+    # device cosf/sinf vs glibc: <= 2 ulp of 1.0 on the unit vector, times ranges of up to 25 m — for EVERY point, whatever the counts:
+    # each point of either set has its partner in the other one (a flipped point, at most two of them, has none)
+    from scipy.spatial import cKDTree
+    tol = 4 * 1.2e-7 * 25.0 * 1.5
+    da, _ = cKDTree(po[:, :3].astype(np.float64)).query(pa[:, :3].astype(np.float64))
+    db, _ = cKDTree(pa[:, :3].astype(np.float64)).query(po[:, :3].astype(np.float64))
+    assert (da > tol).sum() <= 2 and (db > tol).sum() <= 2, ((da > tol).sum(), (db > tol).sum(), da.max(), db.max())
+    assert len(pa) > 15000
+    if len(pa) == len(po):                                                   # same points kept: then also in the same order
+        assert np.abs(pa - po).max() <= tol
 
 
 @pytest.mark.gpu

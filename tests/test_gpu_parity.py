@@ -34,6 +34,20 @@ def _check_bucketing(reg_cloud, orc_cloud, levels):
             assert np.array_equal(e["normals"][:nv].view(np.uint32), eo["normals"][:nv].view(np.uint32))
 
 
+def test_large_cloud_takes_the_separate_scan_of_the_radix_sort(reg, orc):
+    """More than 128 sort tiles (262 144 points): the counter scan is its own launch again (bucket.hip: RS_FUSED_TILES); a batch that
+    mixes such a cloud with a small one takes that path for both. Bucketing and normals bit-exact against the oracle."""
+    rng = np.random.default_rng(77)
+    big = np.concatenate([synth.planes_cloud(280000, 78, sigma=0.02, size=40.0), rng.uniform(-5, 45, (20000, 3)).astype(np.float32)])
+    small = synth.planes_cloud(5000, 79, sigma=0.01, size=8.0)
+    p = _params(leaf=0.25, iterations=2, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    cb, cs = R.clouds([big, small])
+    _check_bucketing(cb, orc.Cloud(p, big), 1)
+    _check_bucketing(cs, orc.Cloud(p, small), 1)
+    _check_bucketing(R.cloud(small), orc.Cloud(p, small), 1)   # (alone: the fused path)
+
+
 @pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
 def test_config1_every_stage_bit_exact(reg, orc, metric):
     src, tgt, Tgt = synth.config1()
