@@ -1221,21 +1221,23 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
     double dmax = 0.0;
     for (int k = 0; k < 6; k++) if (A[k][k] > dmax) dmax = A[k][k];
     const double tol = pivot_rel_tol * dmax;
-    double Lm[6][6], D[6];
+    double Lm[6][6], D[6], Dinv[6];   // spec v2: ONE division per pivot (its reciprocal), every other quotient is a product with it
     for (int j = 0; j < 6; j++) {
         double d = A[j][j];
         for (int k = 0; k < j; k++) d = d - Lm[j][k] * Lm[j][k] * D[k];
         if (!(d > tol)) return 3;
         D[j] = d;
+        const double inv_d = 1.0 / d;
+        Dinv[j] = inv_d;
         for (int i = j + 1; i < 6; i++) {
             double v = A[i][j];
             for (int k = 0; k < j; k++) v = v - Lm[i][k] * Lm[j][k] * D[k];
-            Lm[i][j] = v / d;
+            Lm[i][j] = v * inv_d;
         }
     }
     double y[6], x[6];
     for (int i = 0; i < 6; i++) { double v = b[i]; for (int k = 0; k < i; k++) v = v - Lm[i][k] * y[k]; y[i] = v; }
-    for (int i = 0; i < 6; i++) y[i] = y[i] / D[i];
+    for (int i = 0; i < 6; i++) y[i] = y[i] * Dinv[i];
     for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v = v - Lm[k][i] * x[k]; x[i] = v; }
     const double w0 = x[0], w1 = x[1], w2 = x[2], v0 = x[3], v1 = x[4], v2 = x[5];
     const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
@@ -1243,12 +1245,15 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
     th2_out = th2; tr2_out = tr2;
     if (!(th2 <= 4.0) || !(tr2 < 1e300)) return 4;
     double sa = 1.0, sb = 1.0, sc = 1.0;
+    // spec v2: the constant divisors are multiplied in as their (correctly rounded) reciprocals — 59 double divisions per solve were
+    // 4 of the 5 us this step takes on one lane. (Unrolled: the reciprocals fold to constants.)
+#pragma unroll
     for (int k = 12; k >= 1; k--) {
-        sa = 1.0 - th2 * sa / (double)((2 * k) * (2 * k + 1));
-        sb = 1.0 - th2 * sb / (double)((2 * k + 1) * (2 * k + 2));
-        sc = 1.0 - th2 * sc / (double)((2 * k + 2) * (2 * k + 3));
+        sa = 1.0 - th2 * sa * (1.0 / (double)((2 * k) * (2 * k + 1)));
+        sb = 1.0 - th2 * sb * (1.0 / (double)((2 * k + 1) * (2 * k + 2)));
+        sc = 1.0 - th2 * sc * (1.0 / (double)((2 * k + 2) * (2 * k + 3)));
     }
-    const double Ac = sa, Bc = sb / 2.0, Cc = sc / 6.0;
+    const double Ac = sa, Bc = sb * 0.5, Cc = sc * (1.0 / 6.0);
     const double W[9] = { 0, -w2, w1, w2, 0, -w0, -w1, w0, 0 };
     const double W2[9] = { -(w1 * w1 + w2 * w2), w0 * w1, w0 * w2, w0 * w1, -(w0 * w0 + w2 * w2), w1 * w2, w0 * w2, w1 * w2, -(w0 * w0 + w1 * w1) };
     double Re[9], Ve[9];
@@ -1271,7 +1276,7 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
 }
 
 // One thread per pair: consume the sums of the iteration that just ran, update the pose, decide.
-__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr) {
+__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr, const double* T_pre = nullptr) {
     M3dPairState* st = J.st;
     if (st->done || (!first_of_level && st->level_done)) return;
     long long sums[M3D_NSUMS];
@@ -1283,7 +1288,7 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
     int exps[6];
     for (int i = 0; i < 6; i++) exps[i] = J.exps[i];
     double T[16];
-    for (int i = 0; i < 16; i++) T[i] = st->T[i];
+    for (int i = 0; i < 16; i++) T[i] = T_pre ? T_pre[i] : st->T[i];   // (T_pre: the pose, fetched while the block was streaming — LDS)
     const int it = st->iters;
     st->iters = it + 1;
     st->n_corr = sums[28];
@@ -1336,7 +1341,7 @@ __host__ __device__ inline int m3d_ticket_group(int bpp);
 // to arrive adds up the pair's block partials, solves the 6x6 system and updates the pose (a8).
 __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, const M3dJob& J, M3dPairState* st, int n_pairs, int pair, int blk, int bpp,
                                               int first_of_level, const long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                              unsigned int seq, unsigned long long* __restrict__ progress) {
+                                              unsigned int seq, unsigned long long* __restrict__ progress, const double* T_pre = nullptr) {
     // ---- a8 in the same launch: the LAST block of the pair to finish adds up the pair's block partials and solves.
     // (A separate solve kernel cost its ~10 us plus a dependent-launch gap of ~5 us in every iteration.)
     // The partials are stored and loaded with agent-scope (write-through / coherent) accesses and the writers wait for
@@ -1393,7 +1398,7 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    m3d_solve_pair(J, first_of_level, s_part[0]);
+    m3d_solve_pair(J, first_of_level, s_part[0], T_pre);
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
 }
 
@@ -1419,6 +1424,11 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     }
     float R[9], tt[3];
     m3d_load_pose(st, R, tt);
+    // the pose in double for the solve at the end of the launch: requested now, parked in LDS after the streaming loop (the last
+    // block's solving thread otherwise starts with a 1 us round trip)
+    __shared__ double s_T[16];
+    double t_pre = 0.0;
+    if (threadIdx.x < 16) t_pre = st->T[threadIdx.x];
     const M3dLevelDev& L = J.tgt;
     const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
@@ -1431,7 +1441,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
     // NB queries per trip, every load of a stage issued before the first use: the pass is a chain of
     // dependent gathers (match -> point, normal), so its speed is the number of them in flight
-    constexpr int NB = 2;   // (4 in flight: 180 VGPRs = 2 waves per SIMD; 2: 154 = 3 waves, same duration alone, +1.7 % with three chains sharing the GPU)
+    constexpr int NB = 2;   // (4 in flight: 180 VGPRs = 2 waves per SIMD; 2: 154 = 3 waves, same duration alone, +1.7 % with three chains sharing the GPU;
+                            //  the next trip's (match, source point) loads issued ahead of this trip's gathers: 170 VGPRs, same duration, -1 %)
     const int stride = bpp * ICP_THREADS;
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB];
@@ -1456,9 +1467,10 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
             m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], d2, nq[k], cx, cy, cz, S);
         }
     }
+    if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;   // (the reduction below has the barriers that publish it)
     block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
     if (!fuse_solve || !partials) return;
-    m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, first_of_level, partials, tickets, seq, progress);
+    m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, first_of_level, partials, tickets, seq, progress, s_T);
 }
 
 
@@ -1480,16 +1492,27 @@ __global__ __launch_bounds__(256) void k_debug_nn(M3dLevelDev L, const float* __
 // ---- launchers ---------------------------------------------------------------------------------------
 // blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
 __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }
-int m3d_ticket_words(int n_pairs, int max_n_src) {
-    const int bpp = m3d_acc_blocks(max_n_src), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
-    return n_pairs * (ng + 1) * 32;
-}
-
-// workgroups per pair of the reduction pass: ~8 queries per thread, so the 29-term block reduction is amortised
-int m3d_acc_blocks(int max_n_src) {
+// workgroups per pair of the reduction pass: ~8 queries per thread, so the 29-term block reduction is amortised — and, when the
+// batch allows it, a whole number of workgroups per CU: 8 pairs x 49 workgroups put two on 136 CUs and one on 120, the launch then
+// takes what two take; 8 x 64 = two on every CU, each a quarter shorter (19.5 -> 18.0 us per launch, serial steps +4 %)
+int m3d_acc_blocks(int max_n_src, int n_pairs) {
     static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
-    const int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
-    return b < 1 ? 1 : b;
+    static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
+    if (fixed > 0) return fixed;
+    int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
+    if (b < 1) b = 1;
+    if (n_pairs > 0 && (b * n_pairs) % 256 != 0) {
+        const int up = ((b * n_pairs + 255) / 256) * 256;   // the next whole round of the 256 CUs
+        if (up % n_pairs == 0) {
+            const int bu = up / n_pairs;
+            if ((long long)bu * 256 * 5 <= (long long)max_n_src) b = bu;   // (still >= 5 queries per thread)
+        }
+    }
+    return b;
+}
+int m3d_ticket_words(int n_pairs, int max_n_src) {
+    const int bpp = m3d_acc_blocks(max_n_src, n_pairs), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
+    return n_pairs * (ng + 1) * 32;
 }
 
 // One Gauss-Newton iteration: k_nn_iter (classify; sparse blocks search cooperatively, dense blocks bin their queries by target
@@ -1513,7 +1536,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
         M3D_DBG(s, "k_nn_tiles");
     }
     if (k1) (void)hipEventRecord(k1, s);
-    const int bpp_a = m3d_acc_blocks(max_n_src);
+    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs);
     unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' record counters and the work-item counter: zeroed here, behind their readers
     if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);
     else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);

@@ -124,7 +124,7 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int lane_min;                // a 256-query block with >= lane_min queries to search bins them / walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
-    long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
+    long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src, n_pairs)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
     M3dPairState* states;        // [n_pairs] the batch's pair states (== jobs[pair].st)
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
@@ -148,7 +148,7 @@ hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_p
                                     const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0, hipEvent_t k1);
 hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels);
 int m3d_ticket_words(int n_pairs, int max_n_src);
-int m3d_acc_blocks(int max_n_src);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
+int m3d_acc_blocks(int max_n_src, int n_pairs);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

@@ -570,7 +570,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | (unused) | cache (int64) | certificate state (float4)
         h->match_cap = cap;
     }
-    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src)) * M3D_PARTIAL_STRIDE;
+    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs))) * M3D_PARTIAL_STRIDE;
     if (n_part > h->partials_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_partials) hipFree(h->d_partials);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Copies what scripts/profile_gpu.sh, scripts/pmc_summary.py, scripts/kiter.sh and a default `python bench.py` run left in gpurun_out/
+# into profiles/ under one tag:  scripts/save_profiles.sh r02_v1
+set -eu
+tag=$1
+cd "$(dirname "$0")/.."
+big() { ls -S gpurun_out/$1/*/*kernel_stats.csv | head -1; }
+cp "$(big stats)" profiles/${tag}_bench_kernel_stats.csv
+cp "$(big stats_serial)" profiles/${tag}_serial_kernel_stats.csv
+cp gpurun_out/pmc_summary.json profiles/pmc_summary.json
+cp gpurun_out/pmc_summary.json profiles/${tag}_pmc_summary.json
+[ -f gpurun_out/kiter_${tag//_/}.txt ] && grep -v amdgpu.ids gpurun_out/kiter_${tag//_/}.txt > profiles/${tag}_nn_stage_per_iteration.txt
+[ -f gpurun_out/bench_full.json ] && tail -1 gpurun_out/bench_full.json > profiles/${tag}_bench.json
+ls -la profiles | grep ${tag}
