@@ -413,9 +413,12 @@ __device__ __forceinline__ void m3d_scan_range(PP pts, uint32_t t, const uint32_
 // rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first.
 // LDS = the bucket is a staged tile entry: lo = {key, first LDS position, sorted position - LDS position, population}, its points are
 // read from LDS, and a crowded row is simply scanned (an LDS read costs a fraction of a gather; no chunk boxes, no 32-bit rows).
-template <bool LDS, typename PP>
+// DEFER (the cooperative walk, 8 lanes per query): a crowded row is not walked by the one lane that owns its bucket — the (at most four) crowded rows of
+// a bucket are noted in D and shared by the eight lanes of the group afterwards (m3d_coop_query).
+struct M3dDefer { uint32_t b0, e0, b1, e1, b2, e2, b3, e3; int n; };
+template <bool LDS, typename PP, bool DEFER = false>
 __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, PP pts, m3d_gf4 cbox, int vx0, int vy0,
-                                              int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0) {
+                                              int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0, M3dDefer* D = nullptr) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
     const int sz0 = max(Q.lo[2] - vz0, 0), sz1 = min(Q.hi[2] - vz0, 1);
@@ -452,6 +455,10 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         M3D_STATW(sit, 19);
         if (LDS || c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
             m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit, LDS ? lo.z : 0u);
+        } else if (DEFER && D->n < 4) {
+            const uint32_t rb = base + c0, re = base + c1;
+            if (D->n == 0) { D->b0 = rb; D->e0 = re; } else if (D->n == 1) { D->b1 = rb; D->e1 = re; } else if (D->n == 2) { D->b2 = rb; D->e2 = re; } else { D->b3 = rb; D->e3 = re; }
+            D->n++;
         } else if (!LDS) {
             // A crowded row (a surface close to the sensor): chunk by chunk, each chunk's exact box first — the points of a voxel keep
             // their input (firing) order, which sweeps the surface strip by strip, so all but the one or two chunks around the query
@@ -792,6 +799,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
                                               float vx, float vy, float vz, float dseed, int sub, long long& code, float& sec, int sit) {
     M3dQuery Q;
     M3dWalk W; m3d_walk_init(W, dmax2);
+    M3dDefer D; D.b0 = D.e0 = D.b1 = D.e1 = D.b2 = D.e2 = D.b3 = D.e3 = 0u; D.n = 0;
     bool ok = false, found = false;
     code = 0;
     uint4 lo = make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u), hi = make_uint4(0u, 0u, 0u, 0u);
@@ -827,13 +835,41 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {   // (one copy of the row walk in the code: a rolled loop, not two inlined calls)
-        if (found) m3d_walk_rows<false>(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit);
+        if (found) m3d_walk_rows<false, m3d_gf4, true>(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit, &D);
         // ... the group agrees on the bound; the other rows are then mostly discarded by their box distance
         float bnd = W.bound;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
         W.bound = bnd;
     }
+    // The crowded rows the lanes set aside: every one is shared by the eight lanes of its group — lane j tests the boxes of chunks j, j + 8, ...
+    // and scans the ones that can still win. (One lane walking such a row alone made 17 to 35 dependent gather trips: a launch that
+    // classifies in 9 us ended after 23 because of a handful of such queries.) Exact in any order: a chunk is skipped only against a
+    // bound that some candidate already met, a skipped chunk's box distance and every loser go into `sec`.
+    {
+        const int lane = (int)(threadIdx.x & 63u), g0 = lane & ~7;
+#pragma unroll 1
+        for (int L = 0; L < 8; L++) {
+            const int ndL = __shfl(D.n, g0 + L);
+#pragma unroll 1
+            for (int r = 0; r < ndL; r++) {   // (uniform inside a group)
+                const uint32_t rb = r == 0 ? D.b0 : (r == 1 ? D.b1 : (r == 2 ? D.b2 : D.b3)), re = r == 0 ? D.e0 : (r == 1 ? D.e1 : (r == 2 ? D.e2 : D.e3));
+                const uint32_t tb = (uint32_t)__shfl((int)rb, g0 + L), te = (uint32_t)__shfl((int)re, g0 + L);
+                W.any_point = true;
+                const uint32_t cl = (te - 1u) / M3D_CHUNK;
+                for (uint32_t c = tb / M3D_CHUNK + (uint32_t)sub; c <= cl; c += 8u) {
+                    M3D_BT_COUNT(W, bt_chunks);
+                    const float4 mn = m3d_ld(cbox, 2 * (size_t)c), mx = m3d_ld(cbox, 2 * (size_t)c + 1);
+                    const float dx = fmaxf(fmaxf(mn.x - vx, vx - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - vy, vy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - vz, vz - mx.z), 0.f);
+                    const float bd = dx * dx + dy * dy + dz * dz;
+                    if (bd > W.bound) { W.sec = min(W.sec, __float_as_uint(bd)); continue; }
+                    m3d_scan_range(pts, max(tb, c * M3D_CHUNK), min(te, (c + 1u) * M3D_CHUNK), vx, vy, vz, W, sit);
+                    W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
+                }
+            }
+        }
+    }
+    M3D_BT_FLUSH(W);
     // merge the 8 lanes of the query: argmin of the keys; `sec` = min of everything that is not the winner
     // (every point lives in exactly one bucket, so two lanes never hold the same candidate)
     unsigned long long bkey = W.bkey; int best = W.best; uint32_t secb = W.sec; bool any_point = W.any_point;
