@@ -936,50 +936,82 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
-    // three lanes per occupied voxel, one z layer of the 27-voxel neighbourhood each (the sums are exact integers: any split gives the
-    // same bits), merged with two shuffles; lane 0 of the triple then solves. 192 of a block's 256 lanes form 64 triples.
+    // eight lanes per occupied voxel, one BUCKET of the 27-voxel neighbourhood each: the 3x3x3 voxels around a voxel lie in exactly 2x2x2
+    // buckets, so one probe of the level's table per lane (both halves of the entry in one round trip) replaces the 27 dependent
+    // probe chains of a per-voxel walk (they, not the arithmetic, were this kernel's 49 us); the lane then adds the moments of the
+    // bucket's voxels that belong to the neighbourhood (1, 2, 4 or 8 of them). The sums are exact integers: any split gives the same
+    // bits. Merged with three shuffles per word into LDS; a workgroup gathers the sums of 64 voxels that way (two rounds of 32), then ONE
+    // wave solves them, a voxel per lane (the eigen-solve with one lane in eight active was the other half of the kernel's time).
     const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int trip = tl / 3, part = tl - 3 * trip;                  // lanes 63 of every wave: no triple
-    const bool lane_ok = tl < 63;
-    const uint32_t v = (blockIdx.x * 4u + (uint32_t)wv) * 21u + (uint32_t)trip;
-    const bool act = lane_ok && v < B.dyn[5];
+    const int grp = tl >> 3, part = tl & 7;
+    const uint32_t n_vox = B.dyn[5];
+    __shared__ long long s_sum[64][10];
+    __shared__ uint32_t s_oi[64];
+    for (uint32_t vb = blockIdx.x * 64u; vb < n_vox; vb += gridDim.x * 64u) {   // (block-uniform: barriers and shuffles inside)
+    for (int rnd = 0; rnd < 2; rnd++) {
+    const int li = rnd * 32 + wv * 8 + grp;   // voxel of this trip this group sums up
+    const uint32_t v = vb + (uint32_t)li;
+    const bool act = v < n_vox;
     const int j = act ? (int)voxel_head_list(B)[v] : 0;   // first sorted position of the voxel (a finite point)
     const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const long long* mom = B.mom;
-    float4* nrm_in = B.nrm_in;
     const float4 pj = L.pts[j];
     const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
               icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    { const int dz = part - 1; const int cz = icz + dz; if (act && cz >= 0 && cz < g.dims[2]) {
-    for (int dy = -1; dy <= 1; dy++) { const int cy = icy + dy; if (cy < 0 || cy >= g.dims[1]) continue;
-    for (int dx = -1; dx <= 1; dx++) { const int cx = icx + dx; if (cx < 0 || cx >= g.dims[0]) continue;
-        const uint2 vr = m3d_find_voxel(L, cx, cy, cz);
-        if (vr.y <= vr.x) continue;
-        const long long* m = &mom[10 * (size_t)vr.x];
-        const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
-        const long long Dx = (long long)dx * M3D_NQ, Dy = (long long)dy * M3D_NQ, Dz = (long long)dz * M3D_NQ;
-        k += n;
-        s0 += Sx + n * Dx; s1 += Sy + n * Dy; s2 += Sz + n * Dz;
-        q0 += m[4] + 2 * Dx * Sx + n * Dx * Dx;
-        q1 += m[5] + Dx * Sy + Dy * Sx + n * Dx * Dy;
-        q2 += m[6] + Dx * Sz + Dz * Sx + n * Dx * Dz;
-        q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
-        q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
-        q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
-    }}}}
-    {   // lane 3t collects the sums of lanes 3t + 1, 3t + 2 (every lane of the wave shuffles)
+    {
+        // bucket (part & 1, part >> 1 & 1, part >> 2) of the neighbourhood: ((ic - 1) >> 1) + {0, 1} per axis (arithmetic shift: -1 at the border)
+        const int bx = ((icx - 1) >> 1) + (part & 1), by = ((icy - 1) >> 1) + ((part >> 1) & 1), bz = ((icz - 1) >> 1) + (part >> 2);
+        const int nb0 = (g.dims[0] + 1) >> 1, nb1 = (g.dims[1] + 1) >> 1, nb2 = (g.dims[2] + 1) >> 1;
+        if (act && bx >= 0 && by >= 0 && bz >= 0 && bx < nb0 && by < nb1 && bz < nb2) {
+            const uint32_t key = m3d_bucket_key(g, bx, by, bz);
+            const uint4* tab = reinterpret_cast<const uint4*>(L.htab);
+            uint32_t h = m3d_hash_slot(key, g.hshift);
+            uint4 lo = tab[2 * (size_t)h], hi = tab[2 * (size_t)h + 1];
+            while (lo.x != key && lo.x != M3D_INVALID_KEY) { h = (h + 1u) & g.hmask; lo = tab[2 * (size_t)h]; hi = tab[2 * (size_t)h + 1]; }
+            if (lo.x == key) {
+#pragma unroll 2
+                for (int sub = 0; sub < 8; sub++) {
+                    const int dx = 2 * bx + (sub & 1) - icx, dy = 2 * by + ((sub >> 1) & 1) - icy, dz = 2 * bz + (sub >> 2) - icz;
+                    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;   // (voxels beyond dims are simply unoccupied)
+                    const uint2 vr = m3d_sub_range(lo, hi, L.bigcum, sub);
+                    if (vr.y <= vr.x) continue;
+                    const long long* m = &mom[10 * (size_t)vr.x];
+                    const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
+                    const long long Dx = (long long)dx * M3D_NQ, Dy = (long long)dy * M3D_NQ, Dz = (long long)dz * M3D_NQ;
+                    k += n;
+                    s0 += Sx + n * Dx; s1 += Sy + n * Dy; s2 += Sz + n * Dz;
+                    q0 += m[4] + 2 * Dx * Sx + n * Dx * Dx;
+                    q1 += m[5] + Dx * Sy + Dy * Sx + n * Dx * Dy;
+                    q2 += m[6] + Dx * Sz + Dz * Sx + n * Dx * Dz;
+                    q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
+                    q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
+                    q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
+                }
+            }
+        }
+    }
+    {   // lane 8g collects the sums of its group (every lane of the wave shuffles)
         long long* acc[10] = { &k, &s0, &s1, &s2, &q0, &q1, &q2, &q3, &q4, &q5 };
 #pragma unroll
         for (int a = 0; a < 10; a++) {
-            const long long a1 = __shfl_down(*acc[a], 1), a2 = __shfl_down(*acc[a], 2);
-            *acc[a] += a1 + a2;
+#pragma unroll
+            for (int o = 4; o >= 1; o >>= 1) *acc[a] += __shfl_down(*acc[a], o);
         }
     }
-    if (!act || part != 0) return;
+    if (part == 0) {
+        s_sum[li][0] = k; s_sum[li][1] = s0; s_sum[li][2] = s1; s_sum[li][3] = s2; s_sum[li][4] = q0;
+        s_sum[li][5] = q1; s_sum[li][6] = q2; s_sum[li][7] = q3; s_sum[li][8] = q4; s_sum[li][9] = q5;
+        s_oi[li] = oi;
+    }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && vb + threadIdx.x < n_vox) {
+    const long long k = s_sum[threadIdx.x][0], s0 = s_sum[threadIdx.x][1], s1 = s_sum[threadIdx.x][2], s2 = s_sum[threadIdx.x][3], q0 = s_sum[threadIdx.x][4],
+                    q1 = s_sum[threadIdx.x][5], q2 = s_sum[threadIdx.x][6], q3 = s_sum[threadIdx.x][7], q4 = s_sum[threadIdx.x][8], q5 = s_sum[threadIdx.x][9];
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     do {
         if (k < (long long)min_pts || k < 3) break;
         const double inv = 1.0 / (double)k;
@@ -1035,7 +1067,10 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
         if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
         out = make_float4((float)v0, (float)v1, (float)v2, 0.f);
     } while (0);
-    nrm_in[oi] = out;
+    B.nrm_in[s_oi[threadIdx.x]] = out;
+    }
+    __syncthreads();   // (the sums are overwritten by the next trip)
+    }
 }
 
 // Pass 3: every other point takes the normal of its voxel's first point; non-finite points (sorted last) get none
@@ -1132,7 +1167,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3((max_n + 83) / 84, n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);   // 84 voxels per block (3 lanes each)
+        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + 63) / 64, 512), n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
         hipLaunchKernelGGL(k_spread_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_spread_normals");
