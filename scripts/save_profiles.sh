@@ -4,7 +4,8 @@
 set -eu
 tag=$1
 cd "$(dirname "$0")/.."
-big() { ls -S gpurun_out/$1/*/*kernel_stats.csv | head -1; }
+# the newest run's file (gpurun merges every call's files into gpurun_out/: older runs stay there), the largest of that run (a bench run has child processes)
+big() { python3 -c "import glob,os,sys; f=glob.glob('gpurun_out/'+sys.argv[1]+'/*/*kernel_stats.csv'); t=max(os.path.getmtime(x) for x in f); print(max((x for x in f if os.path.getmtime(x) > t - 120), key=os.path.getsize))" $1; }
 cp "$(big stats)" profiles/${tag}_bench_kernel_stats.csv
 cp "$(big stats_serial)" profiles/${tag}_serial_kernel_stats.csv
 cp gpurun_out/pmc_summary.json profiles/pmc_summary.json
