@@ -394,23 +394,29 @@ class MultiRegistrar:
         except Exception:
             pass
 
-    def align(self, pairs):
-        """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (poses [n, 4, 4], stats list, device of every pair)"""
+    def describe(self, pairs, source_only=False):
+        """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (descriptor array, buffers to keep alive): host PointCloud2 payloads, encoded the
+        aggregator's way; source_only: the sources are only sorted (m3dreg_cloud_desc.source_only)."""
         from .pointcloud2 import encode_xyz
         n = len(pairs)
         descs = (abi.PairDesc * n)()
         keep = []
         for i, (src, tgt, T0) in enumerate(pairs):
-            for d, xyz in ((descs[i].source, src), (descs[i].target, tgt)):
+            for d, xyz, so in ((descs[i].source, src, source_only), (descs[i].target, tgt, False)):
                 msg = encode_xyz(np.ascontiguousarray(xyz, np.float32))
                 buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
                 keep.append(buf)
                 d.data = C.cast(buf, C.c_void_p); d.n = msg.n; d.point_step = msg.point_step
                 d.off_x, d.off_y, d.off_z = 0, 4, 8
-                d.data_is_device = 0; d.source_only = 0
+                d.data_is_device = 0; d.source_only = 1 if so else 0
             t0 = T_to_colmajor16(np.eye(4) if T0 is None else T0)
             for k in range(16):
                 descs[i].init_T[k] = float(t0[k])
+        return descs, keep
+
+    def align_described(self, descs):
+        """One m3dreg_multi_align call on descriptors built by describe(): (poses [n, 4, 4], stats list, device of every pair)."""
+        n = len(descs)
         out = np.zeros(16 * n, np.float32)
         st = (abi.Stats * n)()
         dev = np.zeros(n, np.int32)
@@ -418,6 +424,11 @@ class MultiRegistrar:
         if rc != 0:
             raise abi.M3dregError(rc, "m3dreg_multi_align", lib().m3dreg_multi_last_error(self._m).decode())
         return np.stack([colmajor16_to_T(out[16 * i:16 * i + 16]) for i in range(n)]), list(st), dev
+
+    def align(self, pairs, source_only=False):
+        """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (poses [n, 4, 4], stats list, device of every pair)"""
+        descs, keep = self.describe(pairs, source_only)
+        return self.align_described(descs)
 
 
 class Aggregator:
