@@ -124,6 +124,7 @@ struct m3dreg_handle {
     int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
+    int fuse_from = 12;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
     int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
@@ -808,6 +809,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }
     if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
     else {
@@ -979,7 +981,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                     if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
                 }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? -1 : 0), nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((h->fuse_from > 0 && it >= h->fuse_from) ? -2 : -1) : 0), nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             roctx_pop();
             h->launched_iters++;
         }

@@ -225,6 +225,30 @@ def test_tile_search_and_global_walk_are_bit_identical(reg, orc, monkeypatch):
     _same_stats(out[1][4], sto)
 
 
+@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
+def test_fused_late_iterations_are_bit_identical(reg, orc, monkeypatch, metric):
+    """From the 12th iteration of a level on, search and reduction run as ONE launch (k_icp_late, M3DREG_FUSE_FROM); with 0 every
+    iteration is the two- / three-launch chain. 20 fixed iterations, two levels, a batch of three pairs: same trace, pose and
+    statistics either way, and equal to the oracle's."""
+    pairs = [synth.hdl32_pair(700, 400 + k, 500 + k, dx=0.25 - 0.1 * k, dy=0.05 * k, dyaw_deg=2.0 + k) for k in range(3)]
+    p = _params(leaf=(0.4, 0.2), iterations=(16, 20), max_corr_dist=(1.0, 0.5), metric=metric, normal_leaf=0.5, eps_rot=0.0, eps_trans=0.0)
+    runs = []
+    for fuse in ("0", "12", "10"):
+        monkeypatch.setenv("M3DREG_FUSE_FROM", fuse)
+        R = reg.Registrar(p)
+        clouds = [tuple(R.clouds([s, t], source_only=[True, False])) for s, t, _ in pairs]
+        T, st = R.align_batch([(cs, ct, None) for cs, ct in clouds])
+        T1, st1 = R.align(clouds[0][0], clouds[0][1])
+        runs.append((T, [(x.status, x.iterations, x.n_corr, x.rms) for x in st], T1, R.trace()))
+    for r in runs[1:]:
+        assert np.array_equal(runs[0][0], r[0]) and runs[0][1] == r[1]
+        assert np.array_equal(runs[0][2], r[2]) and np.array_equal(runs[0][3], r[3])
+    s, t, _ = pairs[0]
+    To, sto, tro = orc.align(p, orc.Cloud(p, s, source_only=True), orc.Cloud(p, t), trace_cap=64)
+    assert np.array_equal(runs[1][2], To) and np.array_equal(runs[1][3], tro)
+    assert runs[1][1][0][1] == 36 and sto.iterations == 36
+
+
 def test_batched_bucketing_equals_single(reg, orc):
     """m3dreg_cloud_create_batch (one pipeline for many clouds of different sizes, some with non-finite
     points) produces exactly the clouds the one-at-a-time path and the oracle produce."""
