@@ -15,7 +15,10 @@ bytes (NN part: 12 N + 12 M + 8 C_occ per pair) over its average
 records on its stream around that step (m3dreg_profile_read): `frac` from one extra, untimed step with nothing else on the GPU
 (what a rocprofv3 kernel trace of serial steps shows), `frac_in_region` from inside the timed region, where three chains share
 the GPU (every seventh iteration is bracketed: an event record is a barrier packet, bracketing all of them cost 4 % of the
-throughput being measured). `cpu_baseline`: the port of the voxel algorithm (oracle/m3d_oracle.c) and a from-scratch k-d tree
+throughput being measured). From the 12th iteration of a level on the library runs search and reduction as ONE launch (k_icp_late)
+wherever nobody asked for a bracket around the correspondence step; a bracketed iteration runs as the two-launch chain (same bits),
+so `roofline` always prices k_nn_iter (+ k_nn_tiles) — the fused launches show up in the step time, not in the bracket.
+`cpu_baseline`: the port of the voxel algorithm (oracle/m3d_oracle.c) and a from-scratch k-d tree
 ICP (oracle/m3d_kdtree_icp.c), each -O3 -march=native at 1 thread and at all cores, warm-up + median, on a bounded sample of
 the same pairs. `legs`: the other BASELINE configurations and the §8d variants of the headline (serial steps, host payloads,
 convergence-terminated), each measured by a child run of this script right after the headline (--no-extra skips them).
@@ -371,7 +374,7 @@ def main():
             "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (the correspondence step of one Gauss-Newton iteration: two launches, one event bracket)",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (the correspondence step of one Gauss-Newton iteration: two launches, one event bracket; an un-bracketed iteration >= 12 of a level runs fused with the reduction as k_icp_late)",
                          "achieved": alone if alone_ms > 0 else in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (alone if alone_ms > 0 else in_region) / HBM_PEAK_GBS,
                          "avg_launch_ms": alone_ms if alone_ms > 0 else 1e3 * avg_launch_s,
