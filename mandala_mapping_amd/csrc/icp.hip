@@ -383,10 +383,7 @@ typedef const __attribute__((address_space(3))) m3d_f32x4* m3d_lf4;
 __device__ __forceinline__ float4 m3d_ld(m3d_lf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 // candidates [t, t1) of the sorted target points against the query: exact argmin on the packed (d2, input index) key.
-// PP = where the candidates live (global memory: t is a sorted position; LDS: t is a position in the staged tile and gdelta
-// turns it back into the sorted position the result is reported as).
-template <typename PP>
-__device__ __forceinline__ void m3d_scan_range(PP pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit, uint32_t gdelta = 0u) {
+__device__ __forceinline__ void m3d_scan_range(m3d_gf4 pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit) {
     for (; t < t1; t += 4) {
         M3D_BT_COUNT(W, bt_trips);
         M3D_STAT(sit, 12);
@@ -405,19 +402,17 @@ __device__ __forceinline__ void m3d_scan_range(PP pts, uint32_t t, const uint32_
             W.sec = min(W.sec, max(db, (uint32_t)(W.bkey >> 32)));   // the loser of (candidate, best so far) is a non-winner
             const bool better = key < W.bkey;
             W.bkey = better ? key : W.bkey;
-            W.best = better ? (int)(idx[j] + gdelta) : W.best;
+            W.best = better ? (int)idx[j] : W.best;
         }
     }
 }
 
 // rows k in [k0, k1) of one bucket, k enumerating the 4 (y,z) rows nearest-first.
-// LDS = the bucket is a staged tile entry: lo = {key, first LDS position, sorted position - LDS position, population}, its points are
-// read from LDS, and a crowded row is simply scanned (an LDS read costs a fraction of a gather; no chunk boxes, no 32-bit rows).
 // DEFER (the cooperative walk, 8 lanes per query): a crowded row is not walked by the one lane that owns its bucket — the (at most four) crowded rows of
 // a bucket are noted in D and shared by the eight lanes of the group afterwards (m3d_coop_query).
 struct M3dDefer { uint32_t b0, e0, b1, e1, b2, e2, b3, e3; int n; };
-template <bool LDS, typename PP, bool DEFER = false>
-__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, PP pts, m3d_gf4 cbox, int vx0, int vy0,
+template <bool DEFER = false>
+__device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo, const uint4& hi, m3d_gu32 bigcum, m3d_gf4 pts, m3d_gf4 cbox, int vx0, int vy0,
                                               int vz0, float ux, float uy, float uz, M3dWalk& W, int k0, int k1, int sit = 0, M3dDefer* D = nullptr) {
     const int sx0 = max(Q.lo[0] - vx0, 0), sx1 = min(Q.hi[0] - vx0, 1);
     const int sy0 = max(Q.lo[1] - vy0, 0), sy1 = min(Q.hi[1] - vy0, 1);
@@ -434,7 +429,7 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         if (sy < sy0 || sy > sy1 || sz < sz0 || sz > sz1) continue;
         const int s_first = sx0 | (sy << 1) | (sz << 2), s_last = sx1 | (sy << 1) | (sz << 2);
         uint32_t c0, c1;
-        if (LDS || lo.w == 0) {
+        if (lo.w == 0) {
             c1 = (uint32_t)(((s_last < 4) ? cumA : cumB) >> (16 * (s_last & 3))) & 0xFFFFu;
             const int sm = s_first - 1;
             c0 = s_first ? ((uint32_t)(((sm < 4) ? cumA : cumB) >> (16 * (sm & 3))) & 0xFFFFu) : 0u;
@@ -453,13 +448,13 @@ __device__ __forceinline__ void m3d_walk_rows(const M3dQuery& Q, const uint4& lo
         if (lb2 > W.bound) { W.sec = min(W.sec, __float_as_uint(lb2)); if (c1 > c0) M3D_STAT(sit, 11); continue; }
         if (c1 > c0) M3D_STATV(sit, 13, c1 - c0);
         M3D_STATW(sit, 19);
-        if (LDS || c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
-            m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit, LDS ? lo.z : 0u);
+        if (c1 - c0 <= (uint32_t)M3D_LONG_ROW) {
+            m3d_scan_range(pts, base + c0, base + c1, ux, uy, uz, W, sit);
         } else if (DEFER && D->n < 4) {
             const uint32_t rb = base + c0, re = base + c1;
             if (D->n == 0) { D->b0 = rb; D->e0 = re; } else if (D->n == 1) { D->b1 = rb; D->e1 = re; } else if (D->n == 2) { D->b2 = rb; D->e2 = re; } else { D->b3 = rb; D->e3 = re; }
             D->n++;
-        } else if (!LDS) {
+        } else {
             // A crowded row (a surface close to the sensor): chunk by chunk, each chunk's exact box first — the points of a voxel keep
             // their input (firing) order, which sweeps the surface strip by strip, so all but the one or two chunks around the query
             // are provably farther than the best so far and are never gathered. A skipped chunk's box distance bounds its points in `sec`.
@@ -839,7 +834,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     if (act) { M3D_STAT(sit, 7); if (found) M3D_STAT(sit, 8); }
 #pragma unroll 1
     for (int phase = 0; phase < 2; phase++) {   // (one copy of the row walk in the code: a rolled loop, not two inlined calls)
-        if (found) m3d_walk_rows<false, m3d_gf4, true>(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit, &D);
+        if (found) m3d_walk_rows<true>(Q, lo, hi, bigcum, pts, cbox, vx0, vy0, vz0, vx, vy, vz, W, phase, phase ? 4 : 1, sit, &D);
         // ... the group agrees on the bound; the other rows are then mostly discarded by their box distance
         float bnd = W.bound;
 #pragma unroll
