@@ -601,7 +601,11 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     const unsigned int tb_slot = s_tbslot;
 #endif
     TB_STAMP(0);
-    for (int i = tid; i < M3D_TILE_CS; i += 256) s_ck[i] = M3D_INVALID_KEY;
+    // (the set holds occupied positions only when the bitmap exists: at most ECAP = 512 of them may be staged, 1024 slots do; without it every
+    // candidate position goes in: 4096)
+    const int cs_bits = occ_ok ? 10 : 12;
+    const uint32_t cs_mask = (1u << cs_bits) - 1u;
+    for (int i = tid; i <= (int)cs_mask; i += 256) s_ck[i] = M3D_INVALID_KEY;
     if (tid == 0) { s_cnt = 0u; s_over = 0u; }
     // 1. own bucket heads, in sorted order; their bucket coordinates (one point load per head)
     uint32_t nheads = 0;
@@ -625,21 +629,36 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     TB_STAMP(1);
     // 2. the 27 bucket positions around every own bucket, as a set (LDS only: neighbouring own buckets share most of them)
     const int nb0 = (g.dims[0] + 1) >> 1, nb1 = (g.dims[1] + 1) >> 1, nb2 = (g.dims[2] + 1) >> 1;
-    for (uint32_t item = (uint32_t)tid; item < nheads * 27u; item += 256u) {
-        const uint32_t hd = item / 27u, d = item - hd * 27u;
-        const uint32_t c = s_head[hd];
-        const int cx = (int)(c & 2047u) + (int)(d % 3u) - 1, cy = (int)((c >> 11) & 2047u) + (int)((d / 3u) % 3u) - 1, cz = (int)(c >> 22) + (int)(d / 9u) - 1;
-        if (cx < 0 || cy < 0 || cz < 0 || cx >= nb0 || cy >= nb1 || cz >= nb2) continue;
-        const uint32_t key = m3d_bucket_key(g, cx, cy, cz);
-        uint32_t h = (key * 0x9E3779B1u) >> (32 - 12);
-        static_assert(M3D_TILE_CS == 4096, "candidate set hash: 12 bits");
-        int tries = 0;
-        for (; tries < M3D_TILE_CS; tries++) {
-            const uint32_t old = atomicCAS(&s_ck[h], M3D_INVALID_KEY, key);
-            if (old == M3D_INVALID_KEY || old == key) break;
-            h = (h + 1u) & (M3D_TILE_CS - 1u);
+    // (with the occupancy bitmap: only OCCUPIED positions enter the set — eight bitmap words in flight per thread and trip; an empty
+    // position costs one 4-byte load and no LDS traffic)
+    for (uint32_t item0 = (uint32_t)tid; item0 < nheads * 27u; item0 += 8u * 256u) {
+        uint32_t key[8], wbit[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t item = item0 + 256u * (uint32_t)u;
+            key[u] = M3D_INVALID_KEY; wbit[u] = 0xFFFFFFFFu;
+            if (item >= nheads * 27u) continue;
+            const uint32_t hd = item / 27u, d = item - hd * 27u;
+            const uint32_t c = s_head[hd];
+            const int cx = (int)(c & 2047u) + (int)(d % 3u) - 1, cy = (int)((c >> 11) & 2047u) + (int)((d / 3u) % 3u) - 1, cz = (int)(c >> 22) + (int)(d / 9u) - 1;
+            if (cx < 0 || cy < 0 || cz < 0 || cx >= nb0 || cy >= nb1 || cz >= nb2) continue;
+            key[u] = m3d_bucket_key(g, cx, cy, cz);
+            if (occ_ok) wbit[u] = B.occ[key[u] >> 5];
         }
-        if (tries == M3D_TILE_CS) s_over = 1u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t k = key[u];
+            if (k == M3D_INVALID_KEY || !((wbit[u] >> (occ_ok ? (k & 31u) : 0u)) & 1u)) continue;
+            uint32_t h = (k * 0x9E3779B1u) >> (32 - cs_bits);
+            static_assert(M3D_TILE_CS == 4096, "candidate set hash: at most 12 bits");
+            int tries = 0;
+            for (; tries <= (int)cs_mask; tries++) {
+                const uint32_t old = atomicCAS(&s_ck[h], M3D_INVALID_KEY, k);
+                if (old == M3D_INVALID_KEY || old == k) break;
+                h = (h + 1u) & cs_mask;
+            }
+            if (tries > (int)cs_mask) s_over = 1u;   // (set full: more occupied positions than can be staged anyway)
+        }
     }
     __syncthreads();
     TB_STAMP(2);
@@ -647,17 +666,26 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     // "empty" for most candidates at once, the few occupied ones are then looked up in the level's table for their entry; without it
     // (a grid of more than 2^23 bucket positions): one probe chain per candidate, four in flight.
     if (occ_ok) {
-        uint32_t key[M3D_TILE_CS / 256], wbit[M3D_TILE_CS / 256];
+        uint32_t key[4];
 #pragma unroll
-        for (int r = 0; r < M3D_TILE_CS / 256; r++) { key[r] = s_ck[256 * r + tid]; wbit[r] = key[r] != M3D_INVALID_KEY ? B.occ[key[r] >> 5] : 0u; }
+        for (int r = 0; r < 4; r++) key[r] = s_ck[256 * r + tid];   // (the set's 1024 slots hold occupied positions only)
+        // the occupied candidates form the list first (LDS), THEN every thread looks one of them up in the level's table: a thread that
+        // found three occupied ones among its sixteen made three dependent probes while most of the others had none (12 of this
+        // kernel's 28 us per workgroup)
 #pragma unroll
-        for (int r = 0; r < M3D_TILE_CS / 256; r++) {
-            if (!((wbit[r] >> (key[r] & 31u)) & 1u)) continue;
-            uint32_t slot = m3d_hash_slot(key[r], hshift);
-            uint4 lo = tab[2 * (size_t)slot];
-            while (lo.x != key[r]) { slot = (slot + 1u) & hmask; lo = tab[2 * (size_t)slot]; }   // (the bucket exists)
+        for (int r = 0; r < 4; r++) {
+            if (key[r] == M3D_INVALID_KEY) continue;
             const uint32_t e = atomicAdd(&s_cnt, 1u);
-            if (e < (uint32_t)M3D_TILE_ECAP) { s_lk[e] = key[r]; s_lg[e] = slot; }
+            if (e < (uint32_t)M3D_TILE_ECAP) s_lk[e] = key[r];
+        }
+        __syncthreads();
+        const uint32_t n_occ = min(s_cnt, (uint32_t)M3D_TILE_ECAP);
+        for (uint32_t e = (uint32_t)tid; e < n_occ; e += 256u) {   // (keeping both halves of the entry in registers for step 4 cost more occupancy than the round trip it saves)
+            const uint32_t k = s_lk[e];
+            uint32_t slot = m3d_hash_slot(k, hshift);
+            uint4 lo = tab[2 * (size_t)slot];
+            while (lo.x != k) { slot = (slot + 1u) & hmask; lo = tab[2 * (size_t)slot]; }   // (the bucket exists)
+            s_lg[e] = slot;
         }
     } else {
         for (int s0 = 0; s0 < M3D_TILE_CS; s0 += 1024) {
