@@ -1219,6 +1219,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         }
         const unsigned int n_done = min(cs, qn - min(qn, chunk * cs));
         if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
+        (void)n_staged;
         M3D_TBT_END(0, n_done, n_staged);
         first_item = false;
     }
