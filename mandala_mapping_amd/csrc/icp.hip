@@ -898,6 +898,12 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
 #else
 #define M3D_NN_OCC
 #endif
+// LEAN (k_nn_iter<true>, the tile iterations of a level whose target has tiles): classify + bin ONLY — every query that must search goes
+// to its tile's slab however few they are, and the rare one that cannot (a tile that could not be staged, a full slab, more than 64
+// tiles in one workgroup) goes to the pair's fallback list, which k_nn_fallback walks. Without the two walks compiled in the kernel
+// needs 41 VGPRs instead of 124: 7 waves per SIMD instead of 4 — worth 4-6 % of the headline, where three chains compete for the
+// register file (alone it is only 2-5 us faster per launch).
+template <bool LEAN>
 __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
     {   // the source's crowded blocks first (they run several times as long as the rest: started last they were the kernel's tail)
@@ -906,9 +912,9 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     }
     M3D_BT_BEGIN();
     __shared__ int s_cnt[4];
-    __shared__ int s_list[256];          // worklist of the cooperative walk: owner thread | seeded << 8 ...
-    __shared__ float s_wu[3][256];       // ... its transformed query ...
-    __shared__ float s_wd[256];          // ... and the squared distance to its seed (the previous match), all known to the owner
+    __shared__ int s_list[LEAN ? 1 : 256];          // worklist of the cooperative walk: owner thread | seeded << 8 ...
+    __shared__ float s_wu[3][LEAN ? 1 : 256];       // ... its transformed query ...
+    __shared__ float s_wd[LEAN ? 1 : 256];          // ... and the squared distance to its seed (the previous match), all known to the owner
     const int tid = (int)threadIdx.x;
     const int i = blk * 256 + tid;
 #ifdef M3D_STATS
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     if (i < n) { M3D_STAT(sit, 0); if (cls == 1) M3D_STAT(sit, 3); if (cls == 2) M3D_STAT(sit, 4); }
     if (nW == 0) { M3D_BT_END(0); return; }   // block-uniform
     if (tid == 0) M3D_STAT(sit, nW >= A.lane_min ? 5 : 6);
-    if (nW >= A.lane_min && A.tiles && J.tgt.thdr) {
+    if (LEAN || (nW >= A.lane_min && A.tiles && J.tgt.thdr)) {
         // ---- many queries to search, the target has tiles: bin them, k_nn_tiles answers them from LDS ----------------
         // A query goes to the tile that owns its home bucket (one probe of the level's table: the bucket's first sorted position
         // names the tile); every other bucket of its 2x2x2 neighbourhood is within one bucket of that one, hence staged with
@@ -1065,17 +1071,25 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             const size_t r = (size_t)pair * A.rec_stride + (size_t)tile * M3D_TILE_QCAP + pos;
             A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
             A.recd[r] = dseed;
-        } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab: walked here, in global memory (rare)
-            long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
-            out[i] = m;
-            if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-            if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
-            atomicAdd(&A.states[pair].ctr[1], 1u);
+        } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab (rare)
+            if constexpr (LEAN) {   // ... k_nn_fallback walks it
+                const uint32_t fslot = atomicAdd(&tcnt[A.ntile_max], 1u);   // (the counter behind the tiles'; the list holds every query of the pair if it must)
+                const size_t r = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP + fslot;
+                A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
+                A.recd[r] = dseed;
+            } else {                // ... walked here, in global memory
+                long long code = 0; float sec = 0.f;
+                const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
+                out[i] = m;
+                if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+                if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
+                atomicAdd(&A.states[pair].ctr[1], 1u);
+            }
         }
         M3D_BT_END(nW);
         return;
     }
+    if constexpr (!LEAN) {
     if (nW >= A.lane_min) {
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
@@ -1119,6 +1133,45 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __syncthreads();
 #endif
     M3D_BT_END(nW);
+    }
+}
+
+// k_nn_fallback: the queries k_nn_iter<true> could not bin (normally none: every workgroup reads one counter and leaves), walked in
+// global memory 8 lanes per query. A few workgroups per pair stride over the pair's list.
+#define M3D_FALLBACK_BLOCKS 4
+__global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, M3dNnArgs A) {
+    const int pair = (int)blockIdx.x / M3D_FALLBACK_BLOCKS, fb = (int)blockIdx.x % M3D_FALLBACK_BLOCKS;
+    const unsigned int nf = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
+    if (nf == 0u) return;
+    const M3dJob& J = jobs[pair];
+    const M3dPairState* st = A.states + pair;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    const M3dGrid g = J.tgt.g;
+    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts), cbox = m3d_as_global(J.tgt.cbox);
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
+    const float dmax2 = J.dmax2;
+    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+    const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP);
+    const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
+    const int sub = (int)threadIdx.x & 7;
+    for (unsigned int base = (unsigned int)fb * 32u; base < nf; base += 32u * M3D_FALLBACK_BLOCKS) {   // (uniform per workgroup: the shuffles inside need every lane)
+        const unsigned int w = base + (threadIdx.x >> 3);
+        const bool act = w < nf;
+        const float4 r4 = act ? m3d_ld(rec, (size_t)w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t e = __float_as_uint(r4.w);
+        long long code; float sec;
+        const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? recd[w] : 0.f, sub, code, sec, 0);
+        if (act && sub == 0) {
+            const int qi = (int)(e & 0x7FFFFFFFu);
+            out[qi] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
+        }
+    }
+    if (fb == 0 && threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], nf);
 }
 
 // k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
@@ -1687,16 +1740,23 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
         M3D_DBG(s, "k_icp_late");
         return;
     }
-    hipLaunchKernelGGL(k_nn_iter, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-    M3D_DBG(s, "k_nn_iter");
+    if (w.tiles && !late && w.lean) {   // (every target of the batch has tiles: build_jobs checked)
+        hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_iter<lean>");
+        hipLaunchKernelGGL(k_nn_fallback, dim3(M3D_FALLBACK_BLOCKS * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, A);
+        M3D_DBG(s, "k_nn_fallback");
+    } else {
+        hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_iter");
+    }
     if (w.tiles && !late) {
         hipLaunchKernelGGL(k_nn_tiles, dim3(M3D_TILE_GRID), dim3(M3D_TILE_THREADS), 0, s, d_jobs, first_of_level, A);
         M3D_DBG(s, "k_nn_tiles");
     }
     if (k1) (void)hipEventRecord(k1, s);
     unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' record counters and the work-item counter: zeroed here, behind their readers
-    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);
-    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max, w.wcount);
+    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1, w.wcount);
+    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1, w.wcount);
     M3D_DBG(s, "k_accumulate_matches");
 }
 

@@ -124,7 +124,9 @@ struct m3dreg_handle {
     int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
-    int fuse_from = 12;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
+    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles (M3DREG_LEAN)
+    bool batch_all_tiles = false;
+    int fuse_from = 10;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
     int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
@@ -592,7 +594,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     h->match_pairs = n_pairs;
     if (h->tiles) {   // workspace of the LDS-staged search: per pair, query records per tile + the global-walk list, and their counters
         const size_t ntile = size_t(m3d_tiles_of(max_n_tgt));
-        const size_t rec_stride = ntile * M3D_TILE_QCAP;
+        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;   // the tiles' slabs, then the fallback list (k_nn_fallback: it holds every query of the pair if it must)
         const size_t cnt_stride = (ntile + 1 + 31) & ~size_t(31);
         if (n_pairs * rec_stride > h->rec_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -636,7 +638,7 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
     w.rot = h->xcd_rot;
-    w.tiles = h->tiles; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
+    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles) ? 1 : 0; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
     return w;
@@ -657,6 +659,7 @@ int validate_params(const m3dreg_params* p) {
 int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& max_n_src, int& max_n_tgt) {
     const m3dreg_params& P = h->params;
     max_n_src = 0; max_n_tgt = 0;
+    h->batch_all_tiles = h->tiles != 0;
     for (size_t i = 0; i < n_pairs; i++) {
         const m3dreg_cloud* s = pairs[i].source;
         const m3dreg_cloud* t = pairs[i].target;
@@ -669,6 +672,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
             if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
         if (s->n > max_n_src) max_n_src = s->n;   // launch geometry only (the finite count stays on the device; results do not depend on it)
         if (t->n > max_n_tgt) max_n_tgt = t->n;
+        if (!t->has_tiles) h->batch_all_tiles = false;   // (then the tile iterations keep the full k_nn_iter, which walks such a pair's searches itself)
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
@@ -809,6 +813,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("M3DREG_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }
     if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }

@@ -469,6 +469,31 @@ def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
     _same_stats(st1, st2)
 
 
+@pytest.mark.parametrize("lean", ["0", "1"])
+def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkeypatch, lean):
+    """M3DREG_LEAN=1 (default): the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; 0: the full k_nn_iter,
+    which walks what it does not bin. A crowded pair (fallback list in use) and an ordinary one in one batch, 14 iterations (tiles,
+    then fused late iterations): same poses and statistics, equal to the oracle's."""
+    monkeypatch.setenv("M3DREG_LEAN", lean)
+    def blob_cloud(seed):   # 30 000 points inside a 12 cm cube: some 20 cm bucket holds more points than a tile image (2048) — its tile is flagged
+        rng = np.random.default_rng(seed)
+        return np.concatenate([_crowded_cloud(seed), np.array([2.0, -1.0, 0.4]) + rng.uniform(0, 0.12, (30000, 3))]).astype(np.float32)
+    tgt_c = blob_cloud(21)
+    Tc = synth.make_T(synth.rot_z(np.radians(1.0)), np.array([0.02, 0.01, -0.01]))
+    src_c = synth.apply_T(synth.inv_T(Tc), blob_cloud(22).astype(np.float64)).astype(np.float32)
+    src_o, tgt_o, _ = synth.hdl32_pair(600, 610, 611, dx=0.2, dy=0.05, dyaw_deg=1.5)
+    p = _params(leaf=0.1, iterations=14, max_corr_dist=0.3, metric=abi.POINT_TO_PLANE, normal_leaf=0.3, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    cs_c, ct_c, cs_o, ct_o = R.clouds([src_c, tgt_c, src_o, tgt_o], source_only=[True, False, True, False])
+    T, st = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])
+    for k, (s_, t_) in enumerate(((src_c, tgt_c), (src_o, tgt_o))):
+        To, sto, _ = orc.align(p, orc.Cloud(p, s_, source_only=True, omp=True), orc.Cloud(p, t_, omp=True))
+        assert np.array_equal(T[k], To)
+        _same_stats(st[k], sto)
+    tile_searches, walked = R.counters()
+    assert tile_searches > 0 and walked > 0   # (the flagged tile's queries were walked: by k_nn_fallback or by the full k_nn_iter)
+
+
 def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
     """The bench's pipeline: several handles share ONE HIP stream, each holds a batch — bucketing (enqueue-only) and iterations of
     batch k+1 are queued behind batch k, nothing is waited for until every batch has been enqueued, and clouds go back to their
