@@ -10,12 +10,12 @@ then the pose read-back; with N > 1 the poses of all ranks are gathered over RCC
 collective; pairs never exchange data).
 
 Prints ONE JSON line (rank 0). `roofline` prices the correspondence step of an iteration (k_nn_iter: source transform,
-NN-certificate check, binning / sparse search; k_nn_tiles: the binned searches from LDS-staged target tiles) by its algorithmic
+NN-certificate check, binning [+ k_nn_fallback: the rare query that cannot be binned]; k_nn_tiles: the binned searches from LDS-staged target tiles) by its algorithmic
 bytes (NN part: 12 N + 12 M + 8 C_occ per pair) over its average duration, taken from hipEvents the library
 records on its stream around that step (m3dreg_profile_read): `frac` from one extra, untimed step with nothing else on the GPU
 (what a rocprofv3 kernel trace of serial steps shows), `frac_in_region` from inside the timed region, where three chains share
 the GPU (every seventh iteration is bracketed: an event record is a barrier packet, bracketing all of them cost 4 % of the
-throughput being measured). From the 12th iteration of a level on the library runs search and reduction as ONE launch (k_icp_late)
+throughput being measured). From the 10th iteration of a level on the library runs search and reduction as ONE launch (k_icp_late)
 wherever nobody asked for a bracket around the correspondence step; a bracketed iteration runs as the two-launch chain (same bits),
 so `roofline` always prices k_nn_iter (+ k_nn_tiles) — the fused launches show up in the step time, not in the bracket.
 `cpu_baseline`: the port of the voxel algorithm (oracle/m3d_oracle.c) and a from-scratch k-d tree
@@ -374,7 +374,7 @@ def main():
             "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (the correspondence step of one Gauss-Newton iteration: two launches, one event bracket; an un-bracketed iteration >= 12 of a level runs fused with the reduction as k_icp_late)",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (the correspondence step of one Gauss-Newton iteration: two launches, one event bracket; an un-bracketed iteration >= 10 of a level runs fused with the reduction as k_icp_late)",
                          "achieved": alone if alone_ms > 0 else in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (alone if alone_ms > 0 else in_region) / HBM_PEAK_GBS,
                          "avg_launch_ms": alone_ms if alone_ms > 0 else 1e3 * avg_launch_s,

@@ -1136,13 +1136,17 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     }
 }
 
-// k_nn_fallback: the queries k_nn_iter<true> could not bin (normally none: every workgroup reads one counter and leaves), walked in
-// global memory 8 lanes per query. A few workgroups per pair stride over the pair's list.
-#define M3D_FALLBACK_BLOCKS 4
-__global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ jobs, int n_pairs, int first_of_level, M3dNnArgs A) {
-    const int pair = (int)blockIdx.x / M3D_FALLBACK_BLOCKS, fb = (int)blockIdx.x % M3D_FALLBACK_BLOCKS;
+// k_nn_fallback: the queries k_nn_iter<true> could not bin, walked in global memory. Normally there are none: every workgroup reads
+// one counter and leaves. A few (a flagged tile here and there) are walked 8 lanes per query by the pair's first workgroups; many (a
+// level whose buckets hold more points than a tile image — the coarse levels of a dense map) one query per lane, all workgroups.
+#define M3D_FALLBACK_COOP_MAX 4096   // entries up to which the cooperative walk is used
+__global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk, A.rot);
     const unsigned int nf = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
     if (nf == 0u) return;
+    const bool coop = nf <= (unsigned int)M3D_FALLBACK_COOP_MAX;
+    if ((coop ? 32u : 256u) * (unsigned int)blk >= nf) return;   // (block-uniform)
     const M3dJob& J = jobs[pair];
     const M3dPairState* st = A.states + pair;
     if (st->done || (!first_of_level && st->level_done)) return;
@@ -1156,22 +1160,35 @@ __global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ 
     M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
     const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP);
     const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
-    const int sub = (int)threadIdx.x & 7;
-    for (unsigned int base = (unsigned int)fb * 32u; base < nf; base += 32u * M3D_FALLBACK_BLOCKS) {   // (uniform per workgroup: the shuffles inside need every lane)
-        const unsigned int w = base + (threadIdx.x >> 3);
-        const bool act = w < nf;
-        const float4 r4 = act ? m3d_ld(rec, (size_t)w) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint32_t e = __float_as_uint(r4.w);
-        long long code; float sec;
-        const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? recd[w] : 0.f, sub, code, sec, 0);
-        if (act && sub == 0) {
+    if (coop) {
+        const int sub = (int)threadIdx.x & 7;
+        for (unsigned int base = (unsigned int)blk * 32u; base < nf; base += 32u * (unsigned int)bpp) {   // (uniform per workgroup: the shuffles inside need every lane)
+            const unsigned int w = base + (threadIdx.x >> 3);
+            const bool act = w < nf;
+            const float4 r4 = act ? m3d_ld(rec, (size_t)w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t e = __float_as_uint(r4.w);
+            long long code; float sec;
+            const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? recd[w] : 0.f, sub, code, sec, 0);
+            if (act && sub == 0) {
+                const int qi = (int)(e & 0x7FFFFFFFu);
+                out[qi] = m;
+                if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+                if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
+            }
+        }
+    } else {
+        for (unsigned int w = (unsigned int)blk * 256u + threadIdx.x; w < nf; w += 256u * (unsigned int)bpp) {
+            const float4 r4 = m3d_ld(rec, (size_t)w);
+            const uint32_t e = __float_as_uint(r4.w);
+            long long code = 0; float sec = 0.f;
+            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, r4.x, r4.y, r4.z, dmax2, (e >> 31) != 0u, recd[w], code, sec, 0);
             const int qi = (int)(e & 0x7FFFFFFFu);
             out[qi] = m;
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
             if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
         }
     }
-    if (fb == 0 && threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], nf);
+    if (blk == 0 && threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], nf);
 }
 
 // k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
@@ -1743,7 +1760,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     if (w.tiles && !late && w.lean) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
-        hipLaunchKernelGGL(k_nn_fallback, dim3(M3D_FALLBACK_BLOCKS * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, first_of_level, A);
+        hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_fallback");
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);

@@ -124,7 +124,7 @@ struct m3dreg_handle {
     int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
-    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles (M3DREG_LEAN)
+    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
     bool batch_all_tiles = false;
     int fuse_from = 10;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
     int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
@@ -630,7 +630,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
 }
 
 M3dNnWork nn_work(const m3dreg_handle* h) {
-    M3dNnWork w;
+    M3dNnWork w{};
     w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
     w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
@@ -638,7 +638,10 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
     w.rot = h->xcd_rot;
-    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles) ? 1 : 0; w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
+    // (lean only for one-level registrations: a pyramid's coarse levels put more points into a bucket than a tile image holds, their queries would all
+    // take the fallback list — config 5: 6.5 instead of 5.9 ms)
+    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && h->params.n_levels == 1) ? 1 : 0;
+    w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
     return w;

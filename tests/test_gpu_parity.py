@@ -469,15 +469,16 @@ def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
     _same_stats(st1, st2)
 
 
+@pytest.mark.parametrize("blob", [(30000, 0.12), (2600, 0.05)])   # more / fewer fallback queries than k_nn_fallback walks cooperatively (4096)
 @pytest.mark.parametrize("lean", ["0", "1"])
-def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkeypatch, lean):
+def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkeypatch, lean, blob):
     """M3DREG_LEAN=1 (default): the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; 0: the full k_nn_iter,
     which walks what it does not bin. A crowded pair (fallback list in use) and an ordinary one in one batch, 14 iterations (tiles,
     then fused late iterations): same poses and statistics, equal to the oracle's."""
     monkeypatch.setenv("M3DREG_LEAN", lean)
-    def blob_cloud(seed):   # 30 000 points inside a 12 cm cube: some 20 cm bucket holds more points than a tile image (2048) — its tile is flagged
+    def blob_cloud(seed):   # a cube so full that some 20 cm bucket holds more points than a tile image (2048): its tile is flagged
         rng = np.random.default_rng(seed)
-        return np.concatenate([_crowded_cloud(seed), np.array([2.0, -1.0, 0.4]) + rng.uniform(0, 0.12, (30000, 3))]).astype(np.float32)
+        return np.concatenate([_crowded_cloud(seed), np.array([2.0, -1.0, 0.4]) + rng.uniform(0, blob[1], (blob[0], 3))]).astype(np.float32)
     tgt_c = blob_cloud(21)
     Tc = synth.make_T(synth.rot_z(np.radians(1.0)), np.array([0.02, 0.01, -0.01]))
     src_c = synth.apply_T(synth.inv_T(Tc), blob_cloud(22).astype(np.float64)).astype(np.float32)
