@@ -622,8 +622,9 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     __syncthreads();
     for (uint32_t hd = (uint32_t)tid; hd < nheads; hd += 256u) {
         const float4 p = B.pts[s_head[hd]];
-        s_head[hd] = (uint32_t)((int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1) | ((uint32_t)((int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1) << 11) |
-                     ((uint32_t)((int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1) << 22);
+        // (packed with the grid's own bit widths — the bucket key: sum of the widths <= 28; fixed 11 / 11 / 10-bit fields lost the top bit of z on a grid
+        // of more than 2048 voxels in z)
+        s_head[hd] = m3d_bucket_key(g, (int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1, (int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1, (int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1);
     }
     __syncthreads();
     TB_STAMP(1);
@@ -640,7 +641,8 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
             if (item >= nheads * 27u) continue;
             const uint32_t hd = item / 27u, d = item - hd * 27u;
             const uint32_t c = s_head[hd];
-            const int cx = (int)(c & 2047u) + (int)(d % 3u) - 1, cy = (int)((c >> 11) & 2047u) + (int)((d / 3u) % 3u) - 1, cz = (int)(c >> 22) + (int)(d / 9u) - 1;
+            const int cx = (int)(c & ((1u << g.cb[0]) - 1u)) + (int)(d % 3u) - 1, cy = (int)((c >> g.cb[0]) & ((1u << g.cb[1]) - 1u)) + (int)((d / 3u) % 3u) - 1,
+                      cz = (int)(c >> (g.cb[0] + g.cb[1])) + (int)(d / 9u) - 1;
             if (cx < 0 || cy < 0 || cz < 0 || cx >= nb0 || cy >= nb1 || cz >= nb2) continue;
             key[u] = m3d_bucket_key(g, cx, cy, cz);
             if (occ_ok) wbit[u] = B.occ[key[u] >> 5];

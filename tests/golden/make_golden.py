@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden_v1.json.
+"""Generates tests/golden/golden_v<SPEC_VERSION>.json (never overwrites an existing version without --force: a change of the normative
+arithmetic gets a NEW file and an entry in its spec_history; older files stay frozen and keep being tested for every field the change
+did not touch — tests/test_golden.py).
 
 The reference holds no golden vectors for this path (gpu_6dslam is an empty submodule, the
 tree has no tests), so these vectors are produced by THIS repo's CPU oracle (oracle/m3d_oracle.c) on
@@ -19,6 +21,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from mandala_mapping_amd import abi, synth  # noqa: E402
 from oracle import orc  # noqa: E402
+
+
+SPEC_VERSION = 2   # golden_v2.json: normals v2 (bea73c6) + solve v2 (a025d4d); golden_v1.json = spec v1, frozen
 
 
 def fnv64(a):
@@ -60,11 +65,16 @@ def run_case(gen, pk):
 
 
 def main():
-    out = {"version": 1, "generator": "tests/golden/make_golden.py (CPU oracle; the reference has no vectors for this path)", "cases": {}}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"golden_v{SPEC_VERSION}.json")
+    if os.path.exists(path) and "--force" not in sys.argv:
+        raise SystemExit(f"{path} exists: a spec change gets a new SPEC_VERSION (and a spec_history entry), not a regenerated file")
+    out = {"version": SPEC_VERSION, "generator": "tests/golden/make_golden.py (CPU oracle; the reference has no vectors for this path)", "cases": {}}
+    if os.path.exists(path):
+        out["spec_history"] = json.load(open(path)).get("spec_history", [])
     for name, gen, pk in CASES:
         out["cases"][name] = {"params": {k: (list(v) if isinstance(v, tuple) else v) for k, v in pk.items()}, **run_case(gen, pk)}
         print(name, out["cases"][name]["pose_error_deg_m"], out["cases"][name]["iterations"])
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
 

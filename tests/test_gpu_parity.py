@@ -225,6 +225,37 @@ def test_tile_search_and_global_walk_are_bit_identical(reg, orc, monkeypatch):
     _same_stats(out[1][4], sto)
 
 
+def test_tall_grid_more_than_2048_voxels_in_z(reg, orc, monkeypatch):
+    """A grid of more than 2048 voxels along z (11 bits of bucket coordinate: ADVICE r2 — k_tile_build once packed the own buckets'
+    coordinates into 11 / 11 / 10-bit fields and staged the wrong neighbours above bucket 1023): two patches 205 m apart in z, the upper
+    one straddling voxel 2048. Tile search, global walk and oracle agree on every bit; the tile path really ran."""
+    def tower(seed):
+        lo = synth.planes_cloud(6000, seed, sigma=0.01, size=6.0)
+        hi = synth.planes_cloud(6000, seed + 1, sigma=0.01, size=6.0) + np.array([0.0, 0.0, 203.0], dtype=np.float32)
+        return np.concatenate([lo, hi]).astype(np.float32)
+    tgt = tower(900)
+    Tg = synth.make_T(synth.rot_z(np.radians(0.5)), np.array([0.05, -0.03, 0.04]))
+    src = synth.apply_T(synth.inv_T(Tg), tower(910).astype(np.float64)).astype(np.float32)
+    p = _params(leaf=0.1, iterations=6, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    ot, os_ = orc.Cloud(p, tgt), orc.Cloud(p, src)
+    assert ot.grid_info(0).dims[2] > 2048
+    To, sto, tro = orc.align(p, os_, ot, trace_cap=16)
+    q = synth.apply_T(Tg, src).astype(np.float32)
+    io, do = ot.nn(q, 0.5)
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("M3DREG_TILES", tiles)
+        R = reg.Registrar(p)
+        cs, ct = R.cloud(src), R.cloud(tgt)
+        _check_bucketing(ct, ot, 1)
+        i1, d1 = ct.nn(q, 0.5)
+        assert np.array_equal(i1, io) and np.array_equal(d1.view(np.uint32), do.view(np.uint32))
+        T, st = R.align(cs, ct)
+        assert np.array_equal(R.trace(), tro) and np.array_equal(T, To)
+        _same_stats(st, sto)
+        searched_in_tiles, _ = R.counters()
+        assert (searched_in_tiles > 0) == (tiles == "1")
+
+
 @pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
 def test_fused_late_iterations_are_bit_identical(reg, orc, monkeypatch, metric):
     """From the 12th iteration of a level on, search and reduction run as ONE launch (k_icp_late, M3DREG_FUSE_FROM); with 0 every
