@@ -74,20 +74,23 @@ def parse():
                     help="config4 (default, the headline): B loop-closure pairs per GPU per step; config3: the single 100k pair, point-to-plane, leaf 0.1; "
                          "config2: the single 70k pair, point-to-point, leaf 0.2, eps 1e-5 / 30 iterations; config5: 100k live scan against the 2 M-point map, "
                          "leaves 0.4 / 0.2 / 0.1 (own code path: run_config5)")
-    ap.add_argument("--multi-devices", default=None, help="single-process multi-device mode (m3dreg_multi_*): comma-separated device ordinals, e.g. 0,0 to rehearse "
-                                                         "two contexts on one GPU; implied by --gpus N > 1 without torchrun")
+    ap.add_argument("--multi-devices", default=None, help="single-process multi-device mode (m3dreg_multi_*: ONE process drives the listed devices through the C ABI, host "
+                                                         "payloads in, a different measurement from the contract's line): comma-separated device ordinals, e.g. 0,0 to rehearse "
+                                                         "two contexts on one GPU. Never implied: --gpus N > 1 without torchrun starts N rank processes instead")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes from this one even for --gpus 1 (what --gpus N > 1 does when torchrun did not): checks that "
+                                                         "the launcher adds nothing to the measurement")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
     return ap.parse_args()
 
 
 def run_multi(args):
-    """`python bench.py --gpus N` WITHOUT torchrun (WORLD_SIZE unset): ONE process drives N devices through the C ABI's m3dreg_multi_*
+    """`python bench.py --multi-devices 0,1,...` (explicit only): ONE process drives the listed devices through the C ABI's m3dreg_multi_*
     (include/m3dreg.h) — what a single gpu_6dslam_node on a multi-GPU host would do. A step = N x pairs-per-gpu pairs handed over as HOST
     PointCloud2 payloads: LPT assignment in C++, upload, bucketing and registration on every device, poses gathered in pair order, all
     inside the timed call — a PCIe-inclusive figure by construction (the contract's N > 1 line is the torchrun path above; this is the
     deployment the library offers beside it). --multi-devices 0,0 rehearses it on one GPU."""
     from mandala_mapping_amd import abi, binding, synth
-    devices = [int(x) for x in args.multi_devices.split(",")] if args.multi_devices else list(range(args.gpus))
+    devices = [int(x) for x in args.multi_devices.split(",")]
     params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
     n = args.pairs_per_gpu * len(devices)
     pairs, gts = [], []
@@ -115,12 +118,37 @@ def run_multi(args):
         "roofline": None, "cpu_baseline": None}))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` WITHOUT torchrun: this process — which has not touched the GPU and never will (it imports neither torch
+    nor the library) — starts N fresh rank processes of this same script, one per device, with the environment torchrun would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), so that every rank runs EXACTLY the per-rank code of the N = 1 line:
+    device-resident payloads, the same steps in flight, rendezvous over RCCL, max-over-ranks timing, rank 0 prints the one JSON line.
+    Children are started (subprocess), never exec'ed into; this process only waits and returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M3D_BENCH_RANK_PROCESS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))   # stdout / stderr inherited: rank 0's line is this run's line
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     args = parse()
     if args.workload == "config5":
         return run_config5(args)
-    if (args.gpus > 1 or args.multi_devices) and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if args.multi_devices:
         return run_multi(args)
+    if (args.gpus > 1 or args.spawn) and "M3D_BENCH_RANK_PROCESS" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return launch_ranks(args)
     import torch
     import torch.distributed as dist
     from mandala_mapping_amd import abi, binding, sharding, synth

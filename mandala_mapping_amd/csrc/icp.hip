@@ -690,8 +690,6 @@ struct M3dNnArgs {
                                        //           lower bound of every non-best candidate seen there (NN certificate)
     int certify;                       // 1 = use the NN certificates (default); 0 = always search (A/B, M3DREG_CERTIFY)
     float seed_reach;                  // seeds farther than this many voxel edges are not used (<= 0.99)
-    float skip_reach;                  // a query that moved farther than this many voxel edges since the previous iteration is searched afresh without
-                                       // looking at its certificate state or previous match (0 = never skip; any value gives identical results)
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
     int rot;                           // XCD rotation of the block -> pair map (m3d_map_block)
@@ -902,7 +900,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
 #endif
 // LEAN (k_nn_iter<true>, the tile iterations of a level whose target has tiles): classify + bin ONLY — every query that must search goes
 // to its tile's slab however few they are, and the rare one that cannot (a tile that could not be staged, a full slab, more than 64
-// tiles in one workgroup) goes to the pair's fallback list, which fallback work items of k_nn_tiles walk. Without the two walks compiled in the kernel
+// tiles in one workgroup) goes to the pair's fallback list, which k_nn_fallback walks. Without the two walks compiled in the kernel
 // needs 41 VGPRs instead of 124: 7 waves per SIMD instead of 4 — worth 4-6 % of the headline, where three chains compete for the
 // register file (alone it is only 2-5 us faster per launch).
 template <bool LEAN>
@@ -913,21 +911,6 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         if (ord && blk < J.src_nblk) blk = (int)ord[blk];
     }
     M3D_BT_BEGIN();
-    // the pose of the previous iteration (uniform: scalar registers) — where every query was then
-    float Rp[9], tp[3];
-    const float skip2 = first_of_level ? 0.f : (A.skip_reach * g.leaf) * (A.skip_reach * g.leaf);
-    if (skip2 > 0.f) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) Rp[3 * r + c] = m3d_uniform((float)st->Tp[c * 4 + r]);
-            tp[r] = m3d_uniform((float)st->Tp[12 + r]);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) Rp[k] = 0.f;
-        tp[0] = tp[1] = tp[2] = 0.f;
-    }
     __shared__ int s_cnt[4];
     __shared__ int s_list[LEAN ? 1 : 256];          // worklist of the cooperative walk: owner thread | seeded << 8 ...
     __shared__ float s_wu[3][LEAN ? 1 : 256];       // ... its transformed query ...
@@ -948,19 +931,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
-        // A query that the last pose update moved by more than skip_reach voxel edges cannot be certified (every margin is a fraction of the
-        // point spacing) and its previous match rarely seeds anything: it is searched like in a level's first iteration, WITHOUT reading
-        // its match, its 16-B certificate state or gathering the previous match's point — in the first iterations of a level that is
-        // nearly every query, and those three loads were two thirds of this kernel's traffic and one of its dependent round trips.
-        // Exact either way (a search is always exact; certificates and seeds only save work).
-        bool fresh = first_of_level != 0;
-        if (!fresh && skip2 > 0.f) {
-            const float vx = fmaf(Rp[0], p.x, fmaf(Rp[1], p.y, fmaf(Rp[2], p.z, tp[0]))) - ux;
-            const float vy = fmaf(Rp[3], p.x, fmaf(Rp[4], p.y, fmaf(Rp[5], p.z, tp[1]))) - uy;
-            const float vz = fmaf(Rp[6], p.x, fmaf(Rp[7], p.y, fmaf(Rp[8], p.z, tp[2]))) - uz;
-            fresh = !(vx * vx + vy * vy + vz * vz <= skip2);   // (NaN: fresh, and then rejected as non-finite below)
-        }
-        if (fresh) {
+        if (first_of_level) {
             if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i] = -1;
         } else {
             mp = out[i];
@@ -1101,17 +1072,11 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
             A.recd[r] = dseed;
         } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab (rare)
-            if constexpr (LEAN) {   // ... a fallback work item of k_nn_tiles walks it (no launch of its own: an empty one cost 5 us per iteration)
+            if constexpr (LEAN) {   // ... k_nn_fallback walks it
                 const uint32_t fslot = atomicAdd(&tcnt[A.ntile_max], 1u);   // (the counter behind the tiles'; the list holds every query of the pair if it must)
                 const size_t r = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP + fslot;
                 A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
                 A.recd[r] = dseed;
-                if ((fslot & (uint32_t)(M3D_TILE_CHUNK_CROWDED - 1)) == 0u) {   // the append that opens a chunk of 64 fallback records publishes its work item
-                    const uint32_t c = fslot / (uint32_t)M3D_TILE_CHUNK_CROWDED;
-                    const uint32_t wl = (c + (uint32_t)pair) & (uint32_t)(M3D_TILE_LISTS - 1);
-                    const uint32_t w = atomicAdd(A.wcount + 32u * wl, 1u);
-                    if (w < (uint32_t)A.wcap) A.witems[(size_t)wl * (size_t)A.wcap + w] = make_uint2((uint32_t)pair | 0x80000000u, c);
-                }
             } else {                // ... walked here, in global memory
                 long long code = 0; float sec = 0.f;
                 const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
@@ -1171,30 +1136,59 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     }
 }
 
-// A FALLBACK work item of k_nn_tiles: 64 of the records k_nn_iter<true> could not bin (a tile that cannot be staged, a full slab, more than
-// 64 tiles in one workgroup — normally there are none, and then there is no such item), walked in global memory eight lanes per record
-// like a late iteration's searches. No LDS, no barrier: the workgroup goes on to its next item. (The walk needs ~110 VGPRs, k_nn_tiles is
-// held to 80: it spills here, on the rarely executed path; as a call the kernel arguments went to scratch and the tile search spilled more.)
-__device__ __forceinline__ void m3d_fallback_item(const M3dJob& J, const M3dNnArgs& A, int pair, unsigned int chunk, int tid) {
-    const unsigned int nf = min((A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max], (unsigned int)A.match_stride);
-    const unsigned int wq = chunk * (unsigned int)M3D_TILE_CHUNK_CROWDED + ((unsigned int)tid >> 3);
-    const bool act = wq < nf;
-    const m3d_gf4 frec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP);
-    const float* frecd = A.recd + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
-    const float4 r4 = act ? m3d_ld(frec, (size_t)wq) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t e = __float_as_uint(r4.w);
-    long long fcode; float fsec;
-    const M3dGrid fg = J.tgt.g;
-    const int m = m3d_coop_query(fg, m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab)), m3d_as_global(J.tgt.pts), m3d_as_global(J.tgt.cbox),
-                                 m3d_as_global(J.tgt.bigcum), J.dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? frecd[wq] : 0.f, tid & 7, fcode, fsec, 0);
-    if (act && (tid & 7) == 0) {
-        const int qi = (int)(e & 0x7FFFFFFFu);
-        M3D_GLOBAL int* fout = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
-        fout[qi] = m;
-        if (m == M3D_NN_NONE_CACHED) ((M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride))[qi] = fcode;
-        if (m >= 0) ((M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride))[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, fsec };
+// k_nn_fallback: the queries k_nn_iter<true> could not bin, walked in global memory. Normally there are none: every workgroup reads
+// one counter and leaves. A few (a flagged tile here and there) are walked 8 lanes per query by the pair's first workgroups; many (a
+// level whose buckets hold more points than a tile image — the coarse levels of a dense map) one query per lane, all workgroups.
+#define M3D_FALLBACK_COOP_MAX 4096   // entries up to which the cooperative walk is used
+__global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    int pair, blk;
+    m3d_map_block(n_pairs, bpp, pair, blk, A.rot);
+    const unsigned int nf = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
+    if (nf == 0u) return;
+    const bool coop = nf <= (unsigned int)M3D_FALLBACK_COOP_MAX;
+    if ((coop ? 32u : 256u) * (unsigned int)blk >= nf) return;   // (block-uniform)
+    const M3dJob& J = jobs[pair];
+    const M3dPairState* st = A.states + pair;
+    if (st->done || (!first_of_level && st->level_done)) return;
+    const M3dGrid g = J.tgt.g;
+    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts), cbox = m3d_as_global(J.tgt.cbox);
+    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
+    const float dmax2 = J.dmax2;
+    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+    const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP);
+    const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
+    if (coop) {
+        const int sub = (int)threadIdx.x & 7;
+        for (unsigned int base = (unsigned int)blk * 32u; base < nf; base += 32u * (unsigned int)bpp) {   // (uniform per workgroup: the shuffles inside need every lane)
+            const unsigned int w = base + (threadIdx.x >> 3);
+            const bool act = w < nf;
+            const float4 r4 = act ? m3d_ld(rec, (size_t)w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t e = __float_as_uint(r4.w);
+            long long code; float sec;
+            const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? recd[w] : 0.f, sub, code, sec, 0);
+            if (act && sub == 0) {
+                const int qi = (int)(e & 0x7FFFFFFFu);
+                out[qi] = m;
+                if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+                if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
+            }
+        }
+    } else {
+        for (unsigned int w = (unsigned int)blk * 256u + threadIdx.x; w < nf; w += 256u * (unsigned int)bpp) {
+            const float4 r4 = m3d_ld(rec, (size_t)w);
+            const uint32_t e = __float_as_uint(r4.w);
+            long long code = 0; float sec = 0.f;
+            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, r4.x, r4.y, r4.z, dmax2, (e >> 31) != 0u, recd[w], code, sec, 0);
+            const int qi = (int)(e & 0x7FFFFFFFu);
+            out[qi] = m;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
+        }
     }
-    if (tid == 0) atomicAdd(&A.states[pair].ctr[1], min((unsigned int)M3D_TILE_CHUNK_CROWDED, nf - min(nf, chunk * (unsigned int)M3D_TILE_CHUNK_CROWDED)));
+    if (blk == 0 && threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], nf);
 }
 
 // k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
@@ -1220,15 +1214,11 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
     bool first_item = true;
     for (unsigned int it = blockIdx.x / (unsigned int)M3D_TILE_LISTS; it < n_items; it += gridDim.x / (unsigned int)M3D_TILE_LISTS) {
         const uint2 item = witems[it];
-        const int pair = (int)(item.x & 0x7FFFFFFFu), blk = (int)(item.y & 0xFFFFFu);
+        const int pair = (int)item.x, blk = (int)(item.y & 0xFFFFFu);
         const unsigned int chunk = item.y >> 20;
         const M3dJob& J = jobs[pair];
         const M3dPairState* st = A.states + pair;
         (void)st;
-        if ((item.x >> 31) != 0u) {   // a FALLBACK item (block-uniform; normally there are none)
-            m3d_fallback_item(J, A, pair, item.y, tid);
-            continue;
-        }
         M3D_TBT_BEGIN();
         const M3dGrid g = J.tgt.g;
         const float dmax2 = J.dmax2;
@@ -1418,7 +1408,6 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
         st->th2 = th2; st->tr2 = tr2;
         if (rc >= 0) { st->status = rc; done = 1; }
         else {
-            for (int i = 0; i < 16; i++) st->Tp[i] = T_pre ? T_pre[i] : st->T[i];   // the pose this iteration's queries were searched at (k_nn_iter: skip_reach)
             for (int i = 0; i < 16; i++) st->T[i] = T[i];
             if (th2 < J.eps_rot2 && tr2 < J.eps_trans2) {
                 if (J.last_level) { st->status = 0; done = 1; }
@@ -1749,7 +1738,7 @@ int m3d_ticket_words(int n_pairs, int max_n_src) {
 static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, const M3dNnWork& w,
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.skip_reach = w.skip_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
+    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
     A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
@@ -1771,6 +1760,12 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     if (w.tiles && !late && w.lean) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
+        // (a small grid: the list is normally empty and an empty launch costs what its workgroups take to be dispatched — 5.3 us with one per 256
+        //  queries; the workgroups stride over whatever the list holds)
+        static const int fb_bpp = [] { const char* v = getenv("M3DREG_FB_BPP"); const int q = v ? atoi(v) : 8; return q >= 1 ? q : 8; }();
+        const int bpp_f = bpp_s < fb_bpp ? bpp_s : fb_bpp;
+        hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_f * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_f, first_of_level, A);
+        M3D_DBG(s, "k_nn_fallback");
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");

@@ -116,7 +116,6 @@ struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
 
 struct M3dPairState {      // per-registration state, lives in HBM for the whole run (no host sync per iteration)
     double T[16];                  // current pose, column-major
-    double Tp[16];                 // the pose of the previous iteration of the level (where k_nn_iter's queries were one search ago)
     long long sums[M3D_NSUMS];     // fixed-point normal-equation sums of the running iteration
     double th2, tr2;               // |omega|^2, |v|^2 of the last update
     long long n_corr, ssr;         // of the last executed iteration

@@ -129,10 +129,9 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
     float seed_reach;            // seeds farther than this many voxel edges are not used (<= 0.99)
-    float skip_reach;            // queries moved farther than this many voxel edges by the last update skip the certificate check (M3DREG_SKIP_REACH, 0 = never)
     int rot;                     // XCD rotation of the block -> pair map: differs between handles, so concurrent batches do not stack their k-th pairs on one XCD
     int tiles;                   // 1 = dense blocks bin their searches by target tile and k_nn_tiles answers them from LDS (M3DREG_TILES)
-    int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only; what cannot be binned becomes fallback work items of k_nn_tiles); needs every target of the batch to have tiles (M3DREG_LEAN)
+    int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; needs every target of the batch to have tiles (M3DREG_LEAN)
     int ntile_max;               // tiles per pair the arrays below are laid out for
     float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP + stride] query records
     float* recd;                 // same layout: squared distance to the seed

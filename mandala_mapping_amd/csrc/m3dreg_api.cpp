@@ -123,9 +123,8 @@ struct m3dreg_handle {
     int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
     int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
     float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
-    float skip_reach = 0.5f;           // M3DREG_SKIP_REACH: a query the last update moved by more than this many voxel edges is searched afresh without reading its certificate state (0 = never; identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
-    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs; the rare query that cannot be binned becomes a fallback work item of k_nn_tiles) when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
+    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
     bool batch_all_tiles = false;
     int fuse_from = 10;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
     int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
@@ -595,7 +594,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     h->match_pairs = n_pairs;
     if (h->tiles) {   // workspace of the LDS-staged search: per pair, query records per tile + the global-walk list, and their counters
         const size_t ntile = size_t(m3d_tiles_of(max_n_tgt));
-        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;   // the tiles' slabs, then the fallback list (fallback work items of k_nn_tiles: it holds every query of the pair if it must)
+        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;   // the tiles' slabs, then the fallback list (k_nn_fallback: it holds every query of the pair if it must)
         const size_t cnt_stride = (ntile + 1 + 31) & ~size_t(31);
         if (n_pairs * rec_stride > h->rec_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -638,7 +637,6 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.certify = h->certify;
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
-    w.skip_reach = h->skip_reach;
     w.rot = h->xcd_rot;
     // (lean only for one-level registrations: a pyramid's coarse levels put more points into a bucket than a tile image holds, their queries would all
     // take the fallback list — config 5: 6.5 instead of 5.9 ms)
@@ -817,7 +815,6 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_LANE_MIN")) { int q = atoi(v); if (q >= 1 && q <= 257) h->lane_min = q; }
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
-    if (const char* v = getenv("M3DREG_SKIP_REACH")) { float q = float(atof(v)); if (q >= 0.f) h->skip_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_LEAN")) h->lean = atoi(v) != 0;
     if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }

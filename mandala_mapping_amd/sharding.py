@@ -38,37 +38,99 @@ def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = Non
     return [sorted(x) for x in out]
 
 
+class PoseGather:
+    """The one collective of the path, with everything it touches allocated ONCE: a ring of pinned host record blocks, their
+    device twins, the gathered block on the device and its pinned host copy, and a stream of its own. start() fills a pinned block
+    on the host and enqueues copy -> all_gather -> copy back on that stream without blocking the host (no pageable copy — those are
+    synchronous — and nothing on torch's default stream, which the registrations of a step do not use either); finish() waits for the
+    slot's event and unpacks. With gloo (CPU tensors, the tests and the one-GPU rehearsal) the same calls run on host memory."""
+
+    def __init__(self, n_total: int, dist, device=None, slots: int = 4):
+        import torch
+        self.torch, self.dist, self.device, self.n_total = torch, dist, device, n_total
+        self.world = dist.get_world_size()
+        self.cap = n_total   # upper bound on a shard; a record is 144 bytes, so 64 pairs x 8 ranks is ~74 KB in total
+        self.on_gpu = device is not None
+        self.slots, self.next = [], 0
+        for _ in range(slots):
+            rec_h = torch.empty((self.cap, 18), dtype=torch.float64)
+            out_h = torch.empty((self.world * self.cap, 18), dtype=torch.float64)
+            if self.on_gpu:
+                rec_h, out_h = rec_h.pin_memory(), out_h.pin_memory()
+                slot = dict(rec_h=rec_h, out_h=out_h, rec_d=torch.empty_like(rec_h, device=device), out_d=torch.empty_like(out_h, device=device),
+                            ev=torch.cuda.Event(), busy=False)
+            else:
+                slot = dict(rec_h=rec_h, out_h=out_h, rec_d=rec_h, out_d=out_h, ev=None, busy=False)
+            slot["rec_np"] = rec_h.numpy()   # (shares the pinned memory)
+            self.slots.append(slot)
+        self.stream = torch.cuda.Stream(device=device) if self.on_gpu else None
+
+    def start(self, local_idx: Sequence[int], local_T: np.ndarray, local_status: Sequence[int]):
+        s = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if s["busy"]:
+            raise RuntimeError("PoseGather: more gathers in flight than slots (finish the oldest first)")
+        a = s["rec_np"]
+        a.fill(-1.0)
+        k = len(local_idx)
+        if k:
+            a[:k, 0] = np.asarray(local_idx, np.float64)
+            a[:k, 1] = np.asarray(local_status, np.float64)
+            a[:k, 2:] = np.asarray(local_T, np.float64).reshape(k, 16)
+        if self.on_gpu:
+            torch = self.torch
+            with torch.cuda.stream(self.stream):
+                s["rec_d"].copy_(s["rec_h"], non_blocking=True)
+                work = self.dist.all_gather_into_tensor(s["out_d"], s["rec_d"], async_op=True)
+                work.wait()                                     # orders THIS stream behind the collective; the host does not block
+                s["out_h"].copy_(s["out_d"], non_blocking=True)
+                s["ev"].record(self.stream)
+            s["work"] = work
+        else:
+            s["work"] = self.dist.all_gather_into_tensor(s["out_d"], s["rec_d"], async_op=True)
+        s["busy"] = True
+        return s
+
+    def finish(self, s) -> Tuple[np.ndarray, np.ndarray]:
+        if self.on_gpu:
+            s["ev"].synchronize()
+        else:
+            s["work"].wait()
+        s["busy"] = False
+        a = s["out_h"].numpy()
+        T = np.zeros((self.n_total, 4, 4))
+        st = np.full(self.n_total, -1, np.int64)
+        rows = a[a[:, 0] >= 0]
+        idx = rows[:, 0].astype(np.int64)
+        T[idx] = rows[:, 2:].reshape(-1, 4, 4)
+        st[idx] = rows[:, 1].astype(np.int64)
+        return T, st
+
+
+_GATHERS = {}
+
+
+def _gather_for(n_total, dist, device):
+    key = (n_total, str(device), dist.get_world_size(), dist.get_rank())
+    g = _GATHERS.get(key)
+    if g is None:
+        g = _GATHERS[key] = PoseGather(n_total, dist, device)
+    return g
+
+
 def gather_results_start(local_idx: Sequence[int], local_T: np.ndarray, local_status: Sequence[int], n_total: int, dist, device=None):
     """Enqueue the all-gather of this rank's poses / status words and return a ticket for gather_results_finish.
-    ONE host->device copy and ONE collective; nothing here waits for the other ranks, so a caller that pipelines its
-    batches (bench.py) is not forced into lock-step with the slowest rank at every batch."""
-    import torch
-    world = dist.get_world_size()
-    cap = n_total   # upper bound on a shard; a record is 144 bytes, so 64 pairs x 8 ranks is ~74 KB in total
-    # the record block is assembled on the host (element-wise writes into a device tensor cost a launch each)
-    rec_h = np.full((cap, 18), -1.0, dtype=np.float64)
-    for j, i in enumerate(local_idx):
-        rec_h[j, 0] = float(i)
-        rec_h[j, 1] = float(local_status[j])
-        rec_h[j, 2:] = np.asarray(local_T[j], np.float64).reshape(16)
-    rec = torch.from_numpy(rec_h).to(device) if device is not None else torch.from_numpy(rec_h)
-    out = torch.empty((world * cap, 18), dtype=torch.float64, device=rec.device)
-    work = dist.all_gather_into_tensor(out, rec, async_op=True)
-    return (work, out, rec, n_total)
+    ONE pinned host->device copy, ONE collective, ONE copy back, all on the gather's own stream (PoseGather); nothing here waits for
+    the other ranks or for the device, so a caller that pipelines its batches (bench.py) is not forced into lock-step with the slowest
+    rank at every batch."""
+    g = _gather_for(n_total, dist, device)
+    return (g, g.start(local_idx, local_T, local_status))
 
 
 def gather_results_finish(ticket) -> Tuple[np.ndarray, np.ndarray]:
     """Wait for the collective of gather_results_start and unpack it into pair order: ([n_total,4,4], [n_total])."""
-    work, out, _rec, n_total = ticket
-    work.wait()
-    a = out.cpu().numpy()   # ONE device->host copy
-    T = np.zeros((n_total, 4, 4))
-    st = np.full(n_total, -1, np.int64)
-    rows = a[a[:, 0] >= 0]
-    idx = rows[:, 0].astype(np.int64)
-    T[idx] = rows[:, 2:].reshape(-1, 4, 4)
-    st[idx] = rows[:, 1].astype(np.int64)
-    return T, st
+    g, slot = ticket
+    return g.finish(slot)
 
 
 def gather_results(local_idx: Sequence[int], local_T: np.ndarray, local_status: Sequence[int], n_total: int,
