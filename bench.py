@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=100)   # (the driver passes --steps 20 --warmup 5)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20, help="fixed Gauss-Newton iterations per registration")
@@ -77,9 +77,14 @@ def parse():
     ap.add_argument("--multi-devices", default=None, help="single-process multi-device mode (m3dreg_multi_*: ONE process drives the listed devices through the C ABI, host "
                                                          "payloads in, a different measurement from the contract's line): comma-separated device ordinals, e.g. 0,0 to rehearse "
                                                          "two contexts on one GPU. Never implied: --gpus N > 1 without torchrun starts N rank processes instead")
+    ap.add_argument("--pageable", action="store_true", help="--multi-devices / --from-host: hand over PAGEABLE host payloads (default: pinned, m3dreg_host_alloc)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this one even for --gpus 1 (what --gpus N > 1 does when torchrun did not): checks that "
                                                          "the launcher adds nothing to the measurement")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
+    ap.add_argument("--min-seconds", type=float, default=1.5,
+                    help="the block of --steps timed steps is repeated (each block bracketed by barrier + synchronize on both sides, exactly --steps steps) "
+                         "until the blocks add up to this much wall time; the MEDIAN block is reported (0 = one block)")
+    ap.add_argument("--max-blocks", type=int, default=200)
     return ap.parse_args()
 
 
@@ -98,7 +103,7 @@ def run_multi(args):
         src, tgt, Tgt = synth.config4_pair(k, args.azimuth)
         pairs.append((src, tgt, None)); gts.append(Tgt)
     M = binding.MultiRegistrar(params, devices=devices)
-    descs, keep = M.describe(pairs, source_only=True)
+    descs, keep = M.describe(pairs, source_only=True, pinned=not args.pageable)   # pinned host payloads: asynchronous DMA; --pageable: staged through the device threads' pinned blocks
     for _ in range(max(1, args.warmup)):
         T, st, dev = M.align_described(descs)
     t0 = time.perf_counter()
@@ -176,10 +181,12 @@ def main():
     B, K, W = args.pairs_per_gpu, args.steps, args.warmup
     # fixed iteration count: eps = 0 never triggers, so every launch of the dominant kernel does full work
     if args.workload == "config2":   # 70 016 rays, point-to-point, leaf 0.2 m, d_max 1.0 m, eps 1e-5 or 30 iterations
-        args.iters, args.converge = 30, True
-        params = abi.Params.make(leaf=0.2, iterations=30, max_corr_dist=1.0, metric=abi.POINT_TO_POINT, eps_rot=1e-5, eps_trans=1e-5)
+        # coarse to fine FROM IDENTITY (the pair is 0.5 m / 3 deg apart): 0.8 / 0.4 / 0.2 m, the last level with a correspondence distance below the ring
+        # spacing — what point-to-point needs on ring-structured sweeps (tests/test_gpu_parity.py: CONFIG2, 0.076 deg / 1.0 cm)
+        args.iters, args.converge = 150, True
+        params = abi.Params.make(leaf=(0.8, 0.4, 0.2), iterations=(30, 30, 150), max_corr_dist=(2.0, 0.6, 0.2), metric=abi.POINT_TO_POINT, eps_rot=1e-5, eps_trans=1e-5)
         gen_pair = lambda k: synth.config2()
-        init_of = lambda Tgt: synth.perturb(Tgt, np.random.default_rng(2), 1.0, 0.1)   # an odometry prior: the 0.2 m voxels cannot bridge the pair's 0.5 m / 3 deg from identity
+        init_of = lambda Tgt: None   # identity
     else:
         params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE,
                                  normal_leaf=0.4, eps_rot=1e-5 if args.converge else 0.0, eps_trans=1e-5 if args.converge else 0.0)
@@ -226,6 +233,11 @@ def main():
         if rank == 0 and i < 8:
             host_pairs.append((src, tgt))
     torch.cuda.synchronize()
+    if args.from_host and not args.pageable:   # the payloads a producer hands over live in pinned memory: the copies are asynchronous DMA, not staged
+        pinned_views = [np.frombuffer(m.data, np.uint8) for m in host_msgs]
+        for v in pinned_views:
+            if binding.lib().m3dreg_host_register(C.c_void_p(v.ctypes.data), C.c_size_t(v.nbytes)) != 0:
+                raise SystemExit("m3dreg_host_register failed")
 
     last = {}
 
@@ -316,27 +328,45 @@ def main():
     import gc
     gc.collect()
     gc.disable()   # the host thread only enqueues and collects; a generation-2 collection in the middle of the region is a 40 ms stall (measured: -9 % at 300 steps)
-    barrier()
-    host_log.clear()
-    t0 = time.perf_counter()
-    run_steps(K)
-    barrier()
-    t1 = time.perf_counter()
+    # The block of exactly K timed steps (barrier + synchronize on both sides) is repeated until the blocks add up to --min-seconds: 20 steps
+    # are 23 ms, too short for anything outside this process (the driver's smi sampler) to see a busy GPU, and one block's value moves by a
+    # few per cent with whatever else the box does in those milliseconds. Reported: the MEDIAN block (steps = K as asked).
+    blocks = []
+    for r in regs:
+        r.profile_read(4, reset=True)
+    while True:
+        barrier()
+        host_log.clear()
+        t0 = time.perf_counter()
+        run_steps(K)
+        barrier()
+        t1 = time.perf_counter()
+        bt = t1 - t0
+        if world > 1:   # the same block list on every rank (max over ranks), so every rank takes the same decision to go on
+            tt = torch.tensor([bt], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bt = float(tt.item())
+        blocks.append(bt)
+        if sum(blocks) >= args.min_seconds or len(blocks) >= args.max_blocks:
+            break
     gc.enable()
     if args.trace_host and rank == 0:
         for what, i, a, b in host_log:
             print(f"[host] {what} step {i}: {a:.3f} ms" + (f" bucketing, {b:.3f} ms enqueue of the iterations" if what == "enq" else ""), file=sys.stderr)
-    launches = kern_ms = iters_timed = iter_ms = buck_n = buck_ms = 0
+    launches = kern_ms = iters_timed = iter_ms = buck_n = buck_ms = chain_n = chain_ms = 0
     for r in regs:
         a, b = r.profile_read(1, reset=True)       # the correspondence step (k_nn_iter + k_nn_tiles) alone
         c, d = r.profile_read(0, reset=True)       # correspondence step + reduction + solve of one linearisation
         e_, f_ = r.profile_read(2, reset=True)     # one bucketing batch
+        g_, h_ = r.profile_read(4, reset=True)     # ALL iterations of a batch as they ship (fused late launches included): iterations, ms
         launches, kern_ms, iters_timed, iter_ms, buck_n, buck_ms = launches + a, kern_ms + b, iters_timed + c, iter_ms + d, buck_n + e_, buck_ms + f_
+        chain_n, chain_ms = chain_n + g_, chain_ms + h_
         r.profile_enable(False)
     # After the timed region, untimed: the same kernel with NOTHING else on the GPU (one step, one handle, every launch bracketed).
     # With several chains sharing the GPU a launch takes longer although more launches complete per second; this is the kernel's own
     # duration, reported beside the contract's figure as roofline.alone.
-    alone_ms = alone_iter_ms = alone_bucket_ms = 0.0
+    alone_ms = alone_iter_ms = alone_bucket_ms = alone_chain_ms = 0.0
+    gather_model = None
     if not args.no_events and world == 1:
         last_T, last_st = last.get("T"), last.get("st")
         regs[0].profile_enable(True, every=1)
@@ -351,13 +381,34 @@ def main():
         regs[0].profile_enable(False)
         alone_ms = b_ / max(1, a_)
         alone_iter_ms, alone_bucket_ms = bi_ / max(1, ai_), bb_ / max(1, ab_)
+        # the shipped schedule alone (no per-iteration brackets: the late iterations run fused): one more untimed step, one bracket around its chain
+        regs[0].profile_enable(True, every=1 << 30)
+        regs[0].profile_read(4, reset=True)
+        regs[0].align_batch_async(regs[0]._pairs([(s_, t_, inits[j]) for j, (s_, t_) in enumerate(c_)]), B)
+        regs[0].batch_wait(B)
+        ac_, bc_ = regs[0].profile_read(4, reset=True)
+        regs[0].profile_enable(False)
+        alone_chain_ms = bc_ / max(1, ac_)
+        # SURVEY 8d "gather-model bytes": 12 N k + 8 * 27 N per pair, k = mean number of candidates the spec names per query (all points of its 27
+        # voxels; measured at the initial and at the final pose — the searches prune most of them, the certificates skip most searches)
+        if host_pairs and args.workload != "config5":
+            try:
+                gm = {}
+                T_end = last_T[0] if last_T is not None else np.eye(4)
+                T_ini = inits[0] if inits[0] is not None else np.eye(4)
+                tcl = regs[0].cloud(host_pairs[0][1])
+                nlv = tcl.levels() if hasattr(tcl, "levels") else 1
+                for nm, Tq in (("initial_pose", T_ini), ("final_pose", T_end)):
+                    q = synth.apply_T(Tq, host_pairs[0][0]).astype(np.float32)
+                    kbar = float(np.mean(tcl.candidates(q, level=nlv - 1)))
+                    gm[nm] = {"mean_candidates_per_query": kbar, "bytes_per_launch": int(sum((12.0 * kbar + 8 * 27) * s_.n for s_, _ in c_))}
+                gather_model = gm
+                del tcl
+            except Exception as ex:   # diagnostics only: never fail the bench line over them
+                gather_model = {"error": repr(ex)}
         del c_
         last["T"], last["st"] = last_T, last_st
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sorted(blocks)[len(blocks) // 2]   # the median block (already the max over ranks)
 
     # sanity of the timed work: poses against the generator's ground truth
     errs = [synth.pose_error(last["T"][i], gts[i]) for i in range(B)]
@@ -368,50 +419,68 @@ def main():
         value = total_regs / elapsed
         avg_launch_s = (kern_ms / 1e3) / max(1, launches)
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
+        traffic = l2_hit = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 traffic = sum(j.get(k, {}).get("hbm_bytes_per_iteration", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
+                l2_hit = {k: j[k]["l2_hit_rate"] for k in ("k_nn_iter", "k_nn_tiles", "k_accumulate_matches", "k_icp_late") if k in j and "l2_hit_rate" in j[k]} or None
             except Exception:
-                traffic = None
+                traffic = l2_hit = None
         in_region = achieved
         alone = alg_bytes / (alone_ms / 1e3) / 1e9 if alone_ms > 0 else 0.0
+        # one whole linearisation of the SHIPPED schedule (correspondence step + residuals + reduction + solve; fused k_icp_late launches included):
+        # mean over every iteration of every batch of the timed region, one event bracket per batch (M3DREG_PROFILE_CHAIN)
+        chain_iter_ms = chain_ms / max(1, chain_n)
+        iteration_gbps = alg_bytes_iter / (chain_iter_ms / 1e3) / 1e9 if chain_iter_ms > 0 else 0.0
+        alone_iteration_gbps = alg_bytes_iter / (alone_chain_ms / 1e3) / 1e9 if alone_chain_ms > 0 else 0.0
         workload = {"config4": f"BASELINE config 4 shard: {B} HDL-32-shaped scan pairs per GPU per step, ",
                     "config3": "BASELINE config 3: the single HDL-32-shaped scan pair (seeds 100 / 101), one registration per step, ",
-                    "config2": "BASELINE config 2: the single 70 016-ray HDL-32-shaped scan pair (seeds 100 / 101), one registration per step, "}[args.workload]
+                    "config2": "BASELINE config 2: the single 70 016-ray HDL-32-shaped scan pair (seeds 100 / 101), one registration per step from identity, "}[args.workload]
         out = {
             "metric": "scan-pair registrations/sec (100k-pt clouds, point-to-plane, 0.1 m voxel NN)",
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (int64 fixed-point sums, f64 solve)", "data": "synthetic",
+            "blocks": {"n": len(blocks), "steps_per_block": K, "median_ms": 1e3 * elapsed, "min_ms": 1e3 * min(blocks), "max_ms": 1e3 * max(blocks),
+                       "note": "the block of `steps` timed steps is repeated until the blocks add up to --min-seconds; value / ms_per_step are the MEDIAN block's"},
             "config": {"workload": workload +
                                    f"{n_pts} pts/cloud (as m3d_aggregator publishes the sweeps: its +-1 m self-filter box applied), " +
-                                   ("point-to-point, leaf 0.2 m, eps 1e-5 / at most 30 iterations, " if args.workload == "config2" else
+                                   ("point-to-point, leaves 0.8 / 0.4 / 0.2 m, eps 1e-5 / at most 30 + 30 + 150 iterations, " if args.workload == "config2" else
                                     f"point-to-plane, leaf 0.1 m, {args.iters} " + ("iterations at most (eps 1e-5), " if args.converge else "fixed iterations, ")) +
                                    "decode of both clouds, sort of the source (m3dreg_cloud_desc.source_only), bucketing + tile images + normals of the target inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step",
                        "overlap": ("none (serial steps)" if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
                                   (f"; {Q} steps queued per stream" if Q > 1 else "")},
-            "ms_per_icp_iter_batch": iter_ms / max(1, iters_timed),
-            "ms_per_icp_iter_per_pair": iter_ms / max(1, iters_timed) / B,
-            "ms_per_icp_iter_batch_alone": alone_iter_ms,
+            "ms_per_icp_iter_batch": chain_iter_ms if chain_iter_ms > 0 else iter_ms / max(1, iters_timed),
+            "ms_per_icp_iter_per_pair": (chain_iter_ms if chain_iter_ms > 0 else iter_ms / max(1, iters_timed)) / B,
+            "ms_per_icp_iter_batch_alone": alone_chain_ms if alone_chain_ms > 0 else alone_iter_ms,
+            "ms_per_icp_iter_batch_bracketed_chain": iter_ms / max(1, iters_timed),
             "ms_bucketing_batch": buck_ms / max(1, buck_n), "ms_bucketing_batch_alone": alone_bucket_ms,
-            "iteration_algorithmic_GBps": (alg_bytes_iter / (iter_ms / max(1, iters_timed) / 1e3) / 1e9) if iter_ms > 0 else 0.0,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (the correspondence step of one Gauss-Newton iteration: two launches, one event bracket; an un-bracketed iteration >= 10 of a level runs fused with the reduction as k_icp_late)",
-                         "achieved": alone if alone_ms > 0 else in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (alone if alone_ms > 0 else in_region) / HBM_PEAK_GBS,
-                         "avg_launch_ms": alone_ms if alone_ms > 0 else 1e3 * avg_launch_s,
-                         "frac_source": ("one extra, untimed step after the timed region with nothing else on the GPU, every iteration bracketed: what a rocprofv3 "
-                                         "kernel trace of serial steps shows (profiles/)" if alone_ms > 0 else "inside the timed region"),
+            # ONE definition, kept from round to round: frac = the correspondence step INSIDE the timed region (what the timed region ran, several
+            # chains sharing the GPU, sampled brackets); `alone` = the same bracket with nothing else on the GPU; `iteration` = a whole linearisation
+            # of the shipped schedule (fused late launches included) on its algorithmic bytes
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter (+ k_nn_fallback) + k_nn_tiles: the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
+                                                    "runs as the launch chain; un-bracketed iterations >= 10 of a level run fused with the reduction as k_icp_late: see `iteration`)",
+                         "achieved": in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": in_region / HBM_PEAK_GBS,
+                         "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches, "concurrent_chains": D,
+                         "frac_source": "hipEvent brackets inside the timed region (every --event-every-th iteration), on the library's stream",
                          "traffic": traffic, "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_gpu.sh, not measured in this run)",
+                         "l2_hit_rate": l2_hit,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "in_region": {"concurrent_chains": D, "avg_launch_ms": 1e3 * avg_launch_s, "achieved": in_region, "frac": in_region / HBM_PEAK_GBS,
-                                       "launches_timed": launches}},
+                         "gather_model": gather_model,
+                         "alone": {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS,
+                                   "source": "one extra, untimed step after the timed region with nothing else on the GPU, every iteration bracketed: what a rocprofv3 kernel trace of serial steps shows (profiles/)"},
+                         "iteration": {"what": "one whole linearisation of the shipped schedule: correspondence step + residuals + 29-term reduction + solve (k_icp_late where it runs)",
+                                       "algorithmic_bytes": alg_bytes_iter, "avg_ms": chain_iter_ms, "achieved": iteration_gbps, "frac": iteration_gbps / HBM_PEAK_GBS,
+                                       "iterations_timed": chain_n,
+                                       "alone": {"avg_ms": alone_chain_ms, "achieved": alone_iteration_gbps, "frac": alone_iteration_gbps / HBM_PEAK_GBS}},
+                         # kept for continuity with rounds 1-2 (same numbers as roofline.frac / roofline.alone):
+                         "in_region": {"concurrent_chains": D, "avg_launch_ms": 1e3 * avg_launch_s, "achieved": in_region, "frac": in_region / HBM_PEAK_GBS, "launches_timed": launches}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, host_pairs, args.iters, args.cpu_threads)
@@ -434,6 +503,7 @@ def extra_legs(args):
         "serial": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1"],
         "from_host": ["--steps", "40", "--warmup", "3", "--from-host"],
         "converge": ["--steps", "40", "--warmup", "3", "--converge"],
+        "from_host_converge": ["--steps", "40", "--warmup", "3", "--from-host", "--converge"],   # SURVEY 8d's literal "registrations/s": H2D of both clouds + bucketing + iterations to eps 1e-5 (at most --iters) + D2H
         "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1", "--event-every", "1"],
         "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1", "--event-every", "1"],
         "config5": ["--workload", "config5", "--steps", "10", "--warmup", "2"],
@@ -441,7 +511,7 @@ def extra_legs(args):
     legs = {}
     for name, extra in runs.items():
         try:
-            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(base + extra + ["--min-seconds", "0.5"], capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 legs[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -451,8 +521,8 @@ def extra_legs(args):
                                       "iterations_executed_pair0", "max_rot_err_deg", "max_trans_err_m") if k in d}
             keep["workload"] = d.get("config", {}).get("workload")
             if "roofline" in d:
-                keep["roofline"] = {k: d["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "unit")}
-            for k in ("levels", "map_points", "bucket_map_ms", "registration_ms"):
+                keep["roofline"] = {k: d["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "unit", "alone", "iteration")}
+            for k in ("levels", "map_points", "bucket_map_ms", "bucket_map_wall_ms", "registration_ms", "blocks"):
                 if k in d:
                     keep[k] = d[k]
             legs[name] = keep
@@ -472,13 +542,18 @@ def run_config5(args):
     p = abi.Params.make(leaf=leaves, iterations=(10, 10, 10), max_corr_dist=dmaxs, metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
     live, mp, Tgt, T0 = synth.config5()
     R = binding.Registrar(p)
+    R.profile_enable(True, every=1 << 30)              # (only the bucketing bracket matters here)
     t0 = time.perf_counter()
     tgt = R.cloud(mp)
     R.synchronize()
-    bucket_ms = 1e3 * (time.perf_counter() - t0)       # includes the H2D copy of 32 MB and the first-touch allocations
+    bucket_wall_ms = 1e3 * (time.perf_counter() - t0)  # wall clock: includes the pageable H2D copy of the 24 MB payload and the first-touch allocations
+    R.profile_read(2, reset=True)
     t0 = time.perf_counter()
     tgt2 = R.cloud(mp); R.synchronize()
-    bucket_ms = min(bucket_ms, 1e3 * (time.perf_counter() - t0))
+    bucket_wall_ms = min(bucket_wall_ms, 1e3 * (time.perf_counter() - t0))
+    nb_, mb_ = R.profile_read(2, reset=True)
+    bucket_ms = mb_ / max(1, nb_)                      # the bucketing pipeline itself: hipEvents on the library's stream around its kernels (three levels + normal grid + tiles)
+    R.profile_enable(False)
     tgt2.free()
     src = R.clouds([live], source_only=[True])[0]
     times = []
@@ -519,7 +594,7 @@ def run_config5(args):
         "higher_is_better": True, "scaling": "replicas only", "vs_baseline": None, "dtype": "f32 (int64 fixed-point sums, f64 solve)", "data": "synthetic",
         "config": {"workload": f"BASELINE config 5: {live.shape[0]}-point live scan against a {mp.shape[0]}-point map, leaves 0.4 / 0.2 / 0.1 m x 10 iterations, "
                                "point-to-plane; the map is bucketed once (outside the timed region), the scan is decoded and sorted inside it"},
-        "map_points": int(mp.shape[0]), "bucket_map_ms": bucket_ms, "registration_ms": reg_ms, "levels": levels,
+        "map_points": int(mp.shape[0]), "bucket_map_ms": bucket_ms, "bucket_map_wall_ms": bucket_wall_ms, "registration_ms": reg_ms, "levels": levels,
         "ms_per_icp_iter_batch": sum(x["ms_per_icp_iter"] for x in levels) / 3.0,
         "max_rot_err_deg": rot, "max_trans_err_m": tra, "iterations_executed_pair0": int(st.iterations),
         "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles, finest level", "achieved": fin["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -35,11 +35,13 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 3   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+#define M3DREG_ABI_VERSION 4   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
                                      M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
                                   3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
                                      exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
-                                     m3dreg_debug_accumulate / _trace refuse to run while a batch is pending */
+                                     m3dreg_debug_accumulate / _trace refuse to run while a batch is pending
+                                  4: + m3dreg_host_alloc / _free / _register / _unregister (pinned payloads); m3dreg_multi_align runs one host thread
+                                     per device; m3dreg_default_params is a coarse-to-fine pyramid (see there) */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -214,6 +216,23 @@ int m3dreg_multi_destroy(m3dreg_multi* m);
 int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_pairs, float* out_T /* 16 * n_pairs */,
                        m3dreg_stats* stats /* n_pairs, may be NULL */, int32_t* device_of_pair /* n_pairs, may be NULL: where each pair ran */);
 const char* m3dreg_multi_last_error(const m3dreg_multi* m);
+/* (ABI 4) Inside, every listed device has its own host thread, which uploads, buckets, registers and collects its shard, so the
+ * devices' uploads and enqueues run side by side (one host thread + one HIP stream per device). The call itself is
+ * synchronous and may be made from any ONE thread at a time per context. Host payloads cross PCIe from pinned memory: a payload
+ * that lives in memory from m3dreg_host_alloc (or registered with m3dreg_host_register, or pinned by any other HIP call of the
+ * process) is copied by the DMA engine as it is, asynchronously; a pageable one is first copied into the device thread's pinned
+ * staging block. No exception and no half-enqueued state survive an error: whatever a device thread enqueued is waited for, its
+ * clouds are released and its handle is idle again before the call returns (M3DREG_ERR_OUT_OF_MEMORY: the context stays usable). */
+
+/* ---- pinned host memory without linking HIP ---------------------------------------------------------------------------------
+ * A PointCloud2 payload handed over from pageable memory is copied synchronously and staged by the runtime; from pinned memory the
+ * copy is asynchronous (it overlaps the previous batch's kernels and the other devices' copies). m3dreg_host_alloc / _free wrap
+ * hipHostMalloc / hipHostFree (portable: valid for every device), m3dreg_host_register / _unregister pin an existing range in place
+ * (the ROS shim's message buffers, a bag reader's pool). Every entry point that takes a host payload accepts either kind. */
+int m3dreg_host_alloc(size_t bytes, void** out);
+int m3dreg_host_free(void* p);
+int m3dreg_host_register(void* p, size_t bytes);
+int m3dreg_host_unregister(void* p);
 
 /* ---- aggregation on the device ---------------------------------------------
  * The step m3d_aggregator performs before publishing a cloud (m3d/m3d_aggregator/src/m3d_aggregator.cpp):
@@ -297,6 +316,8 @@ int m3dreg_profile_enable(m3dreg_handle* h, int on);
 #define M3DREG_PROFILE_DOMINANT_KERNEL 1  /* its correspondence step (a6) */
 #define M3DREG_PROFILE_BUCKETING 2        /* one bucketing batch (a2-a4, a9, tiles): m3dreg_cloud_create* */
 #define M3DREG_PROFILE_REDUCE_SOLVE 3     /* a7 + a8 of the bracketed iterations (= ITERATION - DOMINANT_KERNEL) */
+#define M3DREG_PROFILE_CHAIN 4            /* ALL iterations of a batch as they ship (fused late launches included), one bracket per batch:
+                                             n_launches counts the iterations enqueued, total_ms / n_launches = mean time of a whole linearisation */
 /* Synchronises the stream, returns the number of bracketed launches of kind `what` and the sum of their
  * durations since the last reset; `reset` != 0 clears that kind's counters. */
 int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset);
@@ -330,6 +351,10 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
  * level of a bucketed cloud: out_idx[i] = INPUT index of the match or -1, out_d2[i] = squared distance. */
 int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, const float* queries_xyz,
                     size_t nq, float max_corr_dist, int32_t* out_idx, float* out_d2);
+/* How many candidates the spec names for every query: the points of the 27 voxels around it (what an exhaustive search compares;
+ * the product's searches prune most of them). bench.py's gather-model bytes use its mean. */
+int m3dreg_debug_candidates(m3dreg_handle* h, const m3dreg_cloud* target, int level, const float* queries_xyz,
+                            size_t nq, int32_t* out_count);
 /* One linearisation at pose T (no update): the 29 fixed-point sums and their power-of-two exponents
  * (value = sum * 2^-exp; exps[6] = rr, rt, tt, gr, gt, ss). */
 int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,

@@ -35,6 +35,7 @@ EXPORTS = [
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
     "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error",
     "m3dreg_debug_fail_alloc", "m3dreg_debug_throw",
+    "m3dreg_debug_candidates", "m3dreg_host_alloc", "m3dreg_host_free", "m3dreg_host_register", "m3dreg_host_unregister",
 ]
 
 
@@ -75,6 +76,11 @@ def lib():
     L.m3dreg_batch_wait.argtypes = [vp, f32p, C.POINTER(abi.Stats)]
     L.m3dreg_synchronize.argtypes = [vp]
     L.m3dreg_get_stream.argtypes = [vp]
+    L.m3dreg_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.m3dreg_debug_candidates.argtypes = [vp, vp, C.c_int, f32p, sz, C.POINTER(C.c_int32)]
+    L.m3dreg_host_free.argtypes = [vp]
+    L.m3dreg_host_register.argtypes = [vp, sz]
+    L.m3dreg_host_unregister.argtypes = [vp]
     L.m3dreg_get_stream.restype = vp
     L.m3dreg_cloud_levels.argtypes = [vp]
     L.m3dreg_cloud_grid_info.argtypes = [vp, vp, C.c_int, C.POINTER(abi.GridInfo)]
@@ -180,6 +186,14 @@ class Cloud:
         self._reg._check(lib().m3dreg_debug_nn(self._reg._h, self._p, level, _ptr(q, C.c_float), len(q), max_corr_dist,
                                                _ptr(idx, C.c_int32), _ptr(d2, C.c_float)), "debug_nn")
         return idx, d2
+
+
+    def candidates(self, queries, level=0):
+        """points in the 27 voxels around every query (what the spec's exhaustive search compares)"""
+        q = np.ascontiguousarray(queries, np.float32)
+        cnt = np.empty(len(q), np.int32)
+        self._reg._check(lib().m3dreg_debug_candidates(self._reg._h, self._p, level, _ptr(q, C.c_float), len(q), _ptr(cnt, C.c_int32)), "debug_candidates")
+        return cnt
 
 
 class Registrar:
@@ -369,6 +383,26 @@ class Registrar:
         return np.stack([colmajor16_to_T(buf[i]) for i in range(k)]) if k else np.zeros((0, 4, 4))
 
 
+class PinnedBuffer:
+    """bytes of pinned host memory from m3dreg_host_alloc (freed with the object)"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        rc = lib().m3dreg_host_alloc(C.c_size_t(nbytes), C.byref(self.ptr))
+        if rc != 0:
+            self.ptr = None
+            raise abi.M3dregError(rc, "m3dreg_host_alloc")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().m3dreg_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class MultiRegistrar:
     """m3dreg_multi: ONE process, several devices (or several streams of one). Pairs are given as raw PointCloud2 payloads
     (numpy (n, 3) float32 arrays are encoded the aggregator's way); the library shards, uploads, registers and gathers."""
@@ -394,9 +428,10 @@ class MultiRegistrar:
         except Exception:
             pass
 
-    def describe(self, pairs, source_only=False):
+    def describe(self, pairs, source_only=False, pinned=False):
         """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (descriptor array, buffers to keep alive): host PointCloud2 payloads, encoded the
-        aggregator's way; source_only: the sources are only sorted (m3dreg_cloud_desc.source_only)."""
+        aggregator's way; source_only: the sources are only sorted (m3dreg_cloud_desc.source_only); pinned: the payloads live in
+        m3dreg_host_alloc memory (asynchronous DMA, no staging copy) instead of pageable memory."""
         from .pointcloud2 import encode_xyz
         n = len(pairs)
         descs = (abi.PairDesc * n)()
@@ -404,9 +439,16 @@ class MultiRegistrar:
         for i, (src, tgt, T0) in enumerate(pairs):
             for d, xyz, so in ((descs[i].source, src, source_only), (descs[i].target, tgt, False)):
                 msg = encode_xyz(np.ascontiguousarray(xyz, np.float32))
-                buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
-                keep.append(buf)
-                d.data = C.cast(buf, C.c_void_p); d.n = msg.n; d.point_step = msg.point_step
+                if pinned:
+                    buf = PinnedBuffer(len(msg.data))
+                    C.memmove(buf.ptr, bytes(msg.data), len(msg.data))
+                    keep.append(buf)
+                    d.data = buf.ptr
+                else:
+                    buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
+                    keep.append(buf)
+                    d.data = C.cast(buf, C.c_void_p)
+                d.n = msg.n; d.point_step = msg.point_step
                 d.off_x, d.off_y, d.off_z = 0, 4, 8
                 d.data_is_device = 0; d.source_only = 1 if so else 0
             t0 = T_to_colmajor16(np.eye(4) if T0 is None else T0)

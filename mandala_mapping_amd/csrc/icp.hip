@@ -1706,6 +1706,26 @@ __global__ __launch_bounds__(256) void k_debug_nn(M3dLevelDev L, const float* __
     out_idx[i] = idx; out_d2[i] = d2;
 }
 
+// ---- introspection: how many candidates the spec names for a query (all points of the 27 voxels around it) -----------------
+// bench.py's gather-model bytes (12 N k + 8 * 27 N with k = mean candidates per query, measured)
+__global__ __launch_bounds__(256) void k_debug_candidates(M3dLevelDev L, const float* __restrict__ q, int nq, int32_t* __restrict__ out_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float ux = q[3 * i], uy = q[3 * i + 1], uz = q[3 * i + 2];
+    int32_t c = 0;
+    M3dQuery Q;
+    if (m3d_finite3(ux, uy, uz) && m3d_query_setup(L.g, ux, uy, uz, Q))
+        for (int vz = Q.lo[2]; vz <= Q.hi[2]; vz++)
+            for (int vy = Q.lo[1]; vy <= Q.hi[1]; vy++)
+                for (int vx = Q.lo[0]; vx <= Q.hi[0]; vx++) { const uint2 r = m3d_find_voxel(L, vx, vy, vz); c += (int32_t)(r.y - r.x); }
+    out_cnt[i] = c;
+}
+hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, int32_t* out_cnt) {
+    hipLaunchKernelGGL(k_debug_candidates, dim3((nq + 255) / 256), dim3(256), 0, s, L, q_xyz, nq, out_cnt);
+    M3D_DBG(s, "k_debug_candidates");
+    return hipGetLastError();
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 // blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
 __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }

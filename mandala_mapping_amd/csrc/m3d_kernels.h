@@ -151,5 +151,6 @@ hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int
 int m3d_ticket_words(int n_pairs, int max_n_src);
 int m3d_acc_blocks(int max_n_src, int n_pairs);   // workgroups per pair of the reduction pass (sizes M3dNnWork::partials)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w);
+hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, int32_t* out_cnt);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,
                                float* out_d2);

@@ -18,7 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -150,8 +155,9 @@ struct m3dreg_handle {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_kind;          // per recorded event: 0 = before the dominant kernel (= start of an iteration), 1 = after it, 2 = end of the batch
     size_t ev_used = 0;
-    uint64_t prof_launches[4] = { 0, 0, 0, 0 };   // M3DREG_PROFILE_*: iteration, correspondence step, bucketing batch, reduce + solve
-    double prof_ms[4] = { 0.0, 0.0, 0.0, 0.0 };
+    uint64_t prof_launches[5] = { 0, 0, 0, 0, 0 };   // M3DREG_PROFILE_*: iteration, correspondence step, bucketing batch, reduce + solve, all iterations of a batch (launches = iterations enqueued)
+    double prof_ms[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+    uint64_t chain_iters = 0;          // iterations enqueued between the open kind-5 event and its kind-6 partner
 };
 
 namespace {
@@ -314,7 +320,10 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     const int grids_per_cloud = P.n_levels + (want_normals ? 1 : 0);
     const size_t n_builds = k * size_t(grids_per_cloud);
     std::vector<m3dreg_cloud*> cl(k, nullptr);
-    auto cleanup = [&]() { hipStreamSynchronize(h->stream); for (m3dreg_cloud* c : cl) free_cloud(h, c); };
+    auto cleanup = [&]() { hipStreamSynchronize(h->stream); for (m3dreg_cloud*& c : cl) { free_cloud(h, c); c = nullptr; } };
+    // a throw anywhere below (a host allocation: std::vector, new — also AFTER the pipeline was enqueued) gives every block back
+    // before it leaves: the clouds are not the caller's yet (they leaked, with their HBM, when alloc_point() / new threw late)
+    struct Guard { decltype(cleanup)& f; bool armed = true; ~Guard() { if (armed) f(); } } guard{ cleanup };
     size_t max_n = 0;
     for (size_t i = 0; i < k; i++) {
         alloc_point();
@@ -473,6 +482,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         cl[i]->owner = h; h->live_clouds++; cl[i]->ready = br; br->refs++; cl[i]->meta_ready = false; cl[i]->err = 0;
         out[i] = cl[i];
     }
+    guard.armed = false;
     return M3DREG_OK;
 }
 
@@ -715,12 +725,14 @@ hipEvent_t next_event(m3dreg_handle* h) {
 // iteration (search + reduction + solve) — two event records per iteration instead of four (each one is a barrier packet
 // on the queue and cost ~4 us of the ~60 us iterations it was measuring).
 void drain_events(m3dreg_handle* h) {
-    hipEvent_t k0 = nullptr, k1 = nullptr, b0 = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr, b0 = nullptr, c0 = nullptr;
     for (size_t i = 0; i < h->ev_used && i < h->ev_kind.size(); i++) {
         float ms = 0.f;
         const int kind = h->ev_kind[i];
         hipEvent_t e = h->ev_pool[i];
         if (kind == 3) { b0 = e; continue; }   // bucketing batch: begin / end
+        if (kind == 5) { c0 = e; continue; }   // all iterations of a batch (the SHIPPED schedule, fused launches included): begin / end
+        if (kind >= 6) { if (c0 && hipEventElapsedTime(&ms, c0, e) == hipSuccess) { h->prof_ms[4] += double(ms); h->prof_launches[4] += uint64_t(kind - 6); } c0 = nullptr; continue; }   // kind = 6 + iterations enqueued
         if (kind == 4) { if (b0 && hipEventElapsedTime(&ms, b0, e) == hipSuccess) { h->prof_ms[2] += double(ms); h->prof_launches[2]++; } b0 = nullptr; continue; }
         if (kind == 1) { k1 = e; if (k0 && hipEventElapsedTime(&ms, k0, e) == hipSuccess) { h->prof_ms[1] += double(ms); h->prof_launches[1]++; } continue; }
         // kind 0 (start of a bracketed iteration) or 2 (end of one): both close the iteration that k0 opened
@@ -787,7 +799,13 @@ int m3dreg_default_params(m3dreg_params* p) {
     return m3d_guarded(nullptr, "m3dreg_default_params", [&]() -> int {
     if (!p) return M3DREG_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));
-    p->n_levels = 1; p->leaf[0] = 0.1f; p->iterations[0] = 30; p->max_corr_dist[0] = 0.5f;
+    // Coarse to fine (ABI 4; was a single 0.1 m level): the node is launched WITHOUT parameters (m3d_husky_bringup.launch:13), so the defaults
+    // must register what a rotating-lidar unit on a moving platform produces. Measured on the synthetic HDL-32 pairs (oracle == HIP): the
+    // single level converges up to 1.0 m / 6 deg of initial offset and is lost at 1.5 m / 10 deg; 0.4 m -> 0.1 m converges up to 2.0 m /
+    // 15 deg to the same 0.001 m / 0.04 deg, at the price of one more grid per cloud.
+    p->n_levels = 2;
+    p->leaf[0] = 0.4f; p->iterations[0] = 20; p->max_corr_dist[0] = 1.5f;
+    p->leaf[1] = 0.1f; p->iterations[1] = 20; p->max_corr_dist[1] = 0.5f;
     p->metric = M3DREG_POINT_TO_PLANE; p->min_correspondences = 10;
     p->eps_rot = 1e-5; p->eps_trans = 1e-5; p->pivot_rel_tol = 1e-9;
     p->plane_ratio = 0.25f; p->normal_min_pts = 5; p->normal_leaf = 0.4f; p->normal_min_spread = 0.25f;
@@ -868,6 +886,7 @@ static int check_input(m3dreg_handle* h, const m3dreg_cloud_desc& d, CloudInput&
 int m3dreg_cloud_create_batch_async(m3dreg_handle* h, const m3dreg_cloud_desc* descs, size_t n_clouds, m3dreg_cloud** out) {
     return m3d_guarded(h, "m3dreg_cloud_create_batch_async", [&]() -> int {
     if (!h || !descs || !out || n_clouds == 0 || n_clouds > 4096) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_batch: bad argument");
+    if (h->closed) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_create_batch: the handle was destroyed (it only lives on until its last cloud is released)");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<CloudInput> in(n_clouds);
     for (size_t i = 0; i < n_clouds; i++) { out[i] = nullptr; int rc = check_input(h, descs[i], in[i]); if (rc) return rc; }
@@ -954,6 +973,7 @@ int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
 int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
     return m3d_guarded(h, "m3dreg_align_batch_async", [&]() -> int {
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
+    if (h->closed) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: the handle was destroyed");
     if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch_async: a batch is pending on this handle (a handle holds the state of ONE batch: call m3dreg_batch_wait, or use another handle on the same stream)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = ensure_batch(h, n_pairs);
@@ -966,6 +986,8 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
     const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
     bool prev_sampled = false;
+    const uint64_t iters_before = h->launched_iters;
+    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(5); (void)hipEventRecord(e, h->stream); } }   // the whole chain of this batch's iterations as it ships
     for (int l = 0; l < P.n_levels; l++) {
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
         const unsigned int level_first_seq = h->seq + 1;
@@ -995,6 +1017,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
         }
     }
     if (h->profiling && prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
+    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(6 + int(h->launched_iters - iters_before)); (void)hipEventRecord(e, h->stream); } }
     for (size_t i = 0; i < n_pairs; i++) {   // clouds of other handles: their owners' streams wait for this batch before the blocks are re-used
         if ((rc = note_foreign_use(h, pairs[i].source))) return rc;
         if ((rc = note_foreign_use(h, pairs[i].target))) return rc;
@@ -1664,7 +1687,7 @@ int m3dreg_profile_enable(m3dreg_handle* h, int on) {
 
 int m3dreg_profile_read(m3dreg_handle* h, int what, uint64_t* n_launches, double* total_ms, int reset) {
     return m3d_guarded(h, "m3dreg_profile_read", [&]() -> int {
-    if (!h || what < 0 || what > 3) return M3DREG_ERR_INVALID_ARG;
+    if (!h || what < 0 || what > 4) return M3DREG_ERR_INVALID_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drain_events(h);
     if (n_launches) *n_launches = h->prof_launches[what];
@@ -1742,6 +1765,27 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
     hipFree(dq); if (di) hipFree(di); if (dd) hipFree(dd);
     if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_nn", e);
     if (e2 != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_nn", e2);
+    return M3DREG_OK;
+    });
+}
+
+int m3dreg_debug_candidates(m3dreg_handle* h, const m3dreg_cloud* target, int level, const float* queries_xyz, size_t nq, int32_t* out_count) {
+    return m3d_guarded(h, "m3dreg_debug_candidates", [&]() -> int {
+    if (!h || !target || !queries_xyz || !out_count || level < 0 || level >= target->n_levels || nq == 0 || nq >= 0x7FFFFFFFull)
+        return fail(h, M3DREG_ERR_INVALID_ARG, "debug_candidates: bad argument");
+    if (target->source_only) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "debug_candidates: a source-only cloud has no bucket table");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    float* dq = nullptr; int32_t* di = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dq, 12 * nq));
+    hipError_t e = hipMalloc((void**)&di, 4 * nq);
+    if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = m3d_launch_debug_candidates(h->stream, level_dev(target->lv[level], target->nrm_in), dq, int(nq), di);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_count, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    hipFree(dq); if (di) hipFree(di);
+    if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_candidates", e);
+    if (e2 != hipSuccess) return fail(h, M3DREG_ERR_HIP, "debug_candidates", e2);
     return M3DREG_OK;
     });
 }
@@ -1825,8 +1869,36 @@ int m3dreg_debug_throw(int kind) {
 }  // extern "C"
 
 // ---- one process, several devices (SURVEY.md §8 rows b / e) ------------------------------------------------------
+// One HOST THREAD per listed device ("one host thread + one HIP stream per device"): the worker owns its handle, uploads,
+// buckets and registers its shard and collects its results, so the devices' uploads and enqueues run side by side instead of one
+// after the other on the caller's thread. Host payloads reach the device through PINNED memory: a payload that already is pinned
+// (m3dreg_host_alloc / m3dreg_host_register, or any hipHostMalloc'ed / registered range) is handed to the copy engine as it is — a
+// truly asynchronous hipMemcpyAsync —, a pageable one is first copied into the worker's pinned staging block (a pageable
+// hipMemcpyAsync is synchronous and staged by the runtime anyway; here the staging of one device overlaps the others').
+struct MultiWorker {
+    m3dreg_handle* h = nullptr;
+    int device = 0;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, quit = false, busy = false;
+    void* pinned = nullptr; size_t pinned_bytes = 0;   // staging for pageable payloads (grown on demand, reused by every call)
+    void run() {
+        hipSetDevice(device);
+        for (;;) {
+            std::function<void()> j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return has_job || quit; }); if (quit && !has_job) return; j = std::move(job); has_job = false; }
+            j();   // (never throws: the job catches everything)
+            { std::lock_guard<std::mutex> lk(mu); busy = false; }
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) { { std::lock_guard<std::mutex> lk(mu); job = std::move(j); has_job = true; busy = true; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy; }); }
+};
 struct m3dreg_multi {
-    std::vector<m3dreg_handle*> handles;   // one per entry of `devices` (a device may appear more than once: several streams on it)
+    std::vector<std::unique_ptr<MultiWorker>> workers;   // one per entry of `devices` (a device may appear more than once: several streams on it)
     std::vector<int> devices;
     std::string err;
 };
@@ -1850,12 +1922,89 @@ void lpt_assign(const std::vector<double>& cost, int n_dev, size_t capacity, std
         count[size_t(best)]++;
     }
 }
-int mfail(m3dreg_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
+int mfail(m3dreg_multi* m, int code, const std::string& msg) { if (m) { try { m->err = msg; } catch (...) {} } return code; }
+
+bool host_ptr_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (an ordinary malloc'ed pointer: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
+
+// what one worker does with its shard; everything it allocates is released on every path out, and its handle is idle when it returns
+struct ShardResult { int rc = M3DREG_OK; std::string msg; std::vector<float> T; std::vector<m3dreg_stats> st; };
+void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<size_t>& idx, ShardResult& R) {
+    m3dreg_handle* h = w->h;
+    std::vector<m3dreg_cloud*> clouds;
+    bool touched = false;   // something was enqueued on the handle's stream that may still read host payloads / hold a pending batch
+    auto fail_with = [&](int rc, const char* what) { R.rc = rc; try { R.msg = std::string("device ") + std::to_string(w->device) + ": " + what; } catch (...) {} };
+    try {
+        const size_t k = idx.size();
+        std::vector<m3dreg_cloud_desc> descs(2 * k);
+        // pageable host payloads go through this worker's pinned staging block
+        size_t need = 0;
+        std::vector<size_t> off(2 * k, size_t(-1));
+        for (size_t j = 0; j < k; j++)
+            for (int c = 0; c < 2; c++) {
+                m3dreg_cloud_desc d = c == 0 ? pairs[idx[j]].source : pairs[idx[j]].target;
+                d.source_only = c == 0 ? 1 : 0;
+                descs[2 * j + size_t(c)] = d;
+                if (!d.data_is_device && d.data && d.n && !host_ptr_is_pinned(d.data)) { off[2 * j + size_t(c)] = need; need += (d.n * d.point_step + 255) & ~size_t(255); }
+            }
+        if (need > w->pinned_bytes) {
+            if (w->pinned) { hipStreamSynchronize(h->stream); hipHostFree(w->pinned); w->pinned = nullptr; w->pinned_bytes = 0; }
+            alloc_point();
+            if (hipHostMalloc(&w->pinned, need + need / 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); w->pinned = nullptr; }
+            else w->pinned_bytes = need + need / 4;
+        }
+        if (w->pinned && need <= w->pinned_bytes)
+            for (size_t i = 0; i < 2 * k; i++)
+                if (off[i] != size_t(-1)) {
+                    uint8_t* dst = static_cast<uint8_t*>(w->pinned) + off[i];
+                    memcpy(dst, descs[i].data, descs[i].n * descs[i].point_step);
+                    descs[i].data = dst;
+                }   // (no pinned memory to be had: the payloads go as they are — a synchronous pageable copy, still correct)
+        clouds.assign(2 * k, nullptr);
+        touched = true;
+        int rc = m3dreg_cloud_create_batch_async(h, descs.data(), descs.size(), clouds.data());
+        if (rc != M3DREG_OK) fail_with(rc, h->err.c_str());
+        else {
+            std::vector<m3dreg_pair> pr(k);
+            for (size_t j = 0; j < k; j++) {
+                pr[j].source = clouds[2 * j]; pr[j].target = clouds[2 * j + 1];
+                memcpy(pr[j].init_T, pairs[idx[j]].init_T, sizeof(float) * 16);
+            }
+            R.T.assign(16 * k, 0.f); R.st.assign(k, m3dreg_stats{});
+            rc = m3dreg_align_batch_async(h, pr.data(), pr.size());
+            if (rc == M3DREG_OK) rc = m3dreg_batch_wait(h, R.T.data(), R.st.data());
+            if (rc != M3DREG_OK) fail_with(rc, h->err.c_str());
+        }
+    } catch (const std::bad_alloc&) { fail_with(M3DREG_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+    catch (...) { fail_with(M3DREG_ERR_HIP, "unexpected exception"); }
+    // leave the handle idle and give everything back, whatever happened above (a throw in the middle left earlier devices
+    // with a pending batch, leaked the shard's clouds and returned while copies could still read the caller's payloads)
+    if (touched) {
+        if (h->pending_pairs) { hipStreamSynchronize(h->stream); if (h->ev_used) drain_events(h); h->pending_pairs = 0; }
+        else hipStreamSynchronize(h->stream);
+    }
+    for (m3dreg_cloud* c : clouds) if (c) free_cloud(h, c);
+}
 }  // namespace
 
 extern "C" {
 
 const char* m3dreg_multi_last_error(const m3dreg_multi* m) { return m ? m->err.c_str() : "null context"; }
+
+int m3dreg_multi_destroy(m3dreg_multi* m) {
+    return m3d_guarded(nullptr, "m3dreg_multi_destroy", [&]() -> int {
+    if (!m) return M3DREG_ERR_INVALID_ARG;
+    for (auto& w : m->workers) {
+        if (w->th.joinable()) { { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; } w->cv.notify_all(); w->th.join(); }
+        if (w->h) { hipSetDevice(w->device); if (w->pinned) { hipStreamSynchronize(w->h->stream); hipHostFree(w->pinned); } m3dreg_destroy(w->h); }
+    }
+    delete m;
+    return M3DREG_OK;
+    });
+}
 
 int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_devices, m3dreg_multi** out) {
     return m3d_guarded(nullptr, "m3dreg_multi_create", [&]() -> int {
@@ -1864,84 +2013,81 @@ int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_d
     if (!params || !devices || n_devices < 1 || n_devices > 64) return M3DREG_ERR_INVALID_ARG;
     alloc_point();
     m3dreg_multi* m = new m3dreg_multi();
-    for (int d = 0; d < n_devices; d++) {
-        m3dreg_handle* h = nullptr;
-        const int rc = m3dreg_create(params, devices[d], nullptr, &h);
-        if (rc != M3DREG_OK) { for (m3dreg_handle* g : m->handles) m3dreg_destroy(g); delete m; return rc; }
-        m->handles.push_back(h);
-        m->devices.push_back(devices[d]);
-    }
+    try {
+        for (int d = 0; d < n_devices; d++) {
+            m->workers.emplace_back(new MultiWorker());
+            MultiWorker* w = m->workers.back().get();
+            w->device = devices[d];
+            const int rc = m3dreg_create(params, devices[d], nullptr, &w->h);
+            if (rc != M3DREG_OK) { m3dreg_multi_destroy(m); return rc; }
+            m->devices.push_back(devices[d]);
+            w->th = std::thread([w] { w->run(); });
+        }
+    } catch (...) { m3dreg_multi_destroy(m); throw; }
     *out = m;
     return M3DREG_OK;
     });
 }
 
-int m3dreg_multi_destroy(m3dreg_multi* m) {
-    return m3d_guarded(nullptr, "m3dreg_multi_destroy", [&]() -> int {
-    if (!m) return M3DREG_ERR_INVALID_ARG;
-    for (m3dreg_handle* h : m->handles) m3dreg_destroy(h);
-    delete m;
-    return M3DREG_OK;
-    });
-}
-
 int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_pairs, float* out_T, m3dreg_stats* stats, int32_t* device_of_pair) {
-    return m3d_guarded(nullptr, "m3dreg_multi_align", [&]() -> int {
     if (!m || !pairs || !out_T || n_pairs == 0 || n_pairs > 65535) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: bad argument");
-    const int n_dev = int(m->handles.size());
-    alloc_point();
-    std::vector<double> cost(n_pairs);
-    for (size_t i = 0; i < n_pairs; i++) cost[i] = double(pairs[i].source.n) + double(pairs[i].target.n);
-    std::vector<int> dev_of;
-    lpt_assign(cost, n_dev, (n_pairs + size_t(n_dev) - 1) / size_t(n_dev), dev_of);
-    struct Shard { std::vector<size_t> idx; std::vector<m3dreg_cloud*> clouds; std::vector<m3dreg_pair> pr; bool enqueued = false; };
-    std::vector<Shard> sh{ static_cast<size_t>(n_dev) };
-    for (size_t i = 0; i < n_pairs; i++) sh[size_t(dev_of[i])].idx.push_back(i);
+    const int n_dev = int(m->workers.size());
+    std::vector<std::vector<size_t>> idx;
+    std::vector<ShardResult> res;
+    int posted = 0;
     int rc = M3DREG_OK;
     std::string msg;
-    // enqueue everything, device after device: nothing here waits for a device (bucketing and registration are enqueue-only)
-    for (int d = 0; d < n_dev && rc == M3DREG_OK; d++) {
-        Shard& S = sh[size_t(d)];
-        if (S.idx.empty()) continue;
-        m3dreg_handle* h = m->handles[size_t(d)];
-        std::vector<m3dreg_cloud_desc> descs(2 * S.idx.size());
-        for (size_t k = 0; k < S.idx.size(); k++) {
-            descs[2 * k] = pairs[S.idx[k]].source; descs[2 * k].source_only = 1;
-            descs[2 * k + 1] = pairs[S.idx[k]].target; descs[2 * k + 1].source_only = 0;
+    try {
+        alloc_point();
+        std::vector<double> cost(n_pairs);
+        for (size_t i = 0; i < n_pairs; i++) cost[i] = double(pairs[i].source.n) + double(pairs[i].target.n);
+        std::vector<int> dev_of;
+        lpt_assign(cost, n_dev, (n_pairs + size_t(n_dev) - 1) / size_t(n_dev), dev_of);
+        idx.assign(size_t(n_dev), std::vector<size_t>());
+        res.assign(size_t(n_dev), ShardResult());
+        for (size_t i = 0; i < n_pairs; i++) idx[size_t(dev_of[i])].push_back(i);
+        // every device's worker takes its shard: uploads, bucketing, registrations and the wait for them run side by side
+        for (int d = 0; d < n_dev; d++, posted++) {
+            if (idx[size_t(d)].empty()) continue;
+            MultiWorker* w = m->workers[size_t(d)].get();
+            const std::vector<size_t>* ix = &idx[size_t(d)];
+            ShardResult* R = &res[size_t(d)];
+            w->post([w, pairs, ix, R] { run_shard(w, pairs, *ix, *R); });
         }
-        S.clouds.assign(descs.size(), nullptr);
-        rc = m3dreg_cloud_create_batch_async(h, descs.data(), descs.size(), S.clouds.data());
-        if (rc != M3DREG_OK) { msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; break; }
-        S.pr.resize(S.idx.size());
-        for (size_t k = 0; k < S.idx.size(); k++) {
-            S.pr[k].source = S.clouds[2 * k]; S.pr[k].target = S.clouds[2 * k + 1];
-            memcpy(S.pr[k].init_T, pairs[S.idx[k]].init_T, sizeof(float) * 16);
-        }
-        rc = m3dreg_align_batch_async(h, S.pr.data(), S.pr.size());
-        if (rc != M3DREG_OK) { msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; break; }
-        S.enqueued = true;
-    }
-    // wait and gather in pair order
-    std::vector<float> T; std::vector<m3dreg_stats> st;
+    } catch (const std::bad_alloc&) { rc = M3DREG_ERR_OUT_OF_MEMORY; }
+    catch (...) { rc = M3DREG_ERR_HIP; }
+    // whatever was posted is waited for — also on the error paths: the workers read the caller's payloads and write into res
+    for (int d = 0; d < posted && d < n_dev; d++) m->workers[size_t(d)]->wait();
+    if (rc != M3DREG_OK) return mfail(m, rc, rc == M3DREG_ERR_OUT_OF_MEMORY ? "multi_align: host allocation failed" : "multi_align: unexpected exception");
     for (int d = 0; d < n_dev; d++) {
-        Shard& S = sh[size_t(d)];
-        m3dreg_handle* h = m->handles[size_t(d)];
-        if (S.enqueued) {
-            T.assign(16 * S.idx.size(), 0.f); st.assign(S.idx.size(), m3dreg_stats{});
-            const int rw = m3dreg_batch_wait(h, T.data(), st.data());
-            if (rw != M3DREG_OK && rc == M3DREG_OK) { rc = rw; msg = std::string("device ") + std::to_string(m->devices[size_t(d)]) + ": " + h->err; }
-            if (rw == M3DREG_OK)
-                for (size_t k = 0; k < S.idx.size(); k++) {
-                    memcpy(out_T + 16 * S.idx[k], T.data() + 16 * k, sizeof(float) * 16);
-                    if (stats) stats[S.idx[k]] = st[k];
-                    if (device_of_pair) device_of_pair[S.idx[k]] = m->devices[size_t(d)];
-                }
-        } else if (!S.idx.empty()) m3dreg_synchronize(h);   // (host payloads of a half-enqueued shard must be consumed before we return)
-        for (m3dreg_cloud* c : S.clouds) if (c) m3dreg_cloud_destroy(h, c);
+        const ShardResult& R = res[size_t(d)];
+        if (R.rc != M3DREG_OK) { if (rc == M3DREG_OK) { rc = R.rc; msg = R.msg; } continue; }
+        for (size_t k = 0; k < idx[size_t(d)].size(); k++) {
+            const size_t i = idx[size_t(d)][k];
+            memcpy(out_T + 16 * i, R.T.data() + 16 * k, sizeof(float) * 16);
+            if (stats) stats[i] = R.st[k];
+            if (device_of_pair) device_of_pair[i] = m->devices[size_t(d)];
+        }
     }
     if (rc != M3DREG_OK) return mfail(m, rc, msg);
     return M3DREG_OK;
-    });
 }
+
+// Pinned host memory for callers that do not link HIP: a payload that lives in it reaches the device by a truly asynchronous copy
+// (every cloud_create* entry point and m3dreg_multi_align recognise pinned ranges; pageable ones work too, at the price of a
+// synchronous, staged copy). m3dreg_host_register pins an existing allocation in place until m3dreg_host_unregister.
+int m3dreg_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return M3DREG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return M3DREG_ERR_HIP; }
+    return M3DREG_OK;
+}
+int m3dreg_host_free(void* p) { if (!p) return M3DREG_ERR_INVALID_ARG; return hipHostFree(p) == hipSuccess ? M3DREG_OK : M3DREG_ERR_HIP; }
+int m3dreg_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return M3DREG_ERR_INVALID_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return M3DREG_ERR_HIP; }
+    return M3DREG_OK;
+}
+int m3dreg_host_unregister(void* p) { if (!p) return M3DREG_ERR_INVALID_ARG; return hipHostUnregister(p) == hipSuccess ? M3DREG_OK : M3DREG_ERR_HIP; }
 
 }  // extern "C"

@@ -585,7 +585,9 @@ int orc_set_threads(int n) {
 int orc_default_params(orc_params* p) {
     if (!p) return ORC_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));
-    p->n_levels = 1; p->leaf[0] = 0.1f; p->iterations[0] = 30; p->max_corr_dist[0] = 0.5f;
+    p->n_levels = 2; /* == m3dreg_default_params (tests/test_abi.py): coarse to fine */
+    p->leaf[0] = 0.4f; p->iterations[0] = 20; p->max_corr_dist[0] = 1.5f;
+    p->leaf[1] = 0.1f; p->iterations[1] = 20; p->max_corr_dist[1] = 0.5f;
     p->metric = ORC_PT2PLANE; p->min_correspondences = 10;
     p->eps_rot = 1e-5; p->eps_trans = 1e-5; p->pivot_rel_tol = 1e-9;
     p->plane_ratio = 0.25f; p->normal_min_pts = 5; p->normal_leaf = 0.4f; p->normal_min_spread = 0.25f;

@@ -37,17 +37,32 @@ public:
         nh_.param<std::string>("odom_frame", odom_frame_, "m3d_test/odom");
         m3dreg_params p;
         m3dreg_default_params(&p);
-        double leaf = p.leaf[0], dmax = p.max_corr_dist[0], normal_leaf = p.normal_leaf;
-        int iters = p.iterations[0], device = 0;
+        // the library's defaults are a two-level pyramid (0.4 m -> 0.1 m); ~leaf / ~max_corr_dist / ~iterations address the FINEST level,
+        // ~coarse_leaf / ~coarse_max_corr_dist / ~coarse_iterations the one before it (~coarse_leaf:=0 registers on the fine level alone)
+        const int fine = p.n_levels - 1;
+        double leaf = p.leaf[fine], dmax = p.max_corr_dist[fine], normal_leaf = p.normal_leaf;
+        double coarse_leaf = fine > 0 ? p.leaf[0] : 0.0, coarse_dmax = fine > 0 ? p.max_corr_dist[0] : 0.0;
+        int iters = p.iterations[fine], coarse_iters = fine > 0 ? p.iterations[0] : 0, device = 0;
         nh_.param("leaf", leaf, leaf);
         nh_.param("max_corr_dist", dmax, dmax);
         nh_.param("normal_leaf", normal_leaf, normal_leaf);
         nh_.param("iterations", iters, iters);
+        nh_.param("coarse_leaf", coarse_leaf, coarse_leaf);
+        nh_.param("coarse_max_corr_dist", coarse_dmax, coarse_dmax);
+        nh_.param("coarse_iterations", coarse_iters, coarse_iters);
         nh_.param("device", device, device);
         nh_.param<std::string>("mode", mode_, "scan_to_scan");   // or "scan_to_map": register against the HBM map of all earlier sweeps
         nh_.param("map_leaf", map_leaf_, 0.05);
         nh_.param("map_capacity", map_capacity_, 1 << 22);
-        p.leaf[0] = float(leaf); p.max_corr_dist[0] = float(dmax); p.normal_leaf = float(normal_leaf); p.iterations[0] = iters;
+        if (coarse_leaf > 0.0) {
+            p.n_levels = 2;
+            p.leaf[0] = float(coarse_leaf); p.max_corr_dist[0] = float(coarse_dmax); p.iterations[0] = coarse_iters;
+            p.leaf[1] = float(leaf); p.max_corr_dist[1] = float(dmax); p.iterations[1] = iters;
+        } else {
+            p.n_levels = 1;
+            p.leaf[0] = float(leaf); p.max_corr_dist[0] = float(dmax); p.iterations[0] = iters;
+        }
+        p.normal_leaf = float(normal_leaf);
         int rc = m3dreg_create(&p, device, nullptr, &h_);
         if (rc != M3DREG_OK) {   // same policy as the reference's drivers: fatal + exit (encoder_node_li.cpp:60-80)
             ROS_FATAL("m3dreg_create failed (%d): no usable MI355X; there is no CPU fallback", rc);

@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(tmp_path):
         assert nums[0] == C.sizeof(ct), cname
         assert nums[1:] == [getattr(ct, f).offset for f in fields], cname
     p = binding.default_params()
-    assert p.n_levels == 1 and abs(p.leaf[0] - 0.1) < 1e-7 and p.metric == abi.POINT_TO_PLANE
+    assert p.n_levels == 2 and abs(p.leaf[0] - 0.4) < 1e-7 and abs(p.leaf[1] - 0.1) < 1e-7 and p.metric == abi.POINT_TO_PLANE   # ABI 4: coarse to fine
 
 
 def test_default_params_agree_with_oracle(orc):

@@ -45,6 +45,38 @@ def test_multi_context_equals_single_handle_batch(reg, orc):
     M.close()
 
 
+def test_multi_align_survives_allocation_failures_and_takes_pinned_payloads(reg):
+    """ADVICE r2: a std::bad_alloc anywhere inside m3dreg_multi_align (the caller's thread or a device thread, before or after
+    something was enqueued) comes back as M3DREG_ERR_OUT_OF_MEMORY with every device's handle idle and every cloud released — the
+    next call on the same context works and gives the same poses. Pinned payloads (m3dreg_host_alloc: asynchronous DMA) and pageable
+    ones (staged through the device threads' pinned blocks) give identical results."""
+    p = abi.Params.make(leaf=0.2, iterations=6, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    pairs = _pairs(4)
+    L = reg.lib()
+    M = reg.MultiRegistrar(p, devices=(0, 0))
+    T_ok, st_ok, _ = M.align(pairs, source_only=True)
+    failed = 0
+    for nth in range(1, 12):
+        L.m3dreg_debug_fail_alloc(nth)
+        try:
+            try:
+                T, _, _ = M.align(pairs, source_only=True)
+                assert np.array_equal(T, T_ok)          # (nth beyond the allocation points this call reaches)
+            except abi.M3dregError as e:
+                assert e.code == abi.ERR_OUT_OF_MEMORY, (nth, e)
+                failed += 1
+        finally:
+            L.m3dreg_debug_fail_alloc(0)
+        T2, _, _ = M.align(pairs, source_only=True)     # the context is usable again at once: nothing pending, nothing leaked
+        assert np.array_equal(T2, T_ok), nth
+    assert failed >= 3
+    descs, keep = M.describe(pairs, source_only=True, pinned=True)
+    Tp, stp, _ = M.align_described(descs)
+    assert np.array_equal(Tp, T_ok)
+    assert [(a.status, a.iterations, a.n_corr) for a in stp] == [(a.status, a.iterations, a.n_corr) for a in st_ok]
+    M.close()
+
+
 def test_allocation_failure_is_an_error_code_not_an_exception(reg):
     """std::bad_alloc inside m3dreg_cloud_create_batch comes back as M3DREG_ERR_OUT_OF_MEMORY; the handle stays usable."""
     p = abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)

@@ -298,19 +298,34 @@ def test_batched_bucketing_equals_single(reg, orc):
         _check_bucketing(R.cloud(a), o, 2)
 
 
+CONFIG2 = dict(leaf=(0.8, 0.4, 0.2), iterations=(30, 30, 150), max_corr_dist=(2.0, 0.6, 0.2), metric=abi.POINT_TO_POINT)   # == bench.py's config-2 leg
+
+
 def test_config2_hdl32_point_to_point(reg, orc):
-    """BASELINE config 2: single HDL-32 scan pair (70 016 rays), point-to-point, 1 x MI355X — bit-exact vs the oracle."""
+    """BASELINE config 2: single HDL-32 scan pair (70 016 rays), point-to-point, 1 x MI355X, FROM IDENTITY (0.5 m / 3 deg apart) — bit-exact
+    vs the oracle, and inside the acceptance bar BASELINE.md states for it: <= 0.1 deg / 2 cm (measured 0.076 deg / 1.0 cm; the single
+    0.2 m level of round 2 ended 0.47 m off from identity). Point-to-point on ring-structured sweeps needs the pyramid to get there and a
+    correspondence distance below the ring spacing at the end (with 1.0 m the ground rings pull the translation 12 cm short); its
+    rotation floor at sigma = 2 cm range noise is what remains — point-to-plane reaches 0.007 deg / 0.8 mm on the same pair (below)."""
     src, tgt, Tgt = synth.config2()
-    p = _params(leaf=0.2, iterations=30, max_corr_dist=1.0, metric=abi.POINT_TO_POINT)
+    p = _params(**CONFIG2)
     R = reg.Registrar(p)
-    cs, ct = R.clouds([src, tgt])
+    cs, ct = R.clouds([src, tgt], source_only=[True, False])
     T1, st1 = R.align(cs, ct)
-    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True), orc.Cloud(p, tgt, omp=True), trace_cap=64)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True), trace_cap=256)
     assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
     _same_stats(st1, st2)
-    # point-to-point slides along the walls (textbook behaviour): it must at least reduce the error monotonically enough
-    e0, e1 = synth.pose_error(np.eye(4), Tgt), synth.pose_error(T1, Tgt)
-    assert e1[0] < e0[0] and e1[1] < e0[1]
+    rot, tra = synth.pose_error(T1, Tgt)
+    assert st1.status == abi.CONVERGED and rot <= 0.1 and tra <= 0.02, (rot, tra, st1.as_dict())
+    # the library's DEFAULT parameters (what a node launched without parameters runs: point-to-plane, 0.4 m -> 0.1 m) on the same pair
+    pd = reg.default_params()
+    Rd = reg.Registrar(pd)
+    Td, std = Rd.align(*Rd.clouds([src, tgt], source_only=[True, False]))
+    To, sto, _ = orc.align(pd, orc.Cloud(pd, src, omp=True, source_only=True), orc.Cloud(pd, tgt, omp=True))
+    assert np.array_equal(Td, To)
+    _same_stats(std, sto)
+    rot, tra = synth.pose_error(Td, Tgt)
+    assert std.status == abi.CONVERGED and rot <= 0.05 and tra <= 0.005, (rot, tra)
 
 
 def test_config5_dense_map_multiresolution(reg, orc):

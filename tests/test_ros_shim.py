@@ -53,7 +53,9 @@ def test_shim_registers_two_sweeps_like_the_binding(reg, tmp_path, mode):
     poses = [[float(x) for x in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("pose ")]
     assert len(poses) == 1, (r.stdout, r.stderr)     # the first sweep only becomes the target / the map
     if mode == "scan_to_scan":
-        pr = abi.Params.make(iterations=20)   # == m3dreg_default_params with the shim's iterations parameter
+        pr = reg.default_params()             # the node is started without parameters beyond the test's ~iterations (finest level)
+        assert pr.n_levels == 2
+        pr.iterations[1] = 20
         R = reg.Registrar(pr)
         T, st = R.align(R.cloud(src), R.cloud(tgt))
         assert np.array_equal(np.asarray(poses[0][:3], np.float32), np.asarray(T, np.float64)[:3, 3].astype(np.float32))
