@@ -654,14 +654,24 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
     const uint32_t h0 = Q.key0 * 0x9E3779B1u;
     const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x9E3779B1u << sh1)), c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0x9E3779B1u << sh2));   // (uniform: scalar registers)
 #define M3D_P(b, dx, dy, dz) m3d_tile_probe<b, dx, dy, dz>(vs, Q.G, h0, c1, c2, Q.bound, Q.sec, mask)
+#ifndef M3D_EXP_NOPROBE   // (timing experiment only — WRONG results: what would the search cost without the 26 blind probes?)
     M3D_P(1, -1, 0, 0); M3D_P(2, 1, 0, 0); M3D_P(3, 0, -1, 0); M3D_P(4, 0, 1, 0); M3D_P(5, 0, 0, -1); M3D_P(6, 0, 0, 1);
     M3D_P(7, -1, -1, 0); M3D_P(8, 1, -1, 0); M3D_P(9, -1, 1, 0); M3D_P(10, 1, 1, 0);
     M3D_P(11, -1, 0, -1); M3D_P(12, 1, 0, -1); M3D_P(13, -1, 0, 1); M3D_P(14, 1, 0, 1);
     M3D_P(15, 0, -1, -1); M3D_P(16, 0, 1, -1); M3D_P(17, 0, -1, 1); M3D_P(18, 0, 1, 1);
     M3D_P(19, -1, -1, -1); M3D_P(20, 1, -1, -1); M3D_P(21, -1, 1, -1); M3D_P(22, 1, 1, -1);
     M3D_P(23, -1, -1, 1); M3D_P(24, 1, -1, 1); M3D_P(25, -1, 1, 1); M3D_P(26, 1, 1, 1);
+#endif
 #undef M3D_P
-    // phase 2: the voxels that survived, nearest kinds first (faces, edges, corners), each scanned in full
+#ifdef M3D_EXP_NOPHASE2   // (timing experiment only — WRONG results: the 26 probes are made, the surviving voxels are not visited)
+    asm volatile("" :: "v"(mask));
+    mask = 0u;
+#endif
+    // phase 2: the voxels that survived, nearest kinds first (faces, edges, corners), each scanned in full. (Re-testing every voxel against the
+    // bound its predecessors left — the offsets from an LDS table, the gaps selected out of G — was tried in round 3: bit-identical and 7 %
+    // SLOWER; the re-test costs every visit ~15 instructions and a dependent LDS read, and prunes little: most of what survives phase 1 is
+    // genuinely close. Throw-away builds, iteration 0 of the bench batch: 10 us of the launch are records + staging + results, 11 the home
+    // voxel, 7 the 26 probes, 23 this loop.)
     while (mask) {
         const int b = __ffs((int)mask) - 1;
         mask &= mask - 1u;
@@ -1273,7 +1283,11 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             }
             if (have) {
                 if (j == 0u) m3d_tile_query(g, r4.x, r4.y, r4.z, dmax2, seeded, dseed, Q, code);
+#ifdef M3D_EXP_NOSEARCH   // (timing experiment only — WRONG results: the floor of an item — records, staging, result writes — without the search)
+                const int b = -1;
+#else
                 const int b = m3d_tile_search(g, vs, sp, s_kd, r4.x, r4.y, r4.z, Q, sub, lstride);
+#endif
                 if (b >= 0) m = (int)reinterpret_cast<const uint32_t*>(img + M3D_TILE_IMG_GIDX)[b];   // LDS position -> sorted position
             }
             M3D_TBT_SEARCHED();
