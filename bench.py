@@ -569,7 +569,10 @@ def run_config5(args):
     # per level: a one-level registration on that level's grid alone, started where the coarser levels ended
     levels, Tl = [], T0
     for l in range(3):
-        pl = abi.Params.make(leaf=leaves[l], iterations=10, max_corr_dist=dmaxs[l], metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+        # (a coarser level is measured as what it is in the pyramid — a level above the finest one, whose grid is therefore sorted from the finest
+        #  level's order: two levels, no iterations on the second)
+        pl = (abi.Params.make(leaf=leaves[l], iterations=10, max_corr_dist=dmaxs[l], metric=abi.POINT_TO_PLANE, normal_leaf=0.4) if l == 2 else
+              abi.Params.make(leaf=(leaves[l], leaves[2]), iterations=(10, 0), max_corr_dist=(dmaxs[l], dmaxs[2]), metric=abi.POINT_TO_PLANE, normal_leaf=0.4))
         Rl = binding.Registrar(pl)
         tl, sl = Rl.clouds([mp, live], source_only=[False, True])
         Rl.align(sl, tl, Tl)                       # warm-up (pools, workspaces)
@@ -579,7 +582,7 @@ def run_config5(args):
         Tn, stl = Rl.align(sl, tl, Tl)
         n1, ms1 = Rl.profile_read(1, reset=True)
         n0, ms0 = Rl.profile_read(0, reset=True)
-        g = tl.grid_info()
+        g = tl.grid_info(0)
         alg = 12 * sl.n + 12 * tl.n + 8 * g.n_cells
         nn_ms = ms1 / max(1, n1)
         levels.append({"leaf": leaves[l], "occupied_voxels": int(g.n_cells), "ms_per_icp_iter": ms0 / max(1, n0), "ms_correspondence_step": nn_ms,

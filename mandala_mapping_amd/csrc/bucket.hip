@@ -141,7 +141,19 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__
         const int iz = (int)m3d_cell_f(pz, B.grid.mn[2], B.grid.inv_leaf);
         key = m3d_voxel_key(B.grid.cb, ix, iy, iz);
     }
-    B.keys[i] = key; B.ka[i] = key; B.va[i] = (uint32_t)i;
+    B.keys[i] = key;
+    if (B.fine < 0) { B.ka[i] = key; B.va[i] = (uint32_t)i; }   // (a coarser level of a pyramid is keyed again in the finest level's order: k_rekey)
+}
+
+// a coarser level of a pyramid starts its sort from the finest level's ORDER (M3dBuild::fine): the LSD passes are stable, so inside a
+// coarse voxel the points then lie in the finest level's Morton order
+__global__ __launch_bounds__(256) void k_rekey(const M3dBuild* __restrict__ builds) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (B.fine < 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n) return;
+    const uint32_t v = builds[B.fine].perm_out[i];
+    B.ka[i] = B.keys[v]; B.va[i] = v;
 }
 
 // ---- a4: stable LSD radix sort, 8-bit digits ------------------------------------------------------
@@ -162,9 +174,9 @@ __device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return
 // (fused = the batch's clouds are small enough — at most RS_FUSED_TILES tiles — for every scatter workgroup to scan the counters it
 // needs itself: no k_rs_scan launch, counters stored [tile][digit] so that those reads coalesce)
 #define RS_FUSED_TILES 128
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused, int phase) {
     const M3dBuild& B = builds[blockIdx.y];
-    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
+    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;   // phase 1: the grids that wait for their cloud's finest level
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
     const int n = B.n, shift = 8 * pass;
@@ -182,33 +194,60 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restri
     else B.hist[threadIdx.x * B.ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// one workgroup per build: exclusive scan of its 256 * ntiles counters
-__global__ __launch_bounds__(1024) void k_rs_scan(const M3dBuild* __restrict__ builds, int pass) {
-    const M3dBuild& B = builds[blockIdx.x];
-    if (pass >= B.sort_passes) return;
-    uint32_t* hist = B.hist;
-    const int total = 256 * B.ntiles;
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (total + 1023) / 1024;
-    const int b = t * per, e = min(b + per, total);
+// Clouds of more than RS_FUSED_TILES sort tiles (262 k points: a map): exclusive scan of a build's 256 * ntiles counters, in place, by
+// RS_SCAN_CHUNKS workgroups in two launches — chunk sums, then every chunk scans itself behind the sum of the chunks before it, all
+// loads coalesced. (One workgroup of 1024 threads, each summing a contiguous 183-counter stretch with a stride of 732 bytes between
+// neighbouring lanes, took 223 us per pass for the 1.5 M-point map of config 5: 1.8 of the 2.8 ms its bucketing took.)
+#define RS_SCAN_CHUNKS 64
+__device__ __forceinline__ int rs_scan_chunk_len(int total) { return ((total + RS_SCAN_CHUNKS - 1) / RS_SCAN_CHUNKS + 255) & ~255; }
+__global__ __launch_bounds__(256) void k_rs_scan_sums(const M3dBuild* __restrict__ builds, int pass, int phase) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (pass >= B.sort_passes || (B.fine >= 0) != (phase == 1)) return;
+    const int total = 256 * B.ntiles, len = rs_scan_chunk_len(total);
+    const int b0 = blockIdx.x * len, e0 = min(b0 + len, total);
     uint32_t s = 0;
-    for (int i = b; i < e; i++) s += hist[i];
-    part[t] = s;
+    for (int i = b0 + (int)threadIdx.x; i < e0; i += 256) s += B.hist[i];
+    __shared__ uint32_t w[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan in LDS
-        uint32_t v = (t >= o) ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (threadIdx.x == 0) B.hist[total + blockIdx.x] = w[0] + w[1] + w[2] + w[3];   // (the workspace holds 256 spare counters behind the tiles')
+}
+__global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restrict__ builds, int pass, int phase) {
+    const M3dBuild& B = builds[blockIdx.y];
+    if (pass >= B.sort_passes || (B.fine >= 0) != (phase == 1)) return;
+    const int total = 256 * B.ntiles, len = rs_scan_chunk_len(total);
+    const int b0 = blockIdx.x * len, e0 = min(b0 + len, total);
+    __shared__ uint32_t w[4], s_run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {   // sum of the chunks before this one
+        uint32_t v = ((int)threadIdx.x < (int)blockIdx.x) ? B.hist[total + threadIdx.x] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (threadIdx.x == 0) s_run = v;
     }
-    uint32_t run = part[t] - s;
-    for (int i = b; i < e; i++) { uint32_t v = hist[i]; hist[i] = run; run += v; }
+    __syncthreads();
+    uint32_t run = s_run;
+    for (int i0 = b0; i0 < e0; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        const uint32_t v = i < e0 ? B.hist[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        __syncthreads();   // (w is read below in the previous trip)
+        if (lane == 63) w[wave] = inc;
+        __syncthreads();
+        uint32_t off = run;
+        for (int k = 0; k < wave; k++) off += w[k];
+        if (i < e0) B.hist[i] = off + inc - v;
+        run += w[0] + w[1] + w[2] + w[3];
+    }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase) {
     const M3dBuild& B = builds[blockIdx.y];
-    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles) return;
+    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
     const int n = B.n, shift = 8 * pass, ntiles = B.ntiles;
@@ -1156,7 +1195,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 
 // the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread) {
+                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid) {
     const int n_builds = n_clouds * grids_per_cloud;
     const int max_passes = 4;   // a build whose keys need fewer skips the later ones on the device
     hipLaunchKernelGGL(k_grid_params, dim3((n_clouds + 63) / 64), dim3(64), 0, s, d_builds, n_clouds, grids_per_cloud);
@@ -1166,16 +1205,23 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     const int cb = blocks > 256 ? 256 : blocks;
     hipLaunchKernelGGL(k_voxel_keys, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
     M3D_DBG(s, "k_voxel_keys");
-    for (int pass = 0; pass < max_passes; pass++) {
-        const int fused = ntiles <= RS_FUSED_TILES ? 1 : 0;   // (ntiles = the batch's largest cloud)
-        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused);
-        M3D_DBG(s, "k_rs_hist");
-        if (!fused) {
-            hipLaunchKernelGGL(k_rs_scan, dim3(n_builds), dim3(1024), 0, s, d_builds, pass);
-            M3D_DBG(s, "k_rs_scan");
+    for (int phase = 0; phase < (pyramid ? 2 : 1); phase++) {
+        if (phase == 1) {   // the coarser levels of pyramids: keyed in their cloud's finest-level order, then sorted (stable) by their own keys
+            hipLaunchKernelGGL(k_rekey, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+            M3D_DBG(s, "k_rekey");
         }
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused);
-        M3D_DBG(s, "k_rs_scatter");
+        for (int pass = 0; pass < max_passes; pass++) {
+            const int fused = ntiles <= RS_FUSED_TILES ? 1 : 0;   // (ntiles = the batch's largest cloud)
+            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase);
+            M3D_DBG(s, "k_rs_hist");
+            if (!fused) {
+                hipLaunchKernelGGL(k_rs_scan_sums, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
+                hipLaunchKernelGGL(k_rs_scan_apply, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
+                M3D_DBG(s, "k_rs_scan");
+            }
+            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase);
+            M3D_DBG(s, "k_rs_scatter");
+        }
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_count_cells, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);

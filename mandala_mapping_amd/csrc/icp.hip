@@ -959,8 +959,12 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     for (int w = 0; w < 4; w++) { if (w < wave) offW += s_cnt[w]; nW += s_cnt[w]; }
     if (i < n) { M3D_STAT(sit, 0); if (cls == 1) M3D_STAT(sit, 3); if (cls == 2) M3D_STAT(sit, 4); }
     if (nW == 0) { M3D_BT_END(0); return; }   // block-uniform
-    if (tid == 0) M3D_STAT(sit, nW >= A.lane_min ? 5 : 6);
-    if (LEAN || (nW >= A.lane_min && A.tiles && J.tgt.thdr)) {
+    // A crowded level (hundreds of points per voxel: the coarse levels of a dense map) is walked eight lanes per query whatever the number of
+    // searchers: one lane alone makes a hundred and more dependent gather trips through its 27 voxels' chunks, eight share them (config 5's
+    // 0.4 m level: 0.33 -> 0.20 ms per iteration; its 0.2 m level, 25 points per voxel, is faster one query per lane: 0.051 vs 0.063).
+    const int lane_min = (!LEAN && J.coop_always) ? 257 : A.lane_min;
+    if (tid == 0) M3D_STAT(sit, nW >= lane_min ? 5 : 6);
+    if (LEAN || (nW >= lane_min && A.tiles && J.tgt.thdr)) {
         // ---- many queries to search, the target has tiles: bin them, k_nn_tiles answers them from LDS ----------------
         // A query goes to the tile that owns its home bucket (one probe of the level's table: the bucket's first sorted position
         // names the tile); every other bucket of its 2x2x2 neighbourhood is within one bucket of that one, hence staged with
@@ -1100,7 +1104,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         return;
     }
     if constexpr (!LEAN) {
-    if (nW >= A.lane_min) {
+    if (nW >= lane_min) {
         // ---- one query per lane: every thread walks its own query -------------------------------------------------
         if (cls != 0) {
             long long code = 0; float sec = 0.f;
@@ -1794,11 +1798,9 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     if (w.tiles && !late && w.lean) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
-        // (a small grid: the list is normally empty and an empty launch costs what its workgroups take to be dispatched — 5.3 us with one per 256
-        //  queries; the workgroups stride over whatever the list holds)
-        static const int fb_bpp = [] { const char* v = getenv("M3DREG_FB_BPP"); const int q = v ? atoi(v) : 8; return q >= 1 ? q : 8; }();
-        const int bpp_f = bpp_s < fb_bpp ? bpp_s : fb_bpp;
-        hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_f * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_f, first_of_level, A);
+        // (the full grid although the list is normally empty: an empty launch costs 5.2 us whatever its grid — 1, 8, 32 or 391 workgroups per pair,
+        //  measured — and a one-level registration on a coarse grid sends EVERY query here: with 8 workgroups per pair it took ten times as long)
+        hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_fallback");
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
@@ -1830,6 +1832,7 @@ __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pai
     g.hshift = (int32_t)M->dyn[2];
     J.tgt.g = g;
     if (M->dyn[7] == 0u) J.tgt.occ = nullptr;   // the grid has more bucket positions than the occupancy bitmap covers
+    J.coop_always = ((unsigned long long)(uint32_t)M->g.n_valid > (unsigned long long)M3D_COOP_DENSITY * (unsigned long long)M->dyn[0]) ? 1 : 0;
     J.n_src = MS->g.n_valid;
     int32_t e[6]; float S[6];
     m3d_fixed_exps(M->lbound, J.dmax, e, S);

@@ -32,6 +32,11 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     int n;
     int sort_passes;             // 8-bit LSD passes needed to order this grid's keys
     int ntiles;
+    int fine;                    // -1, or (a coarser level of a pyramid) the index of the build of the SAME cloud's finest level: this grid is then sorted
+                                 // from the finest level's order, so that inside one of its voxels the points lie in the finest level's Morton order
+                                 // instead of input order — chunks of 16 consecutive points become compact boxes, and a coarse level's search (hundreds
+                                 // of points per voxel) skips nearly all of them by their box. The spec's order (stable: input order inside a voxel) is
+                                 // what m3dreg_cloud_export returns (restored on the host); results do not depend on the order inside a voxel.
     const float4* xyz;           // input-order coordinates of the cloud
     M3dGrid grid;                // in: grid.leaf; everything else is derived ON THE DEVICE from the cloud's exact AABB (k_grid_params), like sort_passes
     const uint32_t* aabb;        // [8] the cloud's k_decode_aabb words
@@ -64,7 +69,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 // n_builds = n_clouds * grids_per_cloud, the builds of a cloud are consecutive. No host input beyond sizes: the grid geometry, the
 // number of sort passes and the error state of every cloud are derived on the device.
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread);
+                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid);   // pyramid: some build has fine >= 0
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // aggregate.hip

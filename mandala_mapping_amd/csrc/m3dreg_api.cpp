@@ -424,7 +424,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
     // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
-    bool any_tiles = false;
+    bool any_tiles = false, any_fine = false;
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
         const bool no_normals = in[i].src_only;   // a source-only cloud: sorted, no normal grid, no normals
@@ -438,6 +438,10 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             M3dBuild& B = h_builds[bi];
             memset(&B, 0, sizeof(B));
             B.n = c->n; B.sort_passes = 0; B.ntiles = m3d_sort_tiles(c->n);
+            {   // a coarser level of a pyramid is sorted from its cloud's finest level's order (M3dBuild::fine)
+                const int lvl = gidx - (want_normals ? 1 : 0);
+                B.fine = (!is_ng && P.n_levels > 1 && lvl < P.n_levels - 1) ? int(i * size_t(grids_per_cloud)) + (want_normals ? 1 : 0) + (P.n_levels - 1) : -1;
+            }
             B.xyz = c->xyz; B.aabb = aabb[i];
             B.grid.leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
@@ -449,7 +453,9 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.nrm_in = c->nrm_in;
             B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
             if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
+            if (!is_ng && no_normals && gidx - (want_normals ? 1 : 0) < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // nor the coarser levels of its pyramid: a registration streams a source in its FINEST level's order on every level (build_jobs)
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
+            any_fine = any_fine || B.fine >= 0;
             if (!is_ng && !no_normals && h->tiles) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = true; c->has_tiles = true; }
         }
     }
@@ -467,7 +473,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
     B_HIP(hipEventRecord(h->staged, h->stream));
     B_HIP(m3d_launch_bucket_batch(h->stream, d_builds, int(k), grids_per_cloud, int(max_n), want_normals, any_tiles, P.plane_ratio,
-                                  P.normal_min_pts, P.normal_min_spread));
+                                  P.normal_min_pts, P.normal_min_spread, any_fine));
     if (pb0) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(4); (void)hipEventRecord(e, h->stream); } }
     roctx_pop();
     // One event behind the pipeline lets OTHER handles order their streams after it.
@@ -639,7 +645,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     return M3DREG_OK;
 }
 
-M3dNnWork nn_work(const m3dreg_handle* h) {
+M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     M3dNnWork w{};
     w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
@@ -648,9 +654,11 @@ M3dNnWork nn_work(const m3dreg_handle* h) {
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
     w.rot = h->xcd_rot;
-    // (lean only for one-level registrations: a pyramid's coarse levels put more points into a bucket than a tile image holds, their queries would all
-    // take the fallback list — config 5: 6.5 instead of 5.9 ms)
-    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && h->params.n_levels == 1) ? 1 : 0;
+    // (lean per LEVEL: only on the finest level of a registration — a pyramid's coarse levels put more points into a bucket than a tile image holds,
+    // their queries would all take the fallback list: config 5 with lean on every level took 6.5 instead of 5.9 ms)
+    static const int lean_levels = [] { const char* v = getenv("M3DREG_LEAN_LEVELS"); return v ? atoi(v) : 0; }();   // 0: one-level registrations only (default), 1: also the finest level of a pyramid — measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would send every query to the fallback list
+    const bool lean_here = h->params.n_levels == 1 || (lean_levels && level == h->params.n_levels - 1);
+    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
@@ -1011,7 +1019,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                     if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
                 }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((h->fuse_from > 0 && it >= h->fuse_from) ? -2 : -1) : 0), nn_work(h), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((h->fuse_from > 0 && it >= h->fuse_from) ? -2 : -1) : 0), nn_work(h, l), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             roctx_pop();
             h->launched_iters++;
         }
@@ -1725,9 +1733,18 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
     const DevLevel& L = c->lv[level];
     const size_t n = size_t(c->n);
     HIPCHK(h, hipSetDevice(h->device));
+    // A coarser level of a pyramid keeps its points in the finest level's order inside every voxel (M3dBuild::fine: what makes its chunk boxes
+    // compact); the spec's order — stable, i.e. input order inside a voxel — is restored here, on the host: this is the introspection path.
+    const bool reorder = c->n_levels > 1 && level < c->n_levels - 1 && (perm || sorted_xyz || normals);
+    std::vector<uint32_t> sk_tmp; std::vector<int32_t> pm_tmp;
+    uint32_t* sk_host = sorted_keys; int32_t* pm_host = perm;
+    if (reorder) {
+        if (!sk_host) { sk_tmp.resize(n); sk_host = sk_tmp.data(); }
+        if (!pm_host) { pm_tmp.resize(n); pm_host = pm_tmp.data(); }
+    }
     if (keys) HIPCHK(h, hipMemcpyAsync(keys, L.keys, 4 * n, hipMemcpyDeviceToHost, h->stream));
-    if (sorted_keys) HIPCHK(h, hipMemcpyAsync(sorted_keys, L.skey, 4 * n, hipMemcpyDeviceToHost, h->stream));
-    if (perm) HIPCHK(h, hipMemcpyAsync(perm, L.perm, 4 * n, hipMemcpyDeviceToHost, h->stream));
+    if (sk_host) HIPCHK(h, hipMemcpyAsync(sk_host, L.skey, 4 * n, hipMemcpyDeviceToHost, h->stream));
+    if (pm_host) HIPCHK(h, hipMemcpyAsync(pm_host, L.perm, 4 * n, hipMemcpyDeviceToHost, h->stream));
     float *dx = nullptr, *dn = nullptr;
     if (sorted_xyz || normals) {
         HIPCHK(h, hipMalloc((void**)&dx, 12 * n));
@@ -1741,6 +1758,24 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
         if (e2 != hipSuccess) return fail(h, M3DREG_ERR_HIP, "cloud_export", e2);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (reorder) {
+        std::vector<uint32_t> ord(n);
+        for (size_t i = 0; i < n; i++) ord[i] = uint32_t(i);
+        for (size_t a = 0; a < n;) {   // every run of equal keys: by input index
+            size_t b = a + 1;
+            while (b < n && sk_host[b] == sk_host[a]) b++;
+            std::sort(ord.begin() + a, ord.begin() + b, [&](uint32_t x, uint32_t y) { return pm_host[x] < pm_host[y]; });
+            a = b;
+        }
+        std::vector<int32_t> p2(n);
+        for (size_t i = 0; i < n; i++) p2[i] = pm_host[ord[i]];
+        for (float* arr : { sorted_xyz, normals }) {
+            if (!arr) continue;
+            std::vector<float> t(arr, arr + 3 * n);
+            for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) arr[3 * i + k] = t[3 * size_t(ord[i]) + k];
+        }
+        if (perm) memcpy(perm, p2.data(), 4 * n);
+    }
     return M3DREG_OK;
     });
 }
