@@ -51,7 +51,7 @@ def parse():
                     help="hand over HOST PointCloud2 buffers every step (PCIe-inclusive rate; reported in DESIGN.md, never the headline)")
     ap.add_argument("--converge", action="store_true",
                     help="terminate on eps 1e-5 (max --iters) instead of running a fixed iteration count; secondary figure, see DESIGN.md")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="steps in flight: step i runs on handle/stream i %% D, the host enqueues step i+D-1 before waiting for step i (1 = strictly serial steps)")
     ap.add_argument("--queue-depth", type=int, default=2,
                     help="steps QUEUED per stream (the first of them runs, the others wait behind it on the same stream): with 2 a stream never "
@@ -419,15 +419,16 @@ def main():
         value = total_regs / elapsed
         avg_launch_s = (kern_ms / 1e3) / max(1, launches)
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = l2_hit = None
+        traffic = l2_hit = traffic_unc = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 traffic = sum(j.get(k, {}).get("hbm_bytes_per_iteration", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
+                traffic_unc = sum(j.get(k, {}).get("hbm_bytes_per_iteration_uncorrected", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
                 l2_hit = {k: j[k]["l2_hit_rate"] for k in ("k_nn_iter", "k_nn_tiles", "k_accumulate_matches", "k_icp_late") if k in j and "l2_hit_rate" in j[k]} or None
             except Exception:
-                traffic = l2_hit = None
+                traffic = l2_hit = traffic_unc = None
         in_region = achieved
         alone = alg_bytes / (alone_ms / 1e3) / 1e9 if alone_ms > 0 else 0.0
         # one whole linearisation of the SHIPPED schedule (correspondence step + residuals + reduction + solve; fused k_icp_late launches included):
@@ -469,7 +470,10 @@ def main():
                          "achieved": in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": in_region / HBM_PEAK_GBS,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches, "concurrent_chains": D,
                          "frac_source": "hipEvent brackets inside the timed region (every --event-every-th iteration), on the library's stream",
-                         "traffic": traffic, "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_gpu.sh, not measured in this run)",
+                         "traffic": traffic, "traffic_fetch_uncorrected": traffic_unc,
+                         "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_gpu.sh, not measured in this run); `traffic` = FETCH_SIZE x 2 + "
+                                           "WRITE_SIZE (the guide's gfx950 correction, calibrated for wide coalesced streaming reads), `traffic_fetch_uncorrected` = FETCH_SIZE + WRITE_SIZE: these kernels "
+                                           "mix 16-B streams with 16-B gathers, for which the guide gives no calibration — the true figure lies between the two",
                          "l2_hit_rate": l2_hit,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gather_model": gather_model,

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/st_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/st_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 --queue-depth 1 --no-events $BENCH_ARGS > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/st_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 --queue-depth 1 --no-events --min-seconds 0 $BENCH_ARGS > /dev/null 2>&1
 done
 python3 - <<PY
 import csv,glob,collections
