@@ -857,8 +857,19 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     // bound that some candidate already met, a skipped chunk's box distance and every loser go into `sec`.
     {
         const int lane = (int)(threadIdx.x & 63u), g0 = lane & ~7;
+        // the lane that holds the query's HOME bucket first (its nearest row was set aside first): on a crowded level everything is set aside, and
+        // the first chunks scanned are scanned against d_max — let them be the ones around the query. The bound is agreed on after every row.
+        int hsub = 0;
+        if (ok && Q.lo[0] <= Q.hi[0] && Q.lo[1] <= Q.hi[1] && Q.lo[2] <= Q.hi[2]) {
+            const int b0x = Q.lo[0] >> 1, b0y = Q.lo[1] >> 1, b0z = Q.lo[2] >> 1;
+            const int nbx = (Q.hi[0] >> 1) - b0x, nby = (Q.hi[1] >> 1) - b0y, nbz = (Q.hi[2] >> 1) - b0z;
+            const int hx = min(max((Q.ic[0] >> 1) - b0x, 0), nbx), hy = min(max((Q.ic[1] >> 1) - b0y, 0), nby), hz = min(max((Q.ic[2] >> 1) - b0z, 0), nbz);
+            hsub = hx | (hy << nbx) | (hz << (nbx + nby));
+        }
+        hsub = __shfl(hsub, g0);   // (group-uniform by construction; taken from the group's first lane so that an idle group agrees with itself too)
 #pragma unroll 1
-        for (int L = 0; L < 8; L++) {
+        for (int L0 = 0; L0 < 8; L0++) {
+            const int L = (hsub + L0) & 7;
             const int ndL = __shfl(D.n, g0 + L);
 #pragma unroll 1
             for (int r = 0; r < ndL; r++) {   // (uniform inside a group)
@@ -874,6 +885,12 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
                     if (bd > W.bound) { W.sec = min(W.sec, __float_as_uint(bd)); continue; }
                     m3d_scan_range(pts, max(tb, c * M3D_CHUNK), min(te, (c + 1u) * M3D_CHUNK), vx, vy, vz, W, sit);
                     W.bound = fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f);
+                }
+                {   // (every lane of the group is here: ndL and r are uniform inside a group)
+                    float bnd = W.bound;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) bnd = fminf(bnd, __shfl_xor(bnd, o));
+                    W.bound = bnd;
                 }
             }
         }

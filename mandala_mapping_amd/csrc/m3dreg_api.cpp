@@ -131,8 +131,8 @@ struct m3dreg_handle {
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
     int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
     bool batch_all_tiles = false;
-    int fuse_from = 10;                // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
-    int tile_iters = 10;               // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
+    int fuse_from = 8;                 // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
+    int tile_iters = 8;                // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
     int* d_match = nullptr;            // [pairs * match_stride] x {match int32 | pad | cache int64 | certificate state float4} (variant 2)
     long long* d_partials = nullptr;   // block partial sums of the reduction pass
     unsigned int* d_tickets = nullptr; // arrival counters of the reduction pass
@@ -999,6 +999,9 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     for (int l = 0; l < P.n_levels; l++) {
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
         const unsigned int level_first_seq = h->seq + 1;
+        // (the fused late launches only on the finest level: a pyramid's coarser levels are the crowded ones, where the uncertified few of a late
+        // iteration are long cooperative walks behind a fat workgroup's stream — config 5 with them fused from the 8th iteration: 4.12 instead of 3.82 ms)
+        const int fuse_from_l = (l < P.n_levels - 1) ? 0 : h->fuse_from;
         for (int it = 0; it < P.iterations[l]; it++) {
             if (can_stop_early && it > 0) {   // nothing left to do at this level? (a stale value only delays the exit)
                 const unsigned long long v = *h->h_progress;
@@ -1019,7 +1022,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                     if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
                 }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((h->fuse_from > 0 && it >= h->fuse_from) ? -2 : -1) : 0), nn_work(h, l), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0), nn_work(h, l), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             roctx_pop();
             h->launched_iters++;
         }
