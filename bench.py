@@ -559,11 +559,13 @@ def run_config5(args):
     bucket_ms = mb_ / max(1, nb_)                      # the bucketing pipeline itself: hipEvents on the library's stream around its kernels (three levels + normal grid + tiles)
     R.profile_enable(False)
     tgt2.free()
-    src = R.clouds([live], source_only=[True])[0]
+    from mandala_mapping_amd.pointcloud2 import encode_xyz
+    live_msg = encode_xyz(live)        # the PointCloud2 message as the producer hands it over (encoding it is the aggregator's work, not the registration's)
+    src = R.clouds([live_msg], source_only=[True])[0]
     times = []
     for i in range(args.warmup + args.steps):
         R.synchronize(); t0 = time.perf_counter()
-        s_ = R.clouds([live], source_only=[True])[0]
+        s_ = R.clouds([live_msg], source_only=[True])[0]
         T, st = R.align(s_, tgt, T0)
         times.append(1e3 * (time.perf_counter() - t0))
         s_.free()
