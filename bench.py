@@ -214,11 +214,19 @@ def main():
     elif args.pair_offset is not None:
         pair_ids, generated = [args.pair_offset + i for i in range(B)], {}
     elif world > 1 and args.shard == "lpt":
-        # every rank generates all pairs and derives the same assignment: no communication, deterministic
-        generated = {k: gen_pair(k) for k in range(world * B)}
-        costs = [synth.crowdedness(generated[k][0]) + synth.crowdedness(generated[k][1]) for k in range(world * B)]
+        # every rank derives the same assignment from the same a-priori costs: no communication, deterministic. The costs of the 64 standard pairs are
+        # tabulated (mandala_mapping_amd/config4_costs.json; ray-casting all of them takes half a minute per rank) — anything else is computed here
+        costs, generated = None, {}
+        tab = os.path.join(ROOT, "mandala_mapping_amd", "config4_costs.json")
+        if args.workload == "config4" and os.path.exists(tab):
+            t_ = json.load(open(tab))
+            if t_.get("azimuth") == args.azimuth and len(t_["costs"]) >= world * B:
+                costs = t_["costs"][: world * B]
+        if costs is None:
+            generated = {k: gen_pair(k) for k in range(world * B)}
+            costs = [synth.crowdedness(generated[k][0]) + synth.crowdedness(generated[k][1]) for k in range(world * B)]
         pair_ids = sharding.lpt_assign(costs, world, capacity=B)[rank]
-        generated = {k: generated[k] for k in pair_ids}
+        generated = {k: generated[k] for k in pair_ids if k in generated}
     else:
         pair_ids, generated = [rank * B + i for i in range(B)], {}
     for i in range(B):

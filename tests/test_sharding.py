@@ -112,3 +112,53 @@ def test_lpt_assignment_with_capacity():
     import pytest
     with pytest.raises(ValueError):
         sharding.lpt_assign(costs, 2, capacity=3)
+
+
+def test_config4_cost_table_matches_the_generator():
+    """bench.py derives every rank's shard of BASELINE config 4 from mandala_mapping_amd/config4_costs.json instead of ray-casting all 64 pairs on every rank:
+    the table must be what the generator gives (three pairs recomputed here), and give every rank 8 pairs at N = 8."""
+    import json
+    import os
+    from mandala_mapping_amd import synth
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mandala_mapping_amd", "config4_costs.json")))
+    assert tab["azimuth"] == 3125 and len(tab["costs"]) == 64
+    for k in (0, 17, 63):
+        s, t, _ = synth.config4_pair(k, 3125)
+        assert abs(tab["costs"][k] - (synth.crowdedness(s) + synth.crowdedness(t))) < 1e-4
+    sh = sharding.lpt_assign(tab["costs"], 8, capacity=8)
+    assert sorted(sum(sh, [])) == list(range(64)) and all(len(x) == 8 for x in sh)
+    loads = [sum(tab["costs"][i] for i in x) for x in sh]
+    # one pair of the 64 costs twice what the others do (22.6 against 11.3 - 18): with 8 pairs per rank the rank that holds it cannot get below that pair
+    # plus the seven cheapest ones — the assignment must reach that bound (LPT + swap refinement), and the other ranks must lie below it
+    c = sorted(tab["costs"])
+    assert max(loads) <= c[-1] + sum(c[:7]) + 0.2 and max(loads) / min(loads) < 1.09
+
+
+@pytest.mark.gpu
+def test_pose_gather_on_the_gpu_under_a_single_rank_nccl_group():
+    """The pose gather's GPU path (pinned record blocks, its own stream, RCCL all_gather_into_tensor, non-blocking copy back, event) has only ever a
+    one-GPU box to run on: a single-rank `nccl` group exercises every call of it — several gathers in flight, results in pair order."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 8
+        tickets = []
+        for step in range(3):
+            T = np.stack([np.eye(4) * (step + 1) + k for k in range(n)])
+            tickets.append(sharding.gather_results_start(list(range(n))[::-1], T[::-1], [k + step for k in range(n)][::-1], n, dist, dev))
+        for step, tk in enumerate(tickets):
+            Tg, st = sharding.gather_results_finish(tk)
+            assert [Tg[k, 0, 0] for k in range(n)] == [step + 1 + k for k in range(n)] and list(st) == [k + step for k in range(n)]
+        g = sharding._gather_for(n, dist, dev)
+        assert g.on_gpu and g.slots[0]["rec_h"].is_pinned() and g.slots[0]["out_h"].is_pinned()
+        tt = torch.tensor([1.25], dtype=torch.float64, device=dev)      # bench.py's max-over-ranks of a block time
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert float(tt.item()) == 1.25
+    finally:
+        dist.destroy_process_group()
