@@ -290,7 +290,11 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
         L.cbox = k.take<float4>(2 * ((n + M3D_CHUNK - 1) / M3D_CHUNK));
         L.order = k.take<uint32_t>((n + 255) / 256);
-        if (!c->source_only) {   // a cloud that can be a target: its tiles
+        // tiles only where they are used: a target's FINEST level. A pyramid's coarser levels hold too many points per bucket for an image (their tiles
+        // ended up flagged, their searches in the global walk anyway) — not carving them saves 1.5 images of 56 KB per 512 points and a 1 MiB bitmap per
+        // level (a 2 M-point map: 330 MB per level) and two thirds of k_tile_build's work on a pyramid.
+        static const bool tiles_all_levels = [] { const char* v = getenv("M3DREG_TILES_ALL_LEVELS"); return v && atoi(v); }();
+        if (!c->source_only && (l == P.n_levels - 1 || tiles_all_levels)) {
             const size_t nt = size_t(m3d_tiles_of(int(n))), ni = nt + size_t(m3d_tile_pool(int(nt)));
             L.thdr = k.take<M3dTileHdr>(nt);
             L.timg = k.take<uint8_t>(ni * M3D_TILE_IMG_BYTES);
@@ -456,7 +460,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             if (!is_ng && no_normals && gidx - (want_normals ? 1 : 0) < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // nor the coarser levels of its pyramid: a registration streams a source in its FINEST level's order on every level (build_jobs)
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
             any_fine = any_fine || B.fine >= 0;
-            if (!is_ng && !no_normals && h->tiles) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = true; c->has_tiles = true; }
+            if (!is_ng && !no_normals && h->tiles && L.thdr) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = true; c->has_tiles = true; }
         }
     }
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
