@@ -154,6 +154,9 @@ def main():
         return run_multi(args)
     if (args.gpus > 1 or args.spawn) and "M3D_BENCH_RANK_PROCESS" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         return launch_ranks(args)
+    if os.environ.get("M3D_BENCH_DRYRUN"):   # tests/test_bench_launcher.py: what a rank process is started with (no GPU, no torch)
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"argv": sys.argv[1:]}), flush=True)
+        return
     import torch
     import torch.distributed as dist
     from mandala_mapping_amd import abi, binding, sharding, synth

@@ -159,7 +159,13 @@ int m3dreg_cloud_create(m3dreg_handle* h, const void* data, size_t n, size_t poi
  *                                    (m3dreg_synchronize, m3dreg_cloud_status, or the wait of a registration that uses the
  *                                    cloud). A cloud that turns out empty or too large ends every registration that names it
  *                                    with status M3DREG_BAD_CLOUD; m3dreg_cloud_status (waits) returns its error code, and so
- *                                    do m3dreg_cloud_grid_info / _export. */
+ *                                    do m3dreg_cloud_grid_info / _export.
+ * HBM held by a bucketed cloud of n points, per level (one pooled block per cloud, returned to the handle's pool on destroy): 72 B per point
+ * (sorted points, keys, sorted keys, permutation, chunk boxes, block order, normals in sorted order when point-to-plane) + 32 B x the next
+ * power of two >= 2n (bucket table; its used part is sized on the device) — plus, on the FINEST level of a cloud that can be a target,
+ * 1.5 tile images of 56 KB per 512 points and a 1 MiB occupancy bitmap (164 B per point: 17 MB for a 100 k-point sweep, 250 MB for a
+ * 1.5 M-point map) — plus 16 B (+ 16 B normals) per point in input order, shared by the levels. A source_only cloud builds its finest
+ * level only, without table, tiles or normals. */
 typedef struct m3dreg_cloud_desc {
     const void* data;     /* PointCloud2 payload (host, or device when data_is_device != 0) */
     size_t n, point_step, off_x, off_y, off_z;

@@ -192,6 +192,12 @@ std::atomic<int> g_fail_alloc{0};
 inline void alloc_point() { int v = g_fail_alloc.load(); if (v > 0 && g_fail_alloc.fetch_sub(1) == 1) throw std::bad_alloc(); }
 
 
+// A handle that was destroyed while clouds of it were still alive lives on until the last of them is released — but a stream the CALLER lent it
+// (m3dreg_create's `stream`) may be gone by then: after m3dreg_destroy nothing touches a borrowed stream any more, the device is synchronised instead
+// (ADVICE r2).
+inline bool stream_usable(const m3dreg_handle* h) { return h->own_stream || !h->closed; }
+inline hipError_t sync_handle(m3dreg_handle* h) { return stream_usable(h) ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize(); }
+
 const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
 
 int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
@@ -222,7 +228,7 @@ int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
 // Blocks go back to the cache without a device sync: every use of a block is ordered on the handle's stream.
 void pool_put(m3dreg_handle* h, Block b) {
     if (!b.p) return;
-    if (h->pool_bytes + b.bytes > POOL_CAP_BYTES) { hipStreamSynchronize(h->stream); hipFree(b.p); return; }
+    if (h->pool_bytes + b.bytes > POOL_CAP_BYTES) { sync_handle(h); hipFree(b.p); return; }
     h->pool.push_back(b);
     h->pool_bytes += b.bytes;
 }
@@ -255,7 +261,7 @@ void free_cloud(m3dreg_handle* h, m3dreg_cloud* c) {
     m3dreg_handle* o = c->owner ? c->owner : h;
     if (c->ready && --c->ready->refs == 0) { hipEventDestroy(c->ready->ev); delete c->ready; }
     if (c->last_use) {
-        if (o) { hipSetDevice(o->device); hipStreamWaitEvent(o->stream, c->last_use, 0); }
+        if (o) { hipSetDevice(o->device); if (stream_usable(o)) hipStreamWaitEvent(o->stream, c->last_use, 0); else hipEventSynchronize(c->last_use); }
         hipEventDestroy(c->last_use);
     }
     if (o) pool_put(o, c->block); else if (c->block.p) hipFree(c->block.p);
@@ -778,7 +784,7 @@ void roctx_pop() {
 
 void release_handle(m3dreg_handle* h) {
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    sync_handle(h);
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
