@@ -344,6 +344,29 @@ def test_config5_dense_map_multiresolution(reg, orc):
     assert rot < 0.05 and tra < 0.01, (rot, tra)
 
 
+def test_crowded_coarse_level_is_walked_cooperatively_and_stays_exact(reg, orc):
+    """A pyramid whose coarse level holds hundreds of points per voxel (a dense map): that level is sorted from the finest level's order, has no
+    tiles, and k_patch_jobs sends every one of its searches to the eight-lanes-per-query walk (M3dJob::coop_always, more than 48 points per occupied
+    voxel) — exports in the spec's order, every per-iteration pose and the statistics equal to the oracle's; point-to-point and point-to-plane."""
+    tgt = synth.planes_cloud(60000, 3100, sigma=0.01, size=3.0)
+    Tg = synth.make_T(synth.rot_z(np.radians(2.0)) @ synth.rot_x(np.radians(-1.0)), np.array([0.12, -0.08, 0.05]))
+    src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(20000, 3101, sigma=0.01, size=3.0).astype(np.float64)).astype(np.float32)
+    for metric in (abi.POINT_TO_PLANE, abi.POINT_TO_POINT):
+        p = _params(leaf=(0.4, 0.1), iterations=(10, 6), max_corr_dist=(1.0, 0.5), metric=metric, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+        R = reg.Registrar(p)
+        cs, ct = R.clouds([src, tgt], source_only=[True, False])
+        ot = orc.Cloud(p, tgt, omp=True)
+        g0 = ct.grid_info(0)
+        assert g0.n_valid > 48 * g0.n_cells                       # the coarse level IS crowded
+        _check_bucketing(ct, ot, 2)
+        T, st = R.align(cs, ct)
+        To, sto, tro = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), ot, trace_cap=32)
+        assert np.array_equal(R.trace(), tro) and np.array_equal(T, To)
+        _same_stats(st, sto)
+        e0, e1 = synth.pose_error(np.eye(4), Tg), synth.pose_error(T, Tg)
+        assert e1[0] < e0[0] and e1[1] < e0[1], (e0, e1)        # (parity is the point here; 16 iterations on three 3 m planes only have to go the right way)
+
+
 def test_config5_full_size_properties(reg):
     """BASELINE config 5 at full size: ~2 M-point map vs 100 k live scan, multi-resolution voxel NN."""
     live, mp, Tgt, T0 = synth.config5()
