@@ -677,7 +677,11 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
         mask &= mask - 1u;
         const uint32_t key = Q.key0 + (uint32_t)kdelta[b];
         const m3d_u32x2 s = m3d_tile_find(vs, key);
+#ifdef M3D_EXP_NOSCAN2   // (timing experiment only — WRONG results: the surviving voxels are looked up but their points are not compared)
+        if (s.x == key) Q.sec = min(Q.sec, s.y);
+#else
         if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
+#endif
     }
     if (step > 1u) {
         // the group's result: the smallest key; every other lane's NEW key lost to it (the old best, where a lane kept it, was
