@@ -707,6 +707,7 @@ struct M3dNnArgs {
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
     int rot;                           // XCD rotation of the block -> pair map (m3d_map_block)
+    int coop_kernel;                   // 1 = k_nn_coop follows this launch: the pairs whose target level is crowded (M3dJob::coop_always) are ITS work, k_nn_iter leaves them alone
     // the LDS-staged search: a block with many queries to search BINS them by the target tile that owns their home bucket
     // (k_nn_iter), k_nn_tiles then answers every tile's queries from LDS
     int tiles;                         // 1 = on
@@ -937,6 +938,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
 template <bool LEAN>
 __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
+    if (!LEAN && A.coop_kernel && J.coop_always) return;   // (block-uniform) a crowded level: k_nn_coop, launched right behind, answers this pair
     {   // the source's crowded blocks first (they run several times as long as the rest: started last they were the kernel's tail)
         const uint32_t* ord = J.src_order;
         if (ord && blk < J.src_nblk) blk = (int)ord[blk];
@@ -1168,6 +1170,46 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __syncthreads();
 #endif
     M3D_BT_END(nW);
+    }
+}
+
+// k_nn_coop: the correspondence step of a CROWDED level (M3dJob::coop_always: a coarse level of a dense map, a hundred and more points per voxel) —
+// eight lanes per query like k_nn_iter's cooperative walk, but a workgroup owns 32 queries, not 256: the walk of such a query is a chain of a dozen
+// dependent rounds (boxes of a voxel's chunks, then the chunks that can still win), and k_nn_iter's workgroups went through EIGHT passes of 32 queries
+// one after the other while a 100 k-query level filled 1.5 waves per SIMD. Eight times as many workgroups, one pass each: config 5's 0.4 m level
+// 0.175 -> see DESIGN ms per iteration. Launched behind k_nn_iter<false> on the coarser levels of a pyramid; its workgroups leave at once where the target
+// level is not crowded (and k_nn_iter's where it is). Every lane of a group classifies its group's query (same addresses: one transaction).
+__global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    NN_SETUP();
+    if (!J.coop_always) return;   // (block-uniform)
+    {   // the crowded 256-point blocks first, like k_nn_iter: this workgroup is an eighth of one
+        const uint32_t* ord = J.src_order;
+        const int b256 = blk >> 3;
+        if (ord && b256 < J.src_nblk) blk = (int)ord[b256] * 8 + (blk & 7);
+    }
+    const int tid = (int)threadIdx.x, sub = tid & 7;
+    const int i = blk * 32 + (tid >> 3);
+    int cls = 0;
+    float ux = 0.f, uy = 0.f, uz = 0.f, dseed = 0.f;
+    if (i < n) {
+        const float4 p = m3d_ld(src, i);
+        ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        if (first_of_level) {
+            if (m3d_finite3(ux, uy, uz)) cls = 2; else if (sub == 0) out[i] = -1;
+        } else {
+            const int mp = out[i];
+            bool certified; float4 q1;
+            cls = m3d_classify(g, pts, out, cache, state, i, mp, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, 0);   // (the eight lanes of a group store the same correction, if any)
+        }
+    }
+    long long code; float sec;
+    const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, 0);
+    if (cls != 0 && sub == 0) {
+        out[i] = m;
+        if (m == M3D_NN_NONE_CACHED) cache[i] = code;
+        if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
     }
 }
 
@@ -1797,7 +1839,7 @@ int m3d_ticket_words(int n_pairs, int max_n_src) {
 static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, const M3dNnWork& w,
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
+    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
     A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
@@ -1826,6 +1868,11 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");
+        if (A.coop_kernel) {   // a coarser level of a pyramid: where it is crowded (decided on the device, per pair) this kernel does the work, not the one above
+            const int bpp_c = 8 * bpp_s;
+            hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A);
+            M3D_DBG(s, "k_nn_coop");
+        }
     }
     if (w.tiles && !late) {
         hipLaunchKernelGGL(k_nn_tiles, dim3(M3D_TILE_GRID), dim3(M3D_TILE_THREADS), 0, s, d_jobs, first_of_level, A);

@@ -150,7 +150,9 @@ struct M3dJob {            // one pair at one level
                                // map): every search of k_nn_iter<false> is walked eight lanes per query and none is binned to tiles (they cannot be staged)
     int32_t pad_;
 };
+#ifndef M3D_COOP_DENSITY
 #define M3D_COOP_DENSITY 48
+#endif
 
 // ---- spec primitives shared by every kernel (operation order is normative) --------
 __device__ __forceinline__ bool m3d_finite3(float x, float y, float z) {

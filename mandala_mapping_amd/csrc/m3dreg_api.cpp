@@ -669,6 +669,8 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     static const int lean_levels = [] { const char* v = getenv("M3DREG_LEAN_LEVELS"); return v ? atoi(v) : 0; }();   // 0: one-level registrations only (default), 1: also the finest level of a pyramid — measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would send every query to the fallback list
     const bool lean_here = h->params.n_levels == 1 || (lean_levels && level == h->params.n_levels - 1);
     w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
+    static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();   // 0: crowded levels stay inside k_nn_iter<false> (A/B)
+    w.coop_kernel = (coop_kernel && level >= 0 && level < h->params.n_levels - 1) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
