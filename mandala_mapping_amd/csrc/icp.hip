@@ -672,16 +672,33 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
     // SLOWER; the re-test costs every visit ~15 instructions and a dependent LDS read, and prunes little: most of what survives phase 1 is
     // genuinely close. Throw-away builds, iteration 0 of the bench batch: 10 us of the launch are records + staging + results, 11 the home
     // voxel, 7 the 26 probes, 23 this loop.)
-    while (mask) {
-        const int b = __ffs((int)mask) - 1;
+    // (software-pipelined: the NEXT voxel's key offset and first directory slot are requested before the current voxel's points are compared — the
+    // kernel waits for LDS round trips, not for the VALU, and a visit was three dependent ones: offset table, directory slot, points)
+    if (mask) {
+        int b = __ffs((int)mask) - 1;
         mask &= mask - 1u;
-        const uint32_t key = Q.key0 + (uint32_t)kdelta[b];
-        const m3d_u32x2 s = m3d_tile_find(vs, key);
+        uint32_t key = Q.key0 + (uint32_t)kdelta[b];
+        uint32_t h = (key * 0x9E3779B1u) >> (32 - 11);
+        m3d_u32x2 s = vs[h];
+        for (;;) {
+            const bool more = mask != 0u;
+            uint32_t key_n = 0u, h_n = 0u; m3d_u32x2 s_n = (m3d_u32x2){ M3D_INVALID_KEY, 0u };
+            if (more) {
+                const int b2 = __ffs((int)mask) - 1;
+                mask &= mask - 1u;
+                key_n = Q.key0 + (uint32_t)kdelta[b2];
+                h_n = (key_n * 0x9E3779B1u) >> (32 - 11);
+                s_n = vs[h_n];
+            }
+            while (s.x != key && s.x != M3D_INVALID_KEY) { h = (h + 1u) & (M3D_TILE_VS - 1u); s = vs[h]; }   // (linear probing past the rare collision)
 #ifdef M3D_EXP_NOSCAN2   // (timing experiment only — WRONG results: the surviving voxels are looked up but their points are not compared)
-        if (s.x == key) Q.sec = min(Q.sec, s.y);
+            if (s.x == key) Q.sec = min(Q.sec, s.y);
 #else
-        if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
+            if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
 #endif
+            if (!more) break;
+            key = key_n; h = h_n; s = s_n;
+        }
     }
     if (step > 1u) {
         // the group's result: the smallest key; every other lane's NEW key lost to it (the old best, where a lane kept it, was
