@@ -344,6 +344,41 @@ def test_config5_dense_map_multiresolution(reg, orc):
     assert rot < 0.05 and tra < 0.01, (rot, tra)
 
 
+def test_exact_distance_ties_go_to_the_lowest_input_index(reg, orc, monkeypatch):
+    """Spec: ties of the squared distance go to the lowest INPUT index. Two lattices of exactly representable coordinates, the source half a spacing off:
+    at the first iteration EVERY query is exactly equally far from two (or four) target points that lie in DIFFERENT voxels, and the target's input order is
+    shuffled, so sorted position and input index disagree about who comes first. The LDS tile search, the global walk and the oracle must agree on every pose.
+    (Round 3 tried staged points that carry their sorted position — the winner's position being the answer, input indices fetched only for such ties — to
+    spare the search its last dependent load; exact, by this test, and 19 % slower: the tie check sits in the innermost loop.)"""
+    rng = np.random.default_rng(12)
+    ii, jj, kk = np.meshgrid(np.arange(40), np.arange(40), np.arange(3), indexing="ij")
+    tgt = np.stack([0.5 * ii, 0.5 * jj, 1.0 * kk], -1).reshape(-1, 3).astype(np.float32)
+    tgt = tgt[rng.permutation(len(tgt))]
+    src = (tgt + np.array([0.25, 0.25, 0.0], np.float32))[rng.permutation(len(tgt))][:3000]
+    p = _params(leaf=0.25, iterations=4, max_corr_dist=0.6, metric=abi.POINT_TO_POINT, eps_rot=0.0, eps_trans=0.0)
+    ot, os_ = orc.Cloud(p, tgt), orc.Cloud(p, src)
+    q = src[:500]
+    io, do = ot.nn(q, 0.6)
+    e = q[:, None, :] - tgt[None, :, :]
+    d2 = (e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1]) + e[..., 2] * e[..., 2]
+    assert ((d2 == d2.min(1, keepdims=True)).sum(1) >= 2).all()              # every query really has an exact tie
+    assert np.array_equal(io, np.argmax(d2 == d2.min(1, keepdims=True), axis=1))   # and the oracle takes the lowest input index
+    To, sto, tro = orc.align(p, os_, ot, trace_cap=8)
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("M3DREG_TILES", tiles)
+        R = reg.Registrar(p)
+        cs, ct = R.cloud(src), R.cloud(tgt)
+        i1, d1 = ct.nn(q, 0.6)
+        assert np.array_equal(i1, io) and np.array_equal(d1.view(np.uint32), do.view(np.uint32))
+        s1, e1 = R.accumulate(cs, ct, np.eye(4))
+        s2, e2 = orc.accumulate(p, os_, ot, np.eye(4))
+        assert np.array_equal(s1, s2) and np.array_equal(e1, e2)
+        T, st = R.align(cs, ct)
+        assert np.array_equal(R.trace(), tro) and np.array_equal(T, To)
+        _same_stats(st, sto)
+        assert (R.counters()[0] > 0) == (tiles == "1")
+
+
 def test_crowded_coarse_level_is_walked_cooperatively_and_stays_exact(reg, orc):
     """A pyramid whose coarse level holds hundreds of points per voxel (a dense map): that level is sorted from the finest level's order, has no
     tiles, and k_patch_jobs sends every one of its searches to the eight-lanes-per-query walk (M3dJob::coop_always, more than 48 points per occupied
