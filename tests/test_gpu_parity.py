@@ -402,6 +402,35 @@ def test_crowded_coarse_level_is_walked_cooperatively_and_stays_exact(reg, orc):
         assert e1[0] < e0[0] and e1[1] < e0[1], (e0, e1)        # (parity is the point here; 16 iterations on three 3 m planes only have to go the right way)
 
 
+@pytest.mark.parametrize("n_pairs", [3, 8])
+def test_batch_mixing_crowded_and_ordinary_coarse_levels(reg, orc, n_pairs):
+    """One batch, two levels: some pairs' coarse level is crowded (k_nn_coop answers them, k_nn_iter's workgroups leave), the others' is not (the other way
+    round) — decided per pair on the device. 3 pairs (block -> pair map by division) and 8 (one pair per XCD): every pose equals the pair registered alone
+    and the oracle's."""
+    p = _params(leaf=(0.4, 0.1), iterations=(6, 5), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    data = []
+    for k in range(n_pairs):
+        if k % 2 == 0:   # dense planes: hundreds of points per 0.4 m voxel
+            tgt = synth.planes_cloud(40000 + 3000 * k, 3300 + k, sigma=0.01, size=3.0)
+            Tg = synth.make_T(synth.rot_z(np.radians(1.0 + 0.2 * k)), np.array([0.08, -0.05, 0.03]))
+            src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(12000, 3400 + k, sigma=0.01, size=3.0).astype(np.float64)).astype(np.float32)
+        else:            # an HDL-32-shaped sweep: a handful of points per voxel
+            src, tgt, Tg = synth.hdl32_pair(500 + 40 * k, 3500 + k, 3600 + k, dx=0.2, dy=0.05, dyaw_deg=1.5)
+        data.append((src, tgt))
+    clouds = [tuple(R.clouds([s_, t_], source_only=[True, False])) for s_, t_ in data]
+    dens = [c[1].grid_info(0).n_valid / max(1, c[1].grid_info(0).n_cells) for c in clouds]
+    assert max(dens) > 48 and min(dens) < 48, dens
+    Tb, stb = R.align_batch([(cs, ct, None) for cs, ct in clouds])
+    for k, (src, tgt) in enumerate(data):
+        T1, st1 = R.align(clouds[k][0], clouds[k][1])
+        assert np.array_equal(T1, Tb[k]) and st1.n_corr == stb[k].n_corr, k
+        if k < 3:
+            To, sto, _ = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True))
+            assert np.array_equal(Tb[k], To), k
+            _same_stats(stb[k], sto)
+
+
 def test_config5_full_size_properties(reg):
     """BASELINE config 5 at full size: ~2 M-point map vs 100 k live scan, multi-resolution voxel NN."""
     live, mp, Tgt, T0 = synth.config5()
