@@ -30,6 +30,11 @@ for case in range(n_cases):
         src, tgt, Tgt = synth.hdl32_pair(n_az, int(rng.integers(1, 10**6)), int(rng.integers(1, 10**6)), dx=float(rng.uniform(-0.4, 0.4)),
                                          dy=float(rng.uniform(-0.3, 0.3)), dyaw_deg=float(rng.uniform(-4, 4)),
                                          base=(float(rng.uniform(-5, 5)), float(rng.uniform(-3, 3)), float(rng.uniform(-180, 180))))
+        if rng.integers(0, 5) == 0:   # a fifth: dense planes (hundreds of points per coarse voxel: the crowded-level kernels, k_nn_coop on a pyramid's coarse level)
+            size = float(rng.choice([2.0, 3.0, 5.0]))
+            tgt = synth.planes_cloud(int(rng.integers(8000, 50000)), int(rng.integers(1, 10**6)), sigma=0.01, size=size)
+            Tgt = synth.make_T(synth.rot_z(np.radians(float(rng.uniform(-2, 2)))) @ synth.rot_x(np.radians(float(rng.uniform(-1, 1)))), rng.uniform(-0.1, 0.1, 3))
+            src = synth.apply_T(synth.inv_T(Tgt), synth.planes_cloud(int(rng.integers(3000, 20000)), int(rng.integers(1, 10**6)), sigma=0.01, size=size).astype(np.float64)).astype(np.float32)
         if rng.integers(0, 3) == 0:
             src = src.copy(); src[:: int(rng.integers(17, 90))] = np.nan
         if rng.integers(0, 4) == 0:
