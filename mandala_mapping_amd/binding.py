@@ -45,7 +45,7 @@ def lib():
     global _lib, LIB_PATH
     if _lib is not None:
         return _lib
-    LIB_PATH = os.environ.get("M3DREG_LIB", LIB_PATH)   # A/B of two builds on one box (scripts/ab.sh)
+    LIB_PATH = os.environ.get("M3DREG_LIB") or LIB_PATH   # A/B of two builds on one box (scripts/ab.sh)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the registration path)")

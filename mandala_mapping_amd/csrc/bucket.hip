@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 // Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same
 // normal — the per-point version did 10x the hash probes for identical results): add the (shifted) moments of the 27
 // voxels around it and take the smallest eigenvector of the covariance. The result is stored in the slot of the voxel's
-// first point; k_spread_normals copies it to the others.
+// first point, and the same launch hands it to the voxel's other points (nrm_in, by input index).
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
@@ -1015,7 +1015,8 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const int grp = tl >> 3, part = tl & 7;
     const uint32_t n_vox = B.dyn[5];
     __shared__ long long s_sum[64][10];
-    __shared__ uint32_t s_oi[64];
+    __shared__ uint32_t s_head[65];   // first sorted position of the trip's voxels, and of the voxel after them
+    __shared__ float4 s_nrm[64];
     for (uint32_t vb = blockIdx.x * 64u; vb < n_vox; vb += gridDim.x * 64u) {   // (block-uniform: barriers and shuffles inside)
     for (int rnd = 0; rnd < 2; rnd++) {
     const int li = rnd * 32 + wv * 8 + grp;   // voxel of this trip this group sums up
@@ -1026,7 +1027,6 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const M3dGrid& g = L.g;
     const long long* mom = B.mom;
     const float4 pj = L.pts[j];
-    const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
     const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
               icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
     long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
@@ -1073,9 +1073,11 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     if (part == 0) {
         s_sum[li][0] = k; s_sum[li][1] = s0; s_sum[li][2] = s1; s_sum[li][3] = s2; s_sum[li][4] = q0;
         s_sum[li][5] = q1; s_sum[li][6] = q2; s_sum[li][7] = q3; s_sum[li][8] = q4; s_sum[li][9] = q5;
-        s_oi[li] = oi;
+        if (act) s_head[li] = (uint32_t)j;   // (slot n_trip belongs to thread 0 below)
     }
     }
+    const uint32_t n_trip = min(64u, n_vox - vb);
+    if (threadIdx.x == 0) s_head[n_trip] = vb + 64u < n_vox ? voxel_head_list(B)[vb + 64u] : (uint32_t)B.grid.n_valid;
     __syncthreads();
     if (threadIdx.x < 64 && vb + threadIdx.x < n_vox) {
     const long long k = s_sum[threadIdx.x][0], s0 = s_sum[threadIdx.x][1], s1 = s_sum[threadIdx.x][2], s2 = s_sum[threadIdx.x][3], q0 = s_sum[threadIdx.x][4],
@@ -1136,27 +1138,27 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
         if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
         out = make_float4((float)v0, (float)v1, (float)v2, 0.f);
     } while (0);
-    B.nrm_in[s_oi[threadIdx.x]] = out;
+    s_nrm[threadIdx.x] = out;
+    }
+    __syncthreads();
+    // every point takes the normal of its voxel: the trip's voxels are consecutive in the head list, so their points are ONE contiguous
+    // stretch of the sorted order; a thread per position, its voxel found by bisection of the (ascending) heads in LDS. (This was a launch
+    // of its own that probed the hash table once per point to find the head.)
+    {
+        const uint32_t p0 = s_head[0], p1 = s_head[n_trip];
+        const uint32_t* sval = sorted_vals(B);
+        for (uint32_t t = p0 + threadIdx.x; t < p1; t += 256u) {
+            uint32_t lo = 0, hi = n_trip;   // the last voxel with head <= t
+#pragma unroll
+            for (int st = 0; st < 7; st++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (hi - lo > 1u) { if (s_head[mid] <= t) lo = mid; else hi = mid; }
+            }
+            B.nrm_in[sval[t]] = s_nrm[lo];
+        }
     }
     __syncthreads();   // (the sums are overwritten by the next trip)
     }
-}
-
-// Pass 3: every other point takes the normal of its voxel's first point; non-finite points (sorted last) get none
-__global__ __launch_bounds__(256) void k_spread_normals(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    if (!B.mom) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B.n) return;
-    const M3dLevelDev L = build_level(B);
-    const M3dGrid& g = L.g;
-    const float4 pj = L.pts[j];
-    const uint32_t oi = __float_as_uint(pj.w) & M3D_IDX_MASK;
-    if (j >= g.n_valid) { B.nrm_in[oi] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    const int hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
-                                       (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
-    if (hp == j) return;
-    B.nrm_in[oi] = B.nrm_in[__float_as_uint(L.pts[hp].w) & M3D_IDX_MASK];
 }
 
 // normals re-ordered into each level's sorted order: the reduction kernel gathers them by MATCH position, and
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_gather_normals(const M3dBuild* __restri
     if (!B.nrm_sorted) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B.n) return;
-    B.nrm_sorted[j] = B.nrm_in[B.perm_out[j]];
+    B.nrm_sorted[j] = j < B.grid.n_valid ? B.nrm_in[B.perm_out[j]] : make_float4(0.f, 0.f, 0.f, 0.f);   // (non-finite points, sorted last, have none)
 }
 
 // ---- export helpers (introspection API) -----------------------------------------------------------
@@ -1245,8 +1247,6 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
         M3D_DBG(s, "k_cell_moments");
         hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + 63) / 64, 512), n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
-        hipLaunchKernelGGL(k_spread_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
-        M3D_DBG(s, "k_spread_normals");
         hipLaunchKernelGGL(k_gather_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_gather_normals");
     }
