@@ -346,6 +346,8 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 // While a query stays in the same voxel its neighbourhood is the same set of (static) target voxels, so
 // "-2" is answered again without a single probe. Exact: a changed voxel simply re-runs the full search.
 #define M3D_NN_NONE_CACHED (-2)
+#define M3D_NN_PENDING (-3)   // a query k_nn_iter<lean> could not hand to a tile: walked by k_nn_fallback, or (no such launch) by the reduction pass's workgroup that owns it
+#define M3D_LATE_CAP 2048   // LDS worklist entries of k_icp_late / k_accumulate_matches<.., true>: a workgroup owns at most 8 x 256 queries (launch_iteration checks)
 #define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread)
 #define M3D_TILE_CHUNK_CROWDED 64     // ... of a tile with crowded voxels (one per eighth lane)
 #define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
@@ -1131,6 +1133,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 const size_t r = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP + fslot;
                 A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
                 A.recd[r] = dseed;
+                out[i] = M3D_NN_PENDING;
             } else {                // ... walked here, in global memory
                 long long code = 0; float sec = 0.f;
                 const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
@@ -1545,7 +1548,7 @@ __host__ __device__ inline int m3d_ticket_group(int bpp);
 // to arrive adds up the pair's block partials, solves the 6x6 system and updates the pose (a8).
 __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, const M3dJob& J, M3dPairState* st, int n_pairs, int pair, int blk, int bpp,
                                               int first_of_level, const long long* __restrict__ partials, unsigned int* __restrict__ tickets,
-                                              unsigned int seq, unsigned long long* __restrict__ progress, const double* T_pre = nullptr) {
+                                              unsigned int seq, unsigned long long* __restrict__ progress, const double* T_pre = nullptr, unsigned int* zero_word = nullptr) {
     // ---- a8 in the same launch: the LAST block of the pair to finish adds up the pair's block partials and solves.
     // (A separate solve kernel cost its ~10 us plus a dependent-launch gap of ~5 us in every iteration.)
     // The partials are stored and loaded with agent-scope (write-through / coherent) accesses and the writers wait for
@@ -1577,6 +1580,7 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     }
     __syncthreads();
     if (!s_last) return;
+    if (zero_word && threadIdx.x == 0) *zero_word = 0u;   // (every workgroup of the pair has read it: they all arrived)
     {
         const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
         long long v = 0;
@@ -1606,12 +1610,17 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
 }
 
-template <int METRIC>
+// WALK: no k_nn_fallback launch ran before this one (it costs its 5.3 us in every tile iteration for a list that is empty on ordinary
+// clouds): a query k_nn_iter<lean> left M3D_NN_PENDING is walked HERE, by the workgroup that streams it (so nobody else ever reads
+// its match in this launch), 8 lanes per query like k_icp_late's worklist, its residual added on the spot. Unseeded: a seed only
+// bounds the walk, the match is the same. The host picks per registration (nn_work): a handle whose last registration sent many
+// queries this way launches k_nn_fallback again — 391 workgroups per pair walk a long list faster than the 64 of this pass.
+template <int METRIC, bool WALK>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
-                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n, unsigned int* __restrict__ wcount) {
+                                                                    unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n, unsigned int* __restrict__ wcount, M3dNnArgs A) {
     int pair, blk;
     m3d_map_block(n_pairs, bpp, pair, blk, rot);
     if (gw_cnt && blk == 0) {   // the record counters of k_nn_tiles: each is read by several of its workgroups, so they are zeroed one launch later
@@ -1641,13 +1650,54 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0;
     const int n = J.n_src;
-    const int* in = match + (size_t)pair * match_stride;
+    const int* in = (WALK ? A.match : match) + (size_t)pair * match_stride;   // (WALK writes matches: not through the __restrict__ parameter)
     const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
     // NB queries per trip, every load of a stage issued before the first use: the pass is a chain of
     // dependent gathers (match -> point, normal), so its speed is the number of them in flight
     constexpr int NB = 2;   // (4 in flight: 180 VGPRs = 2 waves per SIMD; 2: 154 = 3 waves, same duration alone, +1.7 % with three chains sharing the GPU;
                             //  the next trip's (match, source point) loads issued ahead of this trip's gathers: 170 VGPRs, same duration, -1 %)
     const int stride = bpp * ICP_THREADS;
+    unsigned int* pend_n = nullptr;   // WALK: the pair's count of pending queries (the counter behind its tiles'); the pair's LAST workgroup zeroes it (m3d_pair_tail)
+    if constexpr (WALK) {
+        pend_n = A.tcnt + (size_t)pair * A.cnt_stride + A.ntile_max;
+        if (*pend_n != 0u) {   // (uniform; nearly never taken — and BEFORE the streaming loop: the 29 sums are not live yet, the walk's registers are the loop's)
+            __shared__ int s_pn;
+            __shared__ int s_pend[M3D_LATE_CAP];   // pending queries of this workgroup (it owns at most 8 x 256: launch_iteration checks)
+            if (threadIdx.x == 0) s_pn = 0;
+            __syncthreads();
+            for (int i = blk * ICP_THREADS + (int)threadIdx.x; i < n; i += stride)
+                if (in[i] == M3D_NN_PENDING) { const int w = atomicAdd(&s_pn, 1); if (w < M3D_LATE_CAP) s_pend[w] = i; }
+            __syncthreads();
+            const int nW = min(s_pn, M3D_LATE_CAP);
+            const M3dGrid g = L.g;
+            const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(L.htab));
+            const m3d_gf4 cbox = m3d_as_global(L.cbox);
+            const m3d_gu32 bigcum = m3d_as_global(L.bigcum);
+            M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+            M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
+            M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+            const int sub = (int)threadIdx.x & 7;
+            for (int base = 0; base < nW; base += ICP_THREADS / 8) {   // uniform trip count: the shuffles inside need every lane
+                const int w = base + ((int)threadIdx.x >> 3);
+                const bool act = w < nW;
+                const int qi = act ? s_pend[w] : 0;
+                const float4 ps = m3d_ld(src, qi);
+                const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
+                const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
+                const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
+                long long code; float sec;
+                const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, J.dmax2, act, false, vx, vy, vz, 0.f, sub, code, sec, 0);
+                if (act && sub == 0) {
+                    out[qi] = mq;   // (read back by this workgroup only, below, behind the barrier)
+                    if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
+                    if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
+                }
+            }
+            if (threadIdx.x == 0 && nW > 0) atomicAdd(&st->ctr[1], (unsigned int)nW);
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB];
 #pragma unroll
@@ -1674,7 +1724,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;   // (the reduction below has the barriers that publish it)
     block_reduce_to_global<NACC>(acc, st->sums, partials ? partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE : nullptr);
     if (!fuse_solve || !partials) return;
-    m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, first_of_level, partials, tickets, seq, progress, s_T);
+    m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, first_of_level, partials, tickets, seq, progress, s_T, pend_n);
 }
 
 
@@ -1688,7 +1738,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
 // sums: any order, same bits. The last workgroup of the pair solves, as in k_accumulate_matches.
 // (Round 1 tried this shape against a per-lane walk and a 27 + 6 + 22 us chain and dropped it; with the cooperative walk sharing its
 // crowded rows and the chain at 21 + 18 us of bandwidth-bound launches it pays.)
-#define M3D_LATE_CAP 2048   // worklist entries: a workgroup owns at most 8 x 256 queries (launch_iteration falls back to the two-launch chain otherwise)
 template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, M3dNnArgs A, long long* __restrict__ partials,
                                                           unsigned int* __restrict__ tickets, unsigned int seq, unsigned long long* __restrict__ progress) {
@@ -1875,13 +1924,18 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
         M3D_DBG(s, "k_icp_late");
         return;
     }
-    if (w.tiles && !late && w.lean) {   // (every target of the batch has tiles: build_jobs checked)
+    // the queries k_nn_iter<lean> cannot bin (M3D_NN_PENDING): walked by the reduction pass itself, or — a handle whose last registration had many — by a launch of their own
+    const bool lean_iter = w.tiles && !late && w.lean;
+    const bool walk_in_acc = lean_iter && !w.fallback_launch && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * 8 >= (long long)max_n_src;   // (the pair's last workgroup zeroes the pending count: m3d_pair_tail)
+    if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
-        // (the full grid although the list is normally empty: an empty launch costs 5.2 us whatever its grid — 1, 8, 32 or 391 workgroups per pair,
-        //  measured — and a one-level registration on a coarse grid sends EVERY query here: with 8 workgroups per pair it took ten times as long)
-        hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-        M3D_DBG(s, "k_nn_fallback");
+        if (!walk_in_acc) {
+            // (the full grid although the list is normally empty: an empty launch costs 5.2 us whatever its grid — 1, 8, 32 or 391 workgroups per pair,
+            //  measured — and a one-level registration on a coarse grid sends EVERY query here: with 8 workgroups per pair it took ten times as long)
+            hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
+            M3D_DBG(s, "k_nn_fallback");
+        }
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");
@@ -1897,8 +1951,11 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     }
     if (k1) (void)hipEventRecord(k1, s);
     unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' record counters and the work-item counter: zeroed here, behind their readers
-    if (metric == 1) hipLaunchKernelGGL(k_accumulate_matches<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1, w.wcount);
-    else hipLaunchKernelGGL(k_accumulate_matches<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + 1, w.wcount);
+#define M3D_ACC_LAUNCH(MET, WK) hipLaunchKernelGGL((k_accumulate_matches<MET, WK>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, \
+                                                   w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + (WK ? 0 : 1), w.wcount, A)
+    if (metric == 1) { if (walk_in_acc) M3D_ACC_LAUNCH(1, true); else M3D_ACC_LAUNCH(1, false); }
+    else { if (walk_in_acc) M3D_ACC_LAUNCH(0, true); else M3D_ACC_LAUNCH(0, false); }
+#undef M3D_ACC_LAUNCH
     M3D_DBG(s, "k_accumulate_matches");
 }
 

@@ -116,6 +116,8 @@ struct m3dreg_handle {
     M3dPairState* h_states = nullptr;  // pinned
     double* h_trace = nullptr;         // pinned
     size_t pending_pairs = 0;
+    int fallback_mode = 0;         // M3DREG_FALLBACK at m3dreg_create: 0 auto, 1 launch, 2 fold
+    bool fallback_hot = false;     // the last finished batch sent many queries past the tiles (more than 256 per pair and iteration): k_nn_fallback is launched again
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
@@ -669,6 +671,9 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     static const int lean_levels = [] { const char* v = getenv("M3DREG_LEAN_LEVELS"); return v ? atoi(v) : 0; }();   // 0: one-level registrations only (default), 1: also the finest level of a pyramid — measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would send every query to the fallback list
     const bool lean_here = h->params.n_levels == 1 || (lean_levels && level == h->params.n_levels - 1);
     w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
+    // M3DREG_FALLBACK: launch = k_nn_fallback behind every k_nn_iter<true> (round 2's schedule), fold = never, auto (default) = only while the handle's
+    // last finished batch left many queries to it (batch_wait). Same bits either way.
+    w.fallback_launch = (h->fallback_mode == 1 || (h->fallback_mode == 0 && h->fallback_hot)) ? 1 : 0;
     static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();   // 0: crowded levels stay inside k_nn_iter<false> (A/B)
     w.coop_kernel = (coop_kernel && level >= 0 && level < h->params.n_levels - 1) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
@@ -855,6 +860,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_LEAN")) h->lean = atoi(v) != 0;
+    if (const char* v = getenv("M3DREG_FALLBACK")) h->fallback_mode = !strcmp(v, "launch") ? 1 : (!strcmp(v, "fold") ? 2 : 0);
     if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }
     if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
@@ -1061,6 +1067,11 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
         const M3dPairState& S = h->h_states[i];
         if (out_T) for (int k = 0; k < 16; k++) out_T[16 * i + k] = float(S.T[k]);
         if (stats) stats_from_state(S, &stats[i]);
+    }
+    {
+        unsigned long long past = 0, its = 0;
+        for (size_t i = 0; i < h->pending_pairs; i++) { past += h->h_states[i].ctr[1]; its += (unsigned long long)std::max(h->h_states[i].iters, 1); }
+        h->fallback_hot = past > 256ull * its;
     }
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);

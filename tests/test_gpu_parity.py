@@ -603,12 +603,16 @@ def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
 
 
 @pytest.mark.parametrize("blob", [(30000, 0.12), (2600, 0.05)])   # more / fewer fallback queries than k_nn_fallback walks cooperatively (4096)
-@pytest.mark.parametrize("lean", ["0", "1"])
+@pytest.mark.parametrize("lean", ["0", "1", "launch"])
 def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkeypatch, lean, blob):
-    """M3DREG_LEAN=1 (default): the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; 0: the full k_nn_iter,
-    which walks what it does not bin. A crowded pair (fallback list in use) and an ordinary one in one batch, 14 iterations (tiles,
-    then fused late iterations): same poses and statistics, equal to the oracle's."""
-    monkeypatch.setenv("M3DREG_LEAN", lean)
+    """M3DREG_LEAN=1 (default): the tile iterations run k_nn_iter<true> (classify + bin only), and what it cannot bin is walked by the
+    reduction pass's workgroups (M3DREG_FALLBACK=auto on a handle that has not seen many such queries, or =fold) or by k_nn_fallback
+    (=launch, or auto after a batch with many: the SECOND batch below); 0: the full k_nn_iter, which walks what it does not bin. A crowded
+    pair (queries past the tiles) and an ordinary one in one batch, 14 iterations (tiles, then fused late iterations): same poses and
+    statistics, equal to the oracle's."""
+    monkeypatch.setenv("M3DREG_LEAN", "0" if lean == "0" else "1")
+    if lean == "launch":
+        monkeypatch.setenv("M3DREG_FALLBACK", "launch")
     def blob_cloud(seed):   # a cube so full that some 20 cm bucket holds more points than a tile image (2048): its tile is flagged
         rng = np.random.default_rng(seed)
         return np.concatenate([_crowded_cloud(seed), np.array([2.0, -1.0, 0.4]) + rng.uniform(0, blob[1], (blob[0], 3))]).astype(np.float32)
@@ -620,12 +624,15 @@ def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkey
     R = reg.Registrar(p)
     cs_c, ct_c, cs_o, ct_o = R.clouds([src_c, tgt_c, src_o, tgt_o], source_only=[True, False, True, False])
     T, st = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])
+    tile_searches, walked = R.counters()
+    assert tile_searches > 0 and walked > 0   # (the flagged tile's queries were walked: by the reduction pass, by k_nn_fallback or by the full k_nn_iter)
+    T2, st2 = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])   # (auto: the handle has now seen how many queries go past the tiles)
+    assert R.counters()[1] > 0
     for k, (s_, t_) in enumerate(((src_c, tgt_c), (src_o, tgt_o))):
         To, sto, _ = orc.align(p, orc.Cloud(p, s_, source_only=True, omp=True), orc.Cloud(p, t_, omp=True))
-        assert np.array_equal(T[k], To)
+        assert np.array_equal(T[k], To) and np.array_equal(T2[k], To)
         _same_stats(st[k], sto)
-    tile_searches, walked = R.counters()
-    assert tile_searches > 0 and walked > 0   # (the flagged tile's queries were walked: by k_nn_fallback or by the full k_nn_iter)
+        _same_stats(st2[k], sto)
 
 
 def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
