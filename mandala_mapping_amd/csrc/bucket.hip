@@ -170,6 +170,9 @@ __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { retu
 // the ping-pong key buffer that does NOT hold the sorted keys is free after the last pass: the normal grid keeps the list
 // of its voxel heads (first sorted position of every occupied voxel) there
 __device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return (B.sort_passes & 1) ? B.ka : B.kb; }
+// both VALUE ping-pong buffers are free after the last pass: a level of a point-to-plane cloud keeps its inverse permutation (sorted position by
+// input index) in the first, for its cloud's normal grid to address the level's normal array with
+__device__ __forceinline__ uint32_t* level_inverse(const M3dBuild& B) { return B.va; }
 
 // (fused = the batch's clouds are small enough — at most RS_FUSED_TILES tiles — for every scatter workgroup to scan the counters it
 // needs itself: no k_rs_scan launch, counters stored [tile][digit] so that those reads coalesce)
@@ -475,6 +478,10 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
     B.pts[j] = p;
+    if (B.nrm_sorted) {   // a level that will carry normals: k_normals (the cloud's normal grid) writes them straight into this level's order
+        if (valid) level_inverse(B)[oi] = (uint32_t)j;
+        else B.nrm_sorted[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (non-finite points, sorted last, have none)
+    }
     if (bhead && B.htab) {
         const uint32_t bk = bucket_key_of_point(B.grid, p);
         uint32_t h = m3d_hash_slot(bk, hshift);
@@ -1001,8 +1008,8 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 // Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same
 // normal — the per-point version did 10x the hash probes for identical results): add the (shifted) moments of the 27
 // voxels around it and take the smallest eigenvector of the covariance. The result is stored in the slot of the voxel's
-// first point, and the same launch hands it to the voxel's other points (nrm_in, by input index).
-__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, float plane_ratio, int min_pts, float min_spread) {
+// first point, and the same launch hands it to the voxel's other points, in every level's sorted order.
+__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
     // eight lanes per occupied voxel, one BUCKET of the 27-voxel neighbourhood each: the 3x3x3 voxels around a voxel lie in exactly 2x2x2
@@ -1142,8 +1149,9 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     }
     __syncthreads();
     // every point takes the normal of its voxel: the trip's voxels are consecutive in the head list, so their points are ONE contiguous
-    // stretch of the sorted order; a thread per position, its voxel found by bisection of the (ascending) heads in LDS. (This was a launch
-    // of its own that probed the hash table once per point to find the head.)
+    // stretch of the sorted order; a thread per position, its voxel found by bisection of the (ascending) heads in LDS; written straight
+    // into the sorted order of every level of the cloud (the builds behind this one), through the level's inverse permutation. (This was
+    // two more launches: one probing the hash table once per point to find the head, one gathering the normals into each level's order.)
     {
         const uint32_t p0 = s_head[0], p1 = s_head[n_trip];
         const uint32_t* sval = sorted_vals(B);
@@ -1154,21 +1162,16 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
                 const uint32_t mid = (lo + hi) >> 1;
                 if (hi - lo > 1u) { if (s_head[mid] <= t) lo = mid; else hi = mid; }
             }
-            B.nrm_in[sval[t]] = s_nrm[lo];
+            const uint32_t oi = sval[t];
+            const float4 nv = s_nrm[lo];
+            for (int l = 1; l < grids_per_cloud; l++) {
+                const M3dBuild& LB = builds[blockIdx.y + l];
+                if (LB.nrm_sorted) LB.nrm_sorted[level_inverse(LB)[oi]] = nv;
+            }
         }
     }
     __syncthreads();   // (the sums are overwritten by the next trip)
     }
-}
-
-// normals re-ordered into each level's sorted order: the reduction kernel gathers them by MATCH position, and
-// neighbouring queries match neighbouring sorted positions (same cache lines) but unrelated input indices
-__global__ __launch_bounds__(256) void k_gather_normals(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    if (!B.nrm_sorted) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B.n) return;
-    B.nrm_sorted[j] = j < B.grid.n_valid ? B.nrm_in[B.perm_out[j]] : make_float4(0.f, 0.f, 0.f, 0.f);   // (non-finite points, sorted last, have none)
 }
 
 // ---- export helpers (introspection API) -----------------------------------------------------------
@@ -1245,10 +1248,8 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + 63) / 64, 512), n_builds), dim3(256), 0, s, d_builds, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
+        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + 63) / 64, 512), n_builds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
-        hipLaunchKernelGGL(k_gather_normals, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
-        M3D_DBG(s, "k_gather_normals");
     }
     return hipGetLastError();
 }

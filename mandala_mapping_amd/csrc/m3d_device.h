@@ -98,7 +98,6 @@ __host__ __device__ inline int m3d_tiles_of(int n) { return (n + M3D_TILE_PTS - 
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level
     const float4* pts;
     const float4* nrm;
-    const float4* nrm_in;      // the same normals by INPUT index
     const M3dTileHdr* thdr;    // [m3d_tiles_of(n)] tile headers, or null (the level then has no tiles: every search walks global memory)
     const uint8_t* timg;       // [tiles + pool][M3D_TILE_IMG_BYTES] tile images
     const M3dTileImgMeta* timeta;   // [tiles + pool] staged points / voxels of every image

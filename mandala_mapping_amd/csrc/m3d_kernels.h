@@ -55,8 +55,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t* order;             // [ceil(n / 256)] out (levels only, else null): the 256-point blocks of the sorted cloud, most crowded first (k_table_params)
     uint32_t* dyn;               // out: the grid's M3dLevelMeta (144 B; its first 8 words are the dyn counters {occupied voxels, hmask, hshift, ...})
     long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
-    float4* nrm_in;              // [n] normals by input index: written by the normal-grid build, read by the level builds
-    float4* nrm_sorted;          // [n] out: the same normals in this level's sorted order (level builds of point-to-plane clouds, else null)
+    float4* nrm_sorted;          // [n] out: the normals in this level's sorted order, written by the cloud's normal-grid build (level builds of point-to-plane clouds, else null)
     M3dTileHdr* thdr;            // [m3d_tiles_of(n)] out: tile headers (levels of clouds that can be targets, else null)
     uint8_t* timg;               // [tiles + pool][M3D_TILE_IMG_BYTES] out: tile images (k_tile_build), tiles = m3d_tiles_of(n), pool = m3d_tile_pool(tiles)
     M3dTileImgMeta* timeta;      // [tiles + pool] out

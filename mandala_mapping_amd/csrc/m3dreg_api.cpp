@@ -79,7 +79,6 @@ struct m3dreg_cloud {
     bool source_only = false;      // m3dreg_cloud_desc.source_only: sorted, but no hash table / chunk boxes / normals — never a target
     bool has_tiles = false;        // the levels' tile images were built (k_tile_build): the LDS-staged search can use this cloud as a target
     float4* xyz = nullptr;         // coordinates in input order
-    float4* nrm_in = nullptr;      // normals by input index (shared by all levels)
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
     Block block;                   // ONE device allocation holds every array of the cloud
@@ -288,7 +287,6 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     Carver k(base);
     const size_t n = size_t(c->n);
     c->xyz = k.take<float4>(n);
-    c->nrm_in = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
     for (int l = 0; l < P.n_levels; l++) {
         DevLevel& L = c->lv[l];
         L.hcap = table_cap(n);
@@ -462,7 +460,6 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.blkw = W.blkw; B.order = is_ng ? nullptr : L.order;
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
             B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
-            B.nrm_in = c->nrm_in;
             B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
             if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
             if (!is_ng && no_normals && gidx - (want_normals ? 1 : 0) < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // nor the coarser levels of its pyramid: a registration streams a source in its FINEST level's order on every level (build_jobs)
@@ -542,9 +539,9 @@ int finish_sync(m3dreg_handle* h, m3dreg_cloud** cl, size_t k) {
     return rc;
 }
 
-M3dLevelDev level_dev(const DevLevel& L, const float4* nrm_in, bool tiles = false) {
+M3dLevelDev level_dev(const DevLevel& L, bool tiles = false) {
     M3dLevelDev d{};
-    d.pts = L.pts; d.nrm = L.nrm; d.nrm_in = nrm_in; d.htab = L.htab; d.bigcum = L.bigcum; d.cbox = L.cbox; d.dyn = L.dyn; d.g = L.grid;
+    d.pts = L.pts; d.nrm = L.nrm; d.htab = L.htab; d.bigcum = L.bigcum; d.cbox = L.cbox; d.dyn = L.dyn; d.g = L.grid;
     d.thdr = tiles ? L.thdr : nullptr; d.timg = tiles ? L.timg : nullptr; d.timeta = tiles ? L.timeta : nullptr; d.occ = tiles ? L.occ : nullptr;
     return d;
 }
@@ -717,7 +714,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
             J.src = s->lv[s->n_levels - 1].pts; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
             J.src_dyn = s->lv[s->n_levels - 1].dyn;
             J.src_order = s->lv[s->n_levels - 1].order; J.src_nblk = (s->n + 255) / 256;
-            J.tgt = level_dev(t->lv[l], t->nrm_in, t->has_tiles && h->tiles);
+            J.tgt = level_dev(t->lv[l], t->has_tiles && h->tiles);
             J.dmax = P.max_corr_dist[l];
             J.dmax2 = P.max_corr_dist[l] * P.max_corr_dist[l];
             J.min_corr = P.min_correspondences;
@@ -1819,7 +1816,7 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
     hipError_t e = hipMalloc((void**)&di, 4 * nq);
     if (e == hipSuccess) e = hipMalloc((void**)&dd, 4 * nq);
     if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = m3d_launch_debug_nn(h->stream, level_dev(target->lv[level], target->nrm_in), dq, int(nq), max_corr_dist * max_corr_dist, di, dd);
+    if (e == hipSuccess) e = m3d_launch_debug_nn(h->stream, level_dev(target->lv[level]), dq, int(nq), max_corr_dist * max_corr_dist, di, dd);
     if (e == hipSuccess) e = hipMemcpyAsync(out_idx, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_d2, dd, 4 * nq, hipMemcpyDeviceToHost, h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
@@ -1841,7 +1838,7 @@ int m3dreg_debug_candidates(m3dreg_handle* h, const m3dreg_cloud* target, int le
     HIPCHK(h, hipMalloc((void**)&dq, 12 * nq));
     hipError_t e = hipMalloc((void**)&di, 4 * nq);
     if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = m3d_launch_debug_candidates(h->stream, level_dev(target->lv[level], target->nrm_in), dq, int(nq), di);
+    if (e == hipSuccess) e = m3d_launch_debug_candidates(h->stream, level_dev(target->lv[level]), dq, int(nq), di);
     if (e == hipSuccess) e = hipMemcpyAsync(out_count, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     hipFree(dq); if (di) hipFree(di);
