@@ -1009,6 +1009,11 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 // normal — the per-point version did 10x the hash probes for identical results): add the (shifted) moments of the 27
 // voxels around it and take the smallest eigenvector of the covariance. The result is stored in the slot of the voxel's
 // first point, and the same launch hands it to the voxel's other points, in every level's sorted order.
+// voxels per workgroup and trip: 32 (one round of 8 lanes per voxel; the solving wave half full) — with 64 a 100 k-point cloud's ~2500 voxels kept 40
+// workgroups busy per cloud, each passing through its three phases (sums, solve, hand-out) alone on its CU
+#ifndef NRM_TRIP
+#define NRM_TRIP 32
+#endif
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread) {
     const M3dBuild& B = builds[blockIdx.y];
     if (!B.mom) return;
@@ -1021,11 +1026,11 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = tl >> 3, part = tl & 7;
     const uint32_t n_vox = B.dyn[5];
-    __shared__ long long s_sum[64][10];
-    __shared__ uint32_t s_head[65];   // first sorted position of the trip's voxels, and of the voxel after them
-    __shared__ float4 s_nrm[64];
-    for (uint32_t vb = blockIdx.x * 64u; vb < n_vox; vb += gridDim.x * 64u) {   // (block-uniform: barriers and shuffles inside)
-    for (int rnd = 0; rnd < 2; rnd++) {
+    __shared__ long long s_sum[NRM_TRIP][10];
+    __shared__ uint32_t s_head[NRM_TRIP + 1];   // first sorted position of the trip's voxels, and of the voxel after them
+    __shared__ float4 s_nrm[NRM_TRIP];
+    for (uint32_t vb = blockIdx.x * (uint32_t)NRM_TRIP; vb < n_vox; vb += gridDim.x * (uint32_t)NRM_TRIP) {   // (block-uniform: barriers and shuffles inside)
+    for (int rnd = 0; rnd < NRM_TRIP / 32; rnd++) {
     const int li = rnd * 32 + wv * 8 + grp;   // voxel of this trip this group sums up
     const uint32_t v = vb + (uint32_t)li;
     const bool act = v < n_vox;
@@ -1083,10 +1088,10 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
         if (act) s_head[li] = (uint32_t)j;   // (slot n_trip belongs to thread 0 below)
     }
     }
-    const uint32_t n_trip = min(64u, n_vox - vb);
-    if (threadIdx.x == 0) s_head[n_trip] = vb + 64u < n_vox ? voxel_head_list(B)[vb + 64u] : (uint32_t)B.grid.n_valid;
+    const uint32_t n_trip = min((uint32_t)NRM_TRIP, n_vox - vb);
+    if (threadIdx.x == 0) s_head[n_trip] = vb + (uint32_t)NRM_TRIP < n_vox ? voxel_head_list(B)[vb + (uint32_t)NRM_TRIP] : (uint32_t)B.grid.n_valid;
     __syncthreads();
-    if (threadIdx.x < 64 && vb + threadIdx.x < n_vox) {
+    if (threadIdx.x < NRM_TRIP && vb + threadIdx.x < n_vox) {
     const long long k = s_sum[threadIdx.x][0], s0 = s_sum[threadIdx.x][1], s1 = s_sum[threadIdx.x][2], s2 = s_sum[threadIdx.x][3], q0 = s_sum[threadIdx.x][4],
                     q1 = s_sum[threadIdx.x][5], q2 = s_sum[threadIdx.x][6], q3 = s_sum[threadIdx.x][7], q4 = s_sum[threadIdx.x][8], q5 = s_sum[threadIdx.x][9];
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1155,18 +1160,30 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     {
         const uint32_t p0 = s_head[0], p1 = s_head[n_trip];
         const uint32_t* sval = sorted_vals(B);
-        for (uint32_t t = p0 + threadIdx.x; t < p1; t += 256u) {
-            uint32_t lo = 0, hi = n_trip;   // the last voxel with head <= t
+        for (uint32_t t0 = p0 + threadIdx.x; t0 < p1; t0 += 1024u) {   // four positions per thread and trip: their (dependent) loads are in flight together
+            uint32_t oi[4], vox[4]; bool ok[4];
 #pragma unroll
-            for (int st = 0; st < 7; st++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (hi - lo > 1u) { if (s_head[mid] <= t) lo = mid; else hi = mid; }
+            for (int u = 0; u < 4; u++) { const uint32_t t = t0 + 256u * (uint32_t)u; ok[u] = t < p1; oi[u] = ok[u] ? sval[t] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + 256u * (uint32_t)u;
+                uint32_t lo = 0, hi = n_trip;   // the last voxel with head <= t
+#pragma unroll
+                for (int st = 0; st < 7; st++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (hi - lo > 1u) { if (s_head[mid] <= t) lo = mid; else hi = mid; }
+                }
+                vox[u] = lo;
             }
-            const uint32_t oi = sval[t];
-            const float4 nv = s_nrm[lo];
             for (int l = 1; l < grids_per_cloud; l++) {
                 const M3dBuild& LB = builds[blockIdx.y + l];
-                if (LB.nrm_sorted) LB.nrm_sorted[level_inverse(LB)[oi]] = nv;
+                if (!LB.nrm_sorted) continue;
+                const uint32_t* inv = level_inverse(LB);
+                uint32_t pos[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) pos[u] = ok[u] ? inv[oi[u]] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (ok[u]) LB.nrm_sorted[pos[u]] = s_nrm[vox[u]];
             }
         }
     }
@@ -1248,7 +1265,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     if (any_normals) {
         hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + 63) / 64, 512), n_builds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
+        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 1024), n_builds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
     }
     return hipGetLastError();
