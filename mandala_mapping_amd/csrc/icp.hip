@@ -211,15 +211,63 @@ __device__ __forceinline__ int m3d_nn27(const M3dLevelDev& L, float ux, float uy
     return 1;
 }
 
-__device__ __forceinline__ long long m3d_quant(float term, float scale) {
-    return (long long)(int)rintf(term * scale);
+__device__ __forceinline__ int m3d_quant(float term, float scale) {
+    return (int)rintf(term * scale);
 }
+// A thread's running sums. Every term is an int32 (m3d_quant) and a thread adds a few dozen of them at most, yet 64-bit registers for
+// each of the 29 sums were 58 of the reduction kernels' VGPRs — and those kernels are chains of dependent gathers whose speed is the
+// number of waves the register file holds (k_icp_late at 1 / 2 waves per SIMD: 65 / 42 us). M3dAcc32: 32-bit running sums of the terms
+// BIASED by 2^31 (sign bit flipped: every addend is then non-negative and a wrap is the unsigned carry), which are exact modulo 2^32, and
+// a carry count per sum in an 8-bit field (four per register: 8 more VGPRs); wide() puts them together and takes the bias out again
+// (2^31 x the number of terms, which is the count slot): the same integers, bit for bit. A field holds 255 carries: a thread adds at
+// most 128 streamed terms (m3d_acc_blocks) or 8 streamed + 64 walked ones (M3D_LATE_CAP / 32 rounds) per sum, one carry each at most.
+// (Carries are NOT rare — a floor point's n_z^2 term alone is ~2^30 — so handing them to LDS atomics made both kernels a quarter
+// slower; the signed-overflow rule instead of the bias cost ten instructions per term instead of five and gave half the gain away.)
+template <int NACC> struct M3dAcc64 {
+    long long v[NACC];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) v[i] = 0;
+    }
+    template <int SLOT> __device__ __forceinline__ void add(int t) { v[SLOT] += (long long)t; }
+    __device__ __forceinline__ long long wide(int i) const { return v[i]; }
+};
+template <int NACC> struct M3dAcc32 {
+    // v: the running sums of (term + 2^31) — every addend non-negative, so a wrap is the plain unsigned carry — modulo 2^32; cw: carries per sum,
+    // an 8-bit field each; n: terms added per sum (the count slot, the last one, is a plain counter: it adds 1 per match)
+    unsigned int v[NACC];
+    unsigned int cw[(NACC + 3) / 4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) v[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < (NACC + 3) / 4; i++) cw[i] = 0u;
+    }
+    template <int SLOT> __device__ __forceinline__ void add(int t) {
+        if (SLOT == NACC - 1) { v[SLOT] += (unsigned int)t; return; }   // the count
+        const unsigned int a = v[SLOT];
+        const unsigned int sum = a + ((unsigned int)t ^ 0x80000000u);
+        constexpr unsigned int K = 1u << (8 * (SLOT & 3));
+        cw[SLOT >> 2] += (sum < a) ? K : 0u;
+        v[SLOT] = sum;
+    }
+    __device__ __forceinline__ long long wide(int i) const {
+        if (i == NACC - 1) return (long long)v[i];
+        const long long carries = (long long)((cw[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        return (long long)v[i] + carries * (1ll << 32) - (long long)v[NACC - 1] * (1ll << 31);
+    }
+};
+#ifdef M3D_ACC64   // A/B build: 64-bit running sums per thread (rounds 1-2)
+#define M3D_ACC M3dAcc64
+#else
+#define M3D_ACC M3dAcc32
+#endif
 
 // slot of H(k,l), k <= l, in the row-major upper triangle
 __host__ __device__ constexpr int hslot21(int k, int l) { return k * 6 - (k * (k - 1)) / 2 + (l - k); }
 
-template <int NACC>
-__device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], long long* __restrict__ sums, long long* __restrict__ partial = nullptr) {
+template <int NACC, typename ACC>
+__device__ __forceinline__ void block_reduce_to_global(const ACC& acc, long long* __restrict__ sums, long long* __restrict__ partial = nullptr) {
     __shared__ long long red[ICP_WAVES][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Transposed butterfly: at every step a lane gives away half of the values it still holds and adds the
@@ -228,7 +276,7 @@ __device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], l
     // pipeline, which all its waves share: they were half of the reduction pass.
     long long v[32];
 #pragma unroll
-    for (int i = 0; i < 32; i++) v[i] = (i < NACC) ? acc[i] : 0ll;
+    for (int i = 0; i < 32; i++) v[i] = (i < NACC) ? acc.wide(i) : 0ll;
 #pragma unroll
     for (int h = 16; h >= 1; h >>= 1) {
         const bool up = (lane & (2 * h)) != 0;     // h = 16 pairs with lane ^ 32, ... h = 1 with lane ^ 2
@@ -256,8 +304,8 @@ __device__ __forceinline__ void block_reduce_to_global(long long (&acc)[NACC], l
 }
 
 // a7: contribution of one correspondence (u matched to q, normal nq) to the running sums
-template <int METRIC, int NACC>
-__device__ __forceinline__ void m3d_accumulate_match(long long (&acc)[NACC], float ux, float uy, float uz, const float4& q, float d2,
+template <int METRIC, int NACC, typename ACC>
+__device__ __forceinline__ void m3d_accumulate_match(ACC& acc, float ux, float uy, float uz, const float4& q, float d2,
                                                      const float4& nq, float cx, float cy, float cz, const float (&S)[6]) {
     const float ex = ux - q.x, ey = uy - q.y, ez = uz - q.z;
     const float wx = ux - cx, wy = uy - cy, wz = uz - cz;
@@ -268,38 +316,55 @@ __device__ __forceinline__ void m3d_accumulate_match(long long (&acc)[NACC], flo
         Jv[0] = wy * nz - wz * ny; Jv[1] = wz * nx - wx * nz; Jv[2] = wx * ny - wy * nx;
         Jv[3] = nx; Jv[4] = ny; Jv[5] = nz;
         const float r = nx * ex + ny * ey + nz * ez;
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-#pragma unroll
-            for (int l = k; l < 6; l++) {
-                const float sc = (l < 3) ? S[0] : (k < 3 ? S[1] : S[2]);
-                acc[hslot21(k, l)] += m3d_quant(Jv[k] * Jv[l], sc);
-            }
-#pragma unroll
-        for (int k = 0; k < 3; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S[3]);
-#pragma unroll
-        for (int k = 3; k < 6; k++) acc[21 + k] += m3d_quant(Jv[k] * r, S[4]);
-        acc[27] += m3d_quant(r * r, S[5]);
-        acc[28] += 1;
+        // H(k,l), k <= l, at hslot21(k, l) (row-major upper triangle; scales: rot-rot S[0], rot-trans S[1], trans-trans S[2]); then g, ssr, count
+        acc.template add<0>(m3d_quant(Jv[0] * Jv[0], S[0]));
+        acc.template add<1>(m3d_quant(Jv[0] * Jv[1], S[0]));
+        acc.template add<2>(m3d_quant(Jv[0] * Jv[2], S[0]));
+        acc.template add<3>(m3d_quant(Jv[0] * Jv[3], S[1]));
+        acc.template add<4>(m3d_quant(Jv[0] * Jv[4], S[1]));
+        acc.template add<5>(m3d_quant(Jv[0] * Jv[5], S[1]));
+        acc.template add<6>(m3d_quant(Jv[1] * Jv[1], S[0]));
+        acc.template add<7>(m3d_quant(Jv[1] * Jv[2], S[0]));
+        acc.template add<8>(m3d_quant(Jv[1] * Jv[3], S[1]));
+        acc.template add<9>(m3d_quant(Jv[1] * Jv[4], S[1]));
+        acc.template add<10>(m3d_quant(Jv[1] * Jv[5], S[1]));
+        acc.template add<11>(m3d_quant(Jv[2] * Jv[2], S[0]));
+        acc.template add<12>(m3d_quant(Jv[2] * Jv[3], S[1]));
+        acc.template add<13>(m3d_quant(Jv[2] * Jv[4], S[1]));
+        acc.template add<14>(m3d_quant(Jv[2] * Jv[5], S[1]));
+        acc.template add<15>(m3d_quant(Jv[3] * Jv[3], S[2]));
+        acc.template add<16>(m3d_quant(Jv[3] * Jv[4], S[2]));
+        acc.template add<17>(m3d_quant(Jv[3] * Jv[5], S[2]));
+        acc.template add<18>(m3d_quant(Jv[4] * Jv[4], S[2]));
+        acc.template add<19>(m3d_quant(Jv[4] * Jv[5], S[2]));
+        acc.template add<20>(m3d_quant(Jv[5] * Jv[5], S[2]));
+        acc.template add<21>(m3d_quant(Jv[0] * r, S[3]));
+        acc.template add<22>(m3d_quant(Jv[1] * r, S[3]));
+        acc.template add<23>(m3d_quant(Jv[2] * r, S[3]));
+        acc.template add<24>(m3d_quant(Jv[3] * r, S[4]));
+        acc.template add<25>(m3d_quant(Jv[4] * r, S[4]));
+        acc.template add<26>(m3d_quant(Jv[5] * r, S[4]));
+        acc.template add<27>(m3d_quant(r * r, S[5]));
+        acc.template add<28>(1);
     } else {
         // 17 running sums: Hrr(6) | sum w (3) | g(6) | ssr | count
-        acc[0] += m3d_quant(wy * wy + wz * wz, S[0]);
-        acc[1] += m3d_quant(-(wx * wy), S[0]);
-        acc[2] += m3d_quant(-(wx * wz), S[0]);
-        acc[3] += m3d_quant(wx * wx + wz * wz, S[0]);
-        acc[4] += m3d_quant(-(wy * wz), S[0]);
-        acc[5] += m3d_quant(wx * wx + wy * wy, S[0]);
-        acc[6] += m3d_quant(wx, S[1]);
-        acc[7] += m3d_quant(wy, S[1]);
-        acc[8] += m3d_quant(wz, S[1]);
-        acc[9] += m3d_quant(wy * ez - wz * ey, S[3]);
-        acc[10] += m3d_quant(wz * ex - wx * ez, S[3]);
-        acc[11] += m3d_quant(wx * ey - wy * ex, S[3]);
-        acc[12] += m3d_quant(ex, S[4]);
-        acc[13] += m3d_quant(ey, S[4]);
-        acc[14] += m3d_quant(ez, S[4]);
-        acc[15] += m3d_quant(d2, S[5]);
-        acc[16] += 1;
+        acc.template add<0>(m3d_quant(wy * wy + wz * wz, S[0]));
+        acc.template add<1>(m3d_quant(-(wx * wy), S[0]));
+        acc.template add<2>(m3d_quant(-(wx * wz), S[0]));
+        acc.template add<3>(m3d_quant(wx * wx + wz * wz, S[0]));
+        acc.template add<4>(m3d_quant(-(wy * wz), S[0]));
+        acc.template add<5>(m3d_quant(wx * wx + wy * wy, S[0]));
+        acc.template add<6>(m3d_quant(wx, S[1]));
+        acc.template add<7>(m3d_quant(wy, S[1]));
+        acc.template add<8>(m3d_quant(wz, S[1]));
+        acc.template add<9>(m3d_quant(wy * ez - wz * ey, S[3]));
+        acc.template add<10>(m3d_quant(wz * ex - wx * ez, S[3]));
+        acc.template add<11>(m3d_quant(wx * ey - wy * ex, S[3]));
+        acc.template add<12>(m3d_quant(ex, S[4]));
+        acc.template add<13>(m3d_quant(ey, S[4]));
+        acc.template add<14>(m3d_quant(ez, S[4]));
+        acc.template add<15>(m3d_quant(d2, S[5]));
+        acc.template add<16>(1);
     }
 }
 
@@ -1616,7 +1681,8 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
 // bounds the walk, the match is the same. The host picks per registration (nn_work): a handle whose last registration sent many
 // queries this way launches k_nn_fallback again — 391 workgroups per pair walk a long list faster than the 64 of this pass.
 template <int METRIC, bool WALK>
-__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
+__global__ __launch_bounds__(ICP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_matches(   // (128 VGPRs: the streaming loop needs 114; the walk ahead of it, nearly never taken, may spill)
+                                                                    const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
@@ -1646,9 +1712,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
     const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
     const int n = J.n_src;
     const int* in = (WALK ? A.match : match) + (size_t)pair * match_stride;   // (WALK writes matches: not through the __restrict__ parameter)
     const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
@@ -1698,6 +1761,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(const M3dJob
             __syncthreads();
         }
     }
+    M3D_ACC<NACC> acc;
+    acc.clear();
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB];
 #pragma unroll
@@ -1766,9 +1831,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     const float cx = g.center[0], cy = g.center[1], cz = g.center[2];
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
-    long long acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    M3D_ACC<NACC> acc;
+    acc.clear();
     __shared__ int s_cnt;
     __shared__ int s_list[M3D_LATE_CAP];         // query index | seeded << 31
     __shared__ float s_wu[3][M3D_LATE_CAP];      // its transformed position
@@ -1882,9 +1946,12 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 int m3d_acc_blocks(int max_n_src, int n_pairs) {
     static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
     static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
-    if (fixed > 0) return fixed;
+    // (a thread's 32-bit running sums count their wraps in 8-bit fields: at most 128 queries per thread, whatever the overrides ask for)
+    const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
+    if (fixed > 0) return fixed > b_min ? fixed : b_min;
     int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
     if (b < 1) b = 1;
+    if (b < b_min) b = b_min;
     if (n_pairs > 0 && (b * n_pairs) % 256 != 0) {
         const int up = ((b * n_pairs + 255) / 256) * 256;   // the next whole round of the 256 CUs
         if (up % n_pairs == 0) {
