@@ -10,13 +10,14 @@ then the pose read-back; with N > 1 the poses of all ranks are gathered over RCC
 collective; pairs never exchange data).
 
 Prints ONE JSON line (rank 0). `roofline` prices the correspondence step of an iteration (k_nn_iter: source transform,
-NN-certificate check, binning [+ k_nn_fallback: the rare query that cannot be binned]; k_nn_tiles: the binned searches from LDS-staged target tiles) by its algorithmic
+NN-certificate check, binning [the rare query that cannot be binned is walked by the reduction pass, or by k_nn_fallback on handles that saw many]; k_nn_tiles: the binned searches from LDS-staged target tiles) by its algorithmic
 bytes (NN part: 12 N + 12 M + 8 C_occ per pair) over its average duration, taken from hipEvents the library
-records on its stream around that step (m3dreg_profile_read): `frac` from one extra, untimed step with nothing else on the GPU
-(what a rocprofv3 kernel trace of serial steps shows), `frac_in_region` from inside the timed region, where three chains share
+records on its stream around that step (m3dreg_profile_read): `frac` from inside the timed region, where four chains share
 the GPU (every seventh iteration is bracketed: an event record is a barrier packet, bracketing all of them cost 4 % of the
-throughput being measured). From the 10th iteration of a level on the library runs search and reduction as ONE launch (k_icp_late)
-wherever nobody asked for a bracket around the correspondence step; a bracketed iteration runs as the two-launch chain (same bits),
+throughput being measured), `alone` from one extra, untimed step with nothing else on the GPU (what a rocprofv3 kernel trace of
+serial steps shows), `iteration` = a whole linearisation of the shipped schedule. From the 8th iteration of a level on the library
+runs search and reduction as ONE launch (k_icp_late) wherever nobody asked for a bracket around the correspondence step; a
+bracketed iteration runs as the two-launch chain (same bits),
 so `roofline` always prices k_nn_iter (+ k_nn_tiles) — the fused launches show up in the step time, not in the bracket.
 `cpu_baseline`: the port of the voxel algorithm (oracle/m3d_oracle.c) and a from-scratch k-d tree
 ICP (oracle/m3d_kdtree_icp.c), each -O3 -march=native at 1 thread and at all cores, warm-up + median, on a bounded sample of
@@ -476,7 +477,7 @@ def main():
             # ONE definition, kept from round to round: frac = the correspondence step INSIDE the timed region (what the timed region ran, several
             # chains sharing the GPU, sampled brackets); `alone` = the same bracket with nothing else on the GPU; `iteration` = a whole linearisation
             # of the shipped schedule (fused late launches included) on its algorithmic bytes
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter (+ k_nn_fallback) + k_nn_tiles: the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (+ k_nn_fallback where the handle launches it): the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
                                                     "runs as the launch chain; un-bracketed iterations >= 10 of a level run fused with the reduction as k_icp_late: see `iteration`)",
                          "achieved": in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": in_region / HBM_PEAK_GBS,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches, "concurrent_chains": D,
