@@ -1803,6 +1803,13 @@ __global__ __launch_bounds__(ICP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // sums: any order, same bits. The last workgroup of the pair solves, as in k_accumulate_matches.
 // (Round 1 tried this shape against a per-lane walk and a 27 + 6 + 22 us chain and dropped it; with the cooperative walk sharing its
 // crowded rows and the chain at 21 + 18 us of bandwidth-bound launches it pays.)
+#ifdef M3D_LATE_STAMPS   // diagnosis build: wall-clock stamps (100 MHz) at k_icp_late's phase boundaries, every workgroup of the LAST launch (scripts/late_stamps.py)
+__device__ unsigned long long g_late_stamp[4096][8];
+extern "C" hipError_t m3d_debug_read_late(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_late_stamp), sizeof(unsigned long long) * 4096 * 8); }
+#define LATE_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096u) g_late_stamp[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define LATE_STAMP(k) ((void)0)
+#endif
 template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, M3dNnArgs A, long long* __restrict__ partials,
                                                           unsigned int* __restrict__ tickets, unsigned int seq, unsigned long long* __restrict__ progress) {
@@ -1814,6 +1821,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
         if (blk == 0 && threadIdx.x == 0) m3d_report_progress(jobs, n_pairs, false, seq, progress);
         return;
     }
+    LATE_STAMP(0);
     float R[9], tt[3];
     m3d_load_pose(st, R, tt);
     __shared__ double s_T[16];
@@ -1839,7 +1847,11 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     __shared__ float s_wd[M3D_LATE_CAP];         // squared distance to its seed
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    constexpr int NB = 2;
+    LATE_STAMP(1);
+#ifndef M3D_LATE_NB
+#define M3D_LATE_NB 2   // queries per thread and trip (A/B builds)
+#endif
+    constexpr int NB = M3D_LATE_NB;
     const int stride = bpp * ICP_THREADS;
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB]; m3d_f32x4 s0[NB];
@@ -1873,6 +1885,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
             }
         }
     }
+    LATE_STAMP(2);
     __syncthreads();
     const int nW = min(s_cnt, M3D_LATE_CAP);   // (the cap cannot be exceeded: see launch_iteration)
     const int sub = (int)threadIdx.x & 7;
@@ -1897,9 +1910,15 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
             }
         }
     }
+    LATE_STAMP(3);
     if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;
     block_reduce_to_global<NACC>(acc, st->sums, partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE);
+    LATE_STAMP(4);
+#ifdef M3D_LATE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096u) g_late_stamp[blockIdx.x][6] = (unsigned long long)nW;
+#endif
     m3d_pair_tail(jobs, J, st, n_pairs, pair, blk, bpp, 0, partials, tickets, seq, progress, s_T);
+    LATE_STAMP(5);
 }
 
 // ---- introspection: NN of arbitrary queries --------------------------------------------------------
