@@ -1959,19 +1959,32 @@ hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, cons
 // ---- launchers ---------------------------------------------------------------------------------------
 // blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
 __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }
-// workgroups per pair of the reduction pass: ~8 queries per thread, so the 29-term block reduction is amortised — and, when the
-// batch allows it, a whole number of workgroups per CU: 8 pairs x 49 workgroups put two on 136 CUs and one on 120, the launch then
-// takes what two take; 8 x 64 = two on every CU, each a quarter shorter (19.5 -> 18.0 us per launch, serial steps +4 %)
-int m3d_acc_blocks(int max_n_src, int n_pairs) {
+// Workgroups per pair of the reduction pass (k_accumulate_matches, k_icp_late). Its streaming loop's time is trips x loaded latency, so what matters is
+// how many threads share the batch's queries: enough workgroups to put 2 on every CU (512: 8 pairs x 64 — 49, from "8 queries per thread", put two on
+// 136 CUs and one on 120 and the launch took what two take), 3 when the batch has the GPU to itself (`alone`: no other batch of this process in flight on
+// the device — 768 = 8 x 96: serial steps +2 %; with other chains in flight the third workgroup's registers are worth more to them: headline -3.7 %) —
+// whatever the number of pairs: ONE 100 k-point pair used to get 49 workgroups for 256 CUs, with 256 a registration takes 0.86 instead of 1.01 ms.
+// Bounds: at most 8 queries per thread (k_icp_late's worklist, and the amortisation of the 29-term block reduction has little left to give beyond),
+// at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
+int m3d_acc_blocks(int max_n_src, int n_pairs, bool alone) {
     static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
     static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
-    // (a thread's 32-bit running sums count their wraps in 8-bit fields: at most 128 queries per thread, whatever the overrides ask for)
+    static const int fill = [] { const char* v = getenv("M3DREG_ACC_FILL"); return v ? atoi(v) : 1; }();   // 0: round 2's rule (A/B)
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
     if (fixed > 0) return fixed > b_min ? fixed : b_min;
     int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
     if (b < 1) b = 1;
     if (b < b_min) b = b_min;
-    if (n_pairs > 0 && (b * n_pairs) % 256 != 0) {
+    if (n_pairs <= 0) return b;
+    if (fill) {
+        const int target = alone ? 768 : 512;
+        int hi = max_n_src / 384; if (hi < b) hi = b;
+        int t = (target + n_pairs - 1) / n_pairs;
+        if (t > hi) t = hi;
+        if (t > b) b = t;
+        return b;
+    }
+    if ((b * n_pairs) % 256 != 0) {
         const int up = ((b * n_pairs + 255) / 256) * 256;   // the next whole round of the 256 CUs
         if (up % n_pairs == 0) {
             const int bu = up / n_pairs;
@@ -1980,8 +1993,8 @@ int m3d_acc_blocks(int max_n_src, int n_pairs) {
     }
     return b;
 }
-int m3d_ticket_words(int n_pairs, int max_n_src) {
-    const int bpp = m3d_acc_blocks(max_n_src, n_pairs), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
+int m3d_ticket_words(int n_pairs, int max_n_src) {   // (sized for the larger of the two grids)
+    const int bpp = m3d_acc_blocks(max_n_src, n_pairs, true), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
     return n_pairs * (ng + 1) * 32;
 }
 
@@ -2000,7 +2013,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     const int late = first_of_level < 0;
     const bool fused_ok = first_of_level == -2;   // -2: a late iteration that may run as one launch
     if (late) first_of_level = 0;
-    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs);
+    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs, w.acc_alone != 0);
     // A late iteration nobody brackets runs as ONE launch (k_icp_late). With an event bracket around the correspondence step (bench.py
     // samples some iterations; its untimed roofline step brackets all of them) the same iteration runs as the two-launch chain — same
     // bits — because the bracket's two halves do not exist inside a fused launch.

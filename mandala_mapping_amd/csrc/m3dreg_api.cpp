@@ -116,6 +116,7 @@ struct m3dreg_handle {
     double* h_trace = nullptr;         // pinned
     size_t pending_pairs = 0;
     int fallback_mode = 0;         // M3DREG_FALLBACK at m3dreg_create: 0 auto, 1 launch, 2 fold
+    bool batch_alone = true;       // the batch being enqueued found no other batch of this process in flight on the device (g_batches_in_flight)
     bool fallback_hot = false;     // the last finished batch sent many queries past the tiles (more than 256 per pair and iteration): k_nn_fallback is launched again
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
@@ -598,7 +599,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | (unused) | cache (int64) | certificate state (float4)
         h->match_cap = cap;
     }
-    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs))) * M3D_PARTIAL_STRIDE;
+    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs), true)) * M3D_PARTIAL_STRIDE;
     if (n_part > h->partials_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_partials) hipFree(h->d_partials);
@@ -654,6 +655,11 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     return M3DREG_OK;
 }
 
+// batches enqueued and not yet waited for, per device, over all handles of the process: a batch that finds none has the GPU to itself as far as this
+// library can tell, and its reduction pass takes the larger grid (m3d_acc_blocks). A wrong guess costs a few per cent, never a bit.
+static std::atomic<int> g_batches_in_flight[64];
+static std::atomic<int>& batches_in_flight(const m3dreg_handle* h) { return g_batches_in_flight[(h->device >= 0 && h->device < 64) ? h->device : 0]; }
+
 M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     M3dNnWork w{};
     w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
@@ -671,6 +677,7 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // M3DREG_FALLBACK: launch = k_nn_fallback behind every k_nn_iter<true> (round 2's schedule), fold = never, auto (default) = only while the handle's
     // last finished batch left many queries to it (batch_wait). Same bits either way.
     w.fallback_launch = (h->fallback_mode == 1 || (h->fallback_mode == 0 && h->fallback_hot)) ? 1 : 0;
+    w.acc_alone = h->batch_alone ? 1 : 0;
     static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();   // 0: crowded levels stay inside k_nn_iter<false> (A/B)
     w.coop_kernel = (coop_kernel && level >= 0 && level < h->params.n_levels - 1) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
@@ -1004,6 +1011,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     int max_n_src = 0, max_n_tgt = 0;
     if ((rc = build_jobs(h, pairs, n_pairs, max_n_src, max_n_tgt))) return rc;
     const m3dreg_params& P = h->params;
+    h->batch_alone = batches_in_flight(h).load(std::memory_order_relaxed) == 0;
     if ((rc = ensure_match(h, n_pairs, max_n_src, max_n_tgt))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
@@ -1051,6 +1059,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
+    batches_in_flight(h).fetch_add(1, std::memory_order_relaxed);
     return M3DREG_OK;
     });
 }
@@ -1073,6 +1082,7 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
     h->pending_pairs = 0;
+    batches_in_flight(h).fetch_sub(1, std::memory_order_relaxed);
     return M3DREG_OK;
     });
 }
@@ -2041,7 +2051,7 @@ void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<
     // leave the handle idle and give everything back, whatever happened above (a throw in the middle left earlier devices
     // with a pending batch, leaked the shard's clouds and returned while copies could still read the caller's payloads)
     if (touched) {
-        if (h->pending_pairs) { hipStreamSynchronize(h->stream); if (h->ev_used) drain_events(h); h->pending_pairs = 0; }
+        if (h->pending_pairs) { hipStreamSynchronize(h->stream); if (h->ev_used) drain_events(h); h->pending_pairs = 0; batches_in_flight(h).fetch_sub(1, std::memory_order_relaxed); }
         else hipStreamSynchronize(h->stream);
     }
     for (m3dreg_cloud* c : clouds) if (c) free_cloud(h, c);
