@@ -520,8 +520,9 @@ def extra_legs(args):
         "from_host": ["--steps", "40", "--warmup", "3", "--from-host"],
         "converge": ["--steps", "40", "--warmup", "3", "--converge"],
         "from_host_converge": ["--steps", "40", "--warmup", "3", "--from-host", "--converge"],   # SURVEY 8d's literal "registrations/s": H2D of both clouds + bucketing + iterations to eps 1e-5 (at most --iters) + D2H
-        "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1", "--event-every", "1"],
-        "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1", "--event-every", "1"],
+        # (the default bracket, every 7th iteration: with every iteration bracketed none of them runs fused, and these two legs are LATENCIES of the shipped schedule)
+        "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
+        "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config5": ["--workload", "config5", "--steps", "10", "--warmup", "2"],
     }
     legs = {}

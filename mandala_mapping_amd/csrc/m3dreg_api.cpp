@@ -116,6 +116,8 @@ struct m3dreg_handle {
     double* h_trace = nullptr;         // pinned
     size_t pending_pairs = 0;
     int fallback_mode = 0;         // M3DREG_FALLBACK at m3dreg_create: 0 auto, 1 launch, 2 fold
+    bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
+    uint32_t coop_seen = 0;
     bool batch_alone = true;       // the batch being enqueued found no other batch of this process in flight on the device (g_batches_in_flight)
     bool fallback_hot = false;     // the last finished batch sent many queries past the tiles (more than 256 per pair and iteration): k_nn_fallback is launched again
     size_t last_trace_n = 0;
@@ -678,8 +680,13 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // last finished batch left many queries to it (batch_wait). Same bits either way.
     w.fallback_launch = (h->fallback_mode == 1 || (h->fallback_mode == 0 && h->fallback_hot)) ? 1 : 0;
     w.acc_alone = h->batch_alone ? 1 : 0;
-    static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();   // 0: crowded levels stay inside k_nn_iter<false> (A/B)
-    w.coop_kernel = (coop_kernel && level >= 0 && level < h->params.n_levels - 1) ? 1 : 0;
+    // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels: 1 (default) = where the handle's last finished batch had a crowded target level (and on
+    // a handle's first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level —, 0 = never
+    // (crowded levels stay inside k_nn_iter<false>, eight passes per workgroup), 2 = always. A wrong guess costs time, never a bit: without the launch
+    // k_nn_iter<false> answers the crowded pairs itself.
+    static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();
+    const bool coop_level = level >= 0 && level < h->params.n_levels - 1;
+    w.coop_kernel = (coop_level && (coop_kernel == 2 || (coop_kernel == 1 && (!h->coop_known || ((h->coop_seen >> level) & 1u))))) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
@@ -1078,6 +1085,9 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
         unsigned long long past = 0, its = 0;
         for (size_t i = 0; i < h->pending_pairs; i++) { past += h->h_states[i].ctr[1]; its += (unsigned long long)std::max(h->h_states[i].iters, 1); }
         h->fallback_hot = past > 256ull * its;
+        uint32_t seen = 0;
+        for (size_t i = 0; i < h->pending_pairs; i++) seen |= h->h_states[i].coop_levels;
+        h->coop_seen = seen; h->coop_known = true;
     }
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
