@@ -413,7 +413,7 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 #define M3D_NN_NONE_CACHED (-2)
 #define M3D_NN_PENDING (-3)   // a query k_nn_iter<lean> could not hand to a tile: walked by k_nn_fallback, or (no such launch) by the reduction pass's workgroup that owns it
 #define M3D_LATE_CAP 2048   // LDS worklist entries of k_icp_late / k_accumulate_matches<.., true>: a workgroup owns at most 8 x 256 queries (launch_iteration checks)
-#define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread)
+#define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread) when the batch has enough of them to fill the GPU; else 256 (M3dNnArgs::tile_chunk: 2 lanes per record; M3DREG_TILE_CHUNK forces 512 / 256 / 128)
 #define M3D_TILE_CHUNK_CROWDED 64     // ... of a tile with crowded voxels (one per eighth lane)
 #define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
 __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
@@ -796,6 +796,7 @@ struct M3dNnArgs {
     // (k_nn_iter), k_nn_tiles then answers every tile's queries from LDS
     int tiles;                         // 1 = on
     int ntile_max;                     // tiles per pair the workspace is laid out for (>= tiles of every target of the batch)
+    int tile_chunk;                    // records per work item of a tile without crowded voxels: 512, or 256 when the batch is small (launch_iteration)
     float4* rec;                       // per pair [ntile_max][M3D_TILE_QCAP] + [match_stride]: query records {u.xyz, bits(query | seeded << 31)} of the
                                        //   tiles, then the records that take the global walk (home bucket empty, tile flagged, slab full)
     float* recd;                       // same layout: squared distance to the seed (the previous match)
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 // all — k_nn_tiles testing every (tile, chunk) against the counters itself — made k_nn_iter as fast and k_nn_tiles
                 // 12-25 us slower: whatever clumps the items of a crowded tile, or hands a workgroup 3 items and its neighbour none,
                 // shows up as the tail of that kernel.)
-                const uint32_t cs = (hmeta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)M3D_TILE_CHUNK;
+                const uint32_t cs = (hmeta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)A.tile_chunk;
                 const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
                 for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
                     const uint32_t wl = ((uint32_t)t0 + c + (uint32_t)pair) & (uint32_t)(M3D_TILE_LISTS - 1);   // (per item, not per workgroup: a crowded tile's chunks spread over all lists)
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const M3dTileHdr H = J.tgt.thdr[blk];
         const unsigned int qn = min((A.tcnt + (size_t)pair * A.cnt_stride)[blk], (unsigned int)M3D_TILE_QCAP);
         const bool sparse = (H.meta0 >> 31) != 0u;   // a tile with crowded voxels: 64 records per item, eight lanes per record (m3d_tile_search)
-        const unsigned int cs = sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)M3D_TILE_CHUNK;
+        const unsigned int cs = sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)A.tile_chunk;
         const unsigned int lstride = M3D_TILE_THREADS / cs;
         M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
         M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
@@ -2005,7 +2006,12 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
     M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
-    A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max; A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
+    A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max;
+    {   // a work item of k_nn_tiles is one workgroup's pass over <= tile_chunk records: ONE 100 k-point pair makes 196 items of 512 for 256 CUs that hold three workgroups each
+        static const int forced = [] { const char* v = getenv("M3DREG_TILE_CHUNK"); const int c = v ? atoi(v) : 0; return (c == 512 || c == 256 || c == 128) ? c : 0; }();
+        const long long items = (long long)n_pairs * ((max_n_src + M3D_TILE_CHUNK - 1) / M3D_TILE_CHUNK);
+        A.tile_chunk = forced ? forced : (items >= 768 ? M3D_TILE_CHUNK : M3D_TILE_CHUNK / 2);   // (config 3: 0.867 / 0.843 / 0.855 ms per registration with 512 / 256 / 128)
+    } A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
     A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
     // first_of_level: 1 = first iteration of a level, 0 = a later one, -1 / -2 = a late one: the searches that are left (a few per cent
