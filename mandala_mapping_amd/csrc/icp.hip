@@ -1640,7 +1640,7 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
 // bounds the walk, the match is the same. The host picks per registration (nn_work): a handle whose last registration sent many
 // queries this way launches k_nn_fallback again — 391 workgroups per pair walk a long list faster than the 64 of this pass.
 template <int METRIC, bool WALK>
-__global__ __launch_bounds__(ICP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_matches(   // (128 VGPRs: the streaming loop needs 114; the walk ahead of it, nearly never taken, may spill)
+__global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK: 133 VGPRs = 3 waves per SIMD, the walk's; forced to 128 = 4 waves with 5 spilled registers: headline and serial steps -0.5 %)
                                                                     const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
                                                                     const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
