@@ -1665,8 +1665,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
     // the pose in double for the solve at the end of the launch: requested now, parked in LDS after the streaming loop (the last
     // block's solving thread otherwise starts with a 1 us round trip)
     __shared__ double s_T[16];
-    double t_pre = 0.0;
-    if (threadIdx.x < 16) t_pre = st->T[threadIdx.x];
     const M3dLevelDev& L = J.tgt;
     const float cx = L.g.center[0], cy = L.g.center[1], cz = L.g.center[2];
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
@@ -1720,6 +1718,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
             __syncthreads();
         }
     }
+    double t_pre = 0.0;   // (requested here, behind the walk: two registers it does not have to carry)
+    if (threadIdx.x < 16) t_pre = st->T[threadIdx.x];
     M3D_ACC<NACC> acc;
     acc.clear();
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
