@@ -224,8 +224,10 @@ __device__ __forceinline__ int m3d_quant(float term, float scale) {
 // slot of H(k,l), k <= l, in the row-major upper triangle
 __host__ __device__ constexpr int hslot21(int k, int l) { return k * 6 - (k * (k - 1)) / 2 + (l - k); }
 
+// (to_lds: the block's sums go to that LDS array and nowhere else — k_icp_late<.., SMALL> parks its streaming loop's there while it walks; add_lds: sums parked that way are added)
 template <int NACC, typename ACC>
-__device__ __forceinline__ void block_reduce_to_global(const ACC& acc, long long* __restrict__ sums, long long* __restrict__ partial = nullptr) {
+__device__ __forceinline__ void block_reduce_to_global(const ACC& acc, long long* __restrict__ sums, long long* __restrict__ partial = nullptr,
+                                                       long long* to_lds = nullptr, const long long* add_lds = nullptr) {
     __shared__ long long red[ICP_WAVES][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Transposed butterfly: at every step a lane gives away half of the values it still holds and adds the
@@ -253,6 +255,8 @@ __device__ __forceinline__ void block_reduce_to_global(const ACC& acc, long long
         long long v = 0;
 #pragma unroll
         for (int w = 0; w < ICP_WAVES; w++) v += red[w][threadIdx.x];
+        if (add_lds) v += add_lds[threadIdx.x];
+        if (to_lds) { to_lds[threadIdx.x] = v; return; }
         // `partial`: this block's own slot, summed by the solve kernel (integer sums: any order gives the same bits).
         // Atomics on the pair's 29 shared words serialise at ~50-100 ns each; with ~50 blocks per pair they were
         // a quarter of the reduction pass.
@@ -370,7 +374,8 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 // "-2" is answered again without a single probe. Exact: a changed voxel simply re-runs the full search.
 #define M3D_NN_NONE_CACHED (-2)
 #define M3D_NN_PENDING (-3)   // a query k_nn_iter<lean> could not hand to a tile: walked by k_nn_fallback, or (no such launch) by the reduction pass's workgroup that owns it
-#define M3D_LATE_CAP 2048   // LDS worklist entries of k_icp_late / k_accumulate_matches<.., true>: a workgroup owns at most 8 x 256 queries (launch_iteration checks)
+#define M3D_LATE_QPT 7      // queries per thread at most in k_icp_late / k_accumulate_matches<.., true> (launch_iteration checks; m3d_acc_blocks sizes the grid for it)
+#define M3D_LATE_CAP (M3D_LATE_QPT * 256)   // their worklist: every query a workgroup owns, if it must (k_icp_late: 7 x 256 x 20 B + the reductions' arrays = 39 KB of LDS)
 #define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread) when the batch has enough of them to fill the GPU; else 256 (M3dNnArgs::tile_chunk: 2 lanes per record; M3DREG_TILE_CHUNK forces 512 / 256 / 128)
 #define M3D_TILE_CHUNK_CROWDED 64     // ... of a tile with crowded voxels (one per eighth lane)
 #define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
@@ -1682,7 +1687,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
         pend_n = A.tcnt + (size_t)pair * A.cnt_stride + A.ntile_max;
         if (*pend_n != 0u) {   // (uniform; nearly never taken — and BEFORE the streaming loop: the 29 sums are not live yet, the walk's registers are the loop's)
             __shared__ int s_pn;
-            __shared__ int s_pend[M3D_LATE_CAP];   // pending queries of this workgroup (it owns at most 8 x 256: launch_iteration checks)
+            __shared__ int s_pend[M3D_LATE_CAP];   // pending queries of this workgroup (it owns at most M3D_LATE_QPT x 256: launch_iteration checks)
             if (threadIdx.x == 0) s_pn = 0;
             __syncthreads();
             for (int i = blk * ICP_THREADS + (int)threadIdx.x; i < n; i += stride)
@@ -1769,7 +1774,15 @@ extern "C" hipError_t m3d_debug_read_late(unsigned long long* out) { return hipM
 #else
 #define LATE_STAMP(k) ((void)0)
 #endif
-template <int METRIC>
+// SMALL (the launch is NOT alone on the device: other batches of the process are in flight): the footprint a workgroup takes from its CU matters more than
+// its own speed. The LDS worklist holds M3D_LATE_CAPS = 512 entries instead of every query the workgroup owns (14 instead of 39 KB: room for k_nn_tiles'
+// 49 KB workgroups of the other chains beside it; a steady-state launch has one or two entries per workgroup, the first fused one ~60, at most 164 on the
+// bench batch) — what does not fit goes to the workgroup's stretch of the tile records' array in global memory, which no late iteration uses —, and the
+// streaming loop's sums are reduced to LDS BEFORE the walk, the walked queries' residuals added in a pass of their own and reduced again (the walk with the
+// running sums live was the kernel's register peak: 157 VGPRs; this way 130). Headline +0.5 ... 0.9 % same-box; forced to 128 VGPRs (a fourth wave per SIMD)
+// it spills 16 bytes per lane and loses 0.7 % instead: scratch is what costs. Alone, the extra reduction costs a serial step 1 %: the other variant.
+#define M3D_LATE_CAPS 512
+template <int METRIC, bool SMALL>
 __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, M3dNnArgs A, long long* __restrict__ partials,
                                                           unsigned int* __restrict__ tickets, unsigned int seq, unsigned long long* __restrict__ progress) {
     int pair, blk;
@@ -1801,9 +1814,13 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     M3D_ACC<NACC> acc;
     acc.clear();
     __shared__ int s_cnt;
-    __shared__ int s_list[M3D_LATE_CAP];         // query index | seeded << 31
-    __shared__ float s_wu[3][M3D_LATE_CAP];      // its transformed position
-    __shared__ float s_wd[M3D_LATE_CAP];         // squared distance to its seed
+    constexpr int CAPS = SMALL ? M3D_LATE_CAPS : M3D_LATE_CAP;
+    __shared__ int s_list[CAPS];                 // query index | seeded << 31
+    __shared__ float s_wu[3][CAPS];              // its transformed position
+    __shared__ float s_wd[CAPS];                 // squared distance to its seed; SMALL: afterwards the match found (bits)
+    // SMALL: entries CAPS ... M3D_LATE_CAP - 1, same layout ({u, bits(query | seeded)}, seed distance / match), in this workgroup's stretch of the record arrays
+    float4* ov = SMALL ? A.rec + (size_t)pair * A.rec_stride + (size_t)blk * (M3D_LATE_CAP - M3D_LATE_CAPS) : nullptr;
+    float* ovd = SMALL ? A.recd + (size_t)pair * A.rec_stride + (size_t)blk * (M3D_LATE_CAP - M3D_LATE_CAPS) : nullptr;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     LATE_STAMP(1);
@@ -1840,38 +1857,84 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
             if (certified) m3d_accumulate_match<METRIC, NACC>(acc, ux, uy, uz, q[k], dseed, nq[k], cx, cy, cz, S);   // (dseed: the same fma chain as the reduction pass's d2)
             else if (cls != 0) {
                 const int w = atomicAdd(&s_cnt, 1);
-                if (w < M3D_LATE_CAP) { s_list[w] = i | (cls == 1 ? (int)0x80000000u : 0); s_wu[0][w] = ux; s_wu[1][w] = uy; s_wu[2][w] = uz; s_wd[w] = dseed; }
+                const int e = i | (cls == 1 ? (int)0x80000000u : 0);
+                if (w < CAPS) { s_list[w] = e; s_wu[0][w] = ux; s_wu[1][w] = uy; s_wu[2][w] = uz; s_wd[w] = dseed; }
+                else if (SMALL && w < M3D_LATE_CAP) { ov[w - CAPS] = make_float4(ux, uy, uz, __int_as_float(e)); ovd[w - CAPS] = dseed; }
             }
         }
     }
     LATE_STAMP(2);
     __syncthreads();
     const int nW = min(s_cnt, M3D_LATE_CAP);   // (the cap cannot be exceeded: see launch_iteration)
-    const int sub = (int)threadIdx.x & 7;
-    for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
-        const int w = base + ((int)threadIdx.x >> 3);
-        const bool act = w < nW;
-        const int e = act ? s_list[w] : 0;
-        const int qi = e & 0x7FFFFFFF;
-        const float vx = act ? s_wu[0][w] : 0.f, vy = act ? s_wu[1][w] : 0.f, vz = act ? s_wu[2][w] : 0.f;
-        long long code; float sec;
-        const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, e < 0, vx, vy, vz, act ? s_wd[w] : 0.f, sub, code, sec, 0);
-        if (act && sub == 0) {
-            out[qi] = mq;
-            if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
-            if (mq >= 0) {
-                state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
-                const float4 qm = m3d_ld(pts, (size_t)mq);
-                const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
-                const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-                m3d_accumulate_match<METRIC, NACC>(acc, vx, vy, vz, qm, d2, nm, cx, cy, cz, S);
+    if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;
+    long long* my_partial = partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE;
+    if constexpr (!SMALL) {
+        const int sub = (int)threadIdx.x & 7;
+        for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
+            const int w = base + ((int)threadIdx.x >> 3);
+            const bool act = w < nW;
+            const int e = act ? s_list[w] : 0;
+            const int qi = e & 0x7FFFFFFF;
+            const float vx = act ? s_wu[0][w] : 0.f, vy = act ? s_wu[1][w] : 0.f, vz = act ? s_wu[2][w] : 0.f;
+            long long code; float sec;
+            const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, e < 0, vx, vy, vz, act ? s_wd[w] : 0.f, sub, code, sec, 0);
+            if (act && sub == 0) {
+                out[qi] = mq;
+                if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
+                if (mq >= 0) {
+                    state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
+                    const float4 qm = m3d_ld(pts, (size_t)mq);
+                    const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
+                    const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    m3d_accumulate_match<METRIC, NACC>(acc, vx, vy, vz, qm, d2, nm, cx, cy, cz, S);
+                }
             }
         }
+        LATE_STAMP(3);
+        block_reduce_to_global<NACC>(acc, st->sums, my_partial);
+    } else {   // (also when the worklist is empty — it rarely is —: a branch around this block, with a reduction of its own, cost 83 VGPRs, 211 instead of 128)
+        __shared__ long long s_first[32];
+        block_reduce_to_global<NACC>(acc, nullptr, nullptr, s_first);
+        __threadfence_block();   // (overflow entries: written to global memory by this workgroup, read by it below)
+        __syncthreads();
+        const int sub = (int)threadIdx.x & 7;
+        for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
+            const int w = base + ((int)threadIdx.x >> 3);
+            const bool act = w < nW;
+            int e = 0; float vx = 0.f, vy = 0.f, vz = 0.f, ds = 0.f;
+            if (act) {
+                if (w < CAPS) { e = s_list[w]; vx = s_wu[0][w]; vy = s_wu[1][w]; vz = s_wu[2][w]; ds = s_wd[w]; }
+                else { const float4 o = ov[w - CAPS]; e = __float_as_int(o.w); vx = o.x; vy = o.y; vz = o.z; ds = ovd[w - CAPS]; }
+            }
+            const int qi = e & 0x7FFFFFFF;
+            long long code; float sec;
+            const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, e < 0, vx, vy, vz, ds, sub, code, sec, 0);
+            if (act && sub == 0) {
+                out[qi] = mq;
+                if (w < CAPS) s_wd[w] = __int_as_float(mq); else ovd[w - CAPS] = __int_as_float(mq);   // (the seed distance has been used: the slot carries the result to the pass below)
+                if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
+                if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        M3D_ACC<NACC> acc2;
+        acc2.clear();
+        for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
+            int mq; float vx, vy, vz;
+            if (w < CAPS) { mq = __float_as_int(s_wd[w]); vx = s_wu[0][w]; vy = s_wu[1][w]; vz = s_wu[2][w]; }
+            else { const float4 o = ov[w - CAPS]; mq = __float_as_int(ovd[w - CAPS]); vx = o.x; vy = o.y; vz = o.z; }
+            if (mq < 0) continue;
+            const float4 qm = m3d_ld(pts, (size_t)mq);
+            const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            m3d_accumulate_match<METRIC, NACC>(acc2, vx, vy, vz, qm, d2, nm, cx, cy, cz, S);
+        }
+        LATE_STAMP(3);
+        block_reduce_to_global<NACC>(acc2, st->sums, my_partial, nullptr, s_first);
     }
-    LATE_STAMP(3);
-    if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;
-    block_reduce_to_global<NACC>(acc, st->sums, partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE);
     LATE_STAMP(4);
 #ifdef M3D_LATE_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 4096u) g_late_stamp[blockIdx.x][6] = (unsigned long long)nW;
@@ -1923,10 +1986,10 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 // 136 CUs and one on 120 and the launch took what two take), 3 when the batch has the GPU to itself (`alone`: no other batch of this process in flight on
 // the device — 768 = 8 x 96: serial steps +2 %; with other chains in flight the third workgroup's registers are worth more to them: headline -3.7 %) —
 // whatever the number of pairs: ONE 100 k-point pair used to get 49 workgroups for 256 CUs, with 256 a registration takes 0.86 instead of 1.01 ms.
-// Bounds: at most 8 queries per thread (k_icp_late's worklist, and the amortisation of the 29-term block reduction has little left to give beyond),
+// Bounds: at most 7 queries per thread (M3D_LATE_QPT: k_icp_late's worklist; the amortisation of the 29-term block reduction has little left to give beyond),
 // at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
 int m3d_acc_blocks(int max_n_src, int n_pairs, bool alone) {
-    static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : 8; return (q >= 1 && q <= 64) ? q : 8; }();
+    static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : M3D_LATE_QPT; return (q >= 1 && q <= 64) ? q : M3D_LATE_QPT; }();
     static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
     static const int fill = [] { const char* v = getenv("M3DREG_ACC_FILL"); return v ? atoi(v) : 1; }();   // 0: round 2's rule (A/B)
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
@@ -1981,15 +2044,21 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     // A late iteration nobody brackets runs as ONE launch (k_icp_late). With an event bracket around the correspondence step (bench.py
     // samples some iterations; its untimed roofline step brackets all of them) the same iteration runs as the two-launch chain — same
     // bits — because the bracket's two halves do not exist inside a fused launch.
-    if (fused_ok && !k0 && !k1 && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * 8 >= (long long)max_n_src) {
-        if (metric == 1) hipLaunchKernelGGL(k_icp_late<1>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress);
-        else hipLaunchKernelGGL(k_icp_late<0>, dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress);
+    if (fused_ok && !k0 && !k1 && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * M3D_LATE_QPT >= (long long)max_n_src) {
+        static const int late_small = [] { const char* v = getenv("M3DREG_LATE_SMALL"); return v ? atoi(v) : -1; }();   // -1: the small-footprint variant when other batches are in flight; 0 / 1: never / always (A/B)
+        // (the small variant's overflow entries live in the tile records' array: there must be one, and a stretch of it for every workgroup)
+        const bool small_ok = w.rec != nullptr && (long long)bpp_a * (M3D_LATE_CAP - M3D_LATE_CAPS) <= (long long)w.rec_stride;
+        const bool small = small_ok && (late_small < 0 ? !w.acc_alone : late_small != 0);
+#define M3D_LATE_LAUNCH(MET, SM) hipLaunchKernelGGL((k_icp_late<MET, SM>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress)
+        if (metric == 1) { if (small) M3D_LATE_LAUNCH(1, true); else M3D_LATE_LAUNCH(1, false); }
+        else { if (small) M3D_LATE_LAUNCH(0, true); else M3D_LATE_LAUNCH(0, false); }
+#undef M3D_LATE_LAUNCH
         M3D_DBG(s, "k_icp_late");
         return;
     }
     // the queries k_nn_iter<lean> cannot bin (M3D_NN_PENDING): walked by the reduction pass itself, or — a handle whose last registration had many — by a launch of their own
     const bool lean_iter = w.tiles && !late && w.lean;
-    const bool walk_in_acc = lean_iter && !w.fallback_launch && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * 8 >= (long long)max_n_src;   // (the pair's last workgroup zeroes the pending count: m3d_pair_tail)
+    const bool walk_in_acc = lean_iter && !w.fallback_launch && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * M3D_LATE_QPT >= (long long)max_n_src;   // (the pair's last workgroup zeroes the pending count: m3d_pair_tail)
     if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");

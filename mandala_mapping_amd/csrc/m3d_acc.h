@@ -12,7 +12,7 @@
 // BIASED by 2^31 (sign bit flipped: every addend is then non-negative and a wrap is the unsigned carry), which are exact modulo 2^32, and
 // a carry count per sum in an 8-bit field (four per register: 8 more VGPRs); wide() puts them together and takes the bias out again
 // (2^31 x the number of terms, which is the count slot): the same integers, bit for bit. A field holds 255 carries: a thread adds at
-// most 128 streamed terms (m3d_acc_blocks) or 8 streamed + 64 walked ones (M3D_LATE_CAP / 32 rounds) per sum, one carry each at most.
+// most 128 streamed terms (m3d_acc_blocks) or 7 streamed + 56 walked ones (M3D_LATE_CAP / 32 rounds) per sum, one carry each at most.
 // (Carries are NOT rare — a floor point's n_z^2 term alone is ~2^30 — so handing them to LDS atomics made both kernels a quarter
 // slower; the signed-overflow rule instead of the bias cost ten instructions per term instead of five and gave half the gain away.)
 template <int NACC> struct M3dAcc64 {
