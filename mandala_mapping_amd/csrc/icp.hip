@@ -2045,7 +2045,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     // samples some iterations; its untimed roofline step brackets all of them) the same iteration runs as the two-launch chain — same
     // bits — because the bracket's two halves do not exist inside a fused launch.
     if (fused_ok && !k0 && !k1 && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * M3D_LATE_QPT >= (long long)max_n_src) {
-        static const int late_small = [] { const char* v = getenv("M3DREG_LATE_SMALL"); return v ? atoi(v) : -1; }();   // -1: the small-footprint variant when other batches are in flight; 0 / 1: never / always (A/B)
+        const int late_small = w.late_small;   // (M3DREG_LATE_SMALL at m3dreg_create) -1: the small-footprint variant when other batches are in flight; 0 / 1: never / always
         // (the small variant's overflow entries live in the tile records' array: there must be one, and a stretch of it for every workgroup)
         const bool small_ok = w.rec != nullptr && (long long)bpp_a * (M3D_LATE_CAP - M3D_LATE_CAPS) <= (long long)w.rec_stride;
         const bool small = small_ok && (late_small < 0 ? !w.acc_alone : late_small != 0);

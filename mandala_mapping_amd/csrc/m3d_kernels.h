@@ -137,6 +137,7 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     int tiles;                   // 1 = dense blocks bin their searches by target tile and k_nn_tiles answers them from LDS (M3DREG_TILES)
     int coop_kernel;             // 1 = this level is a coarser level of a pyramid: k_nn_coop is launched behind k_nn_iter<false> and answers the pairs whose target level is crowded
     int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; needs every target of the batch to have tiles (M3DREG_LEAN)
+    int late_small;              // k_icp_late's variant: -1 = the small-footprint one when other batches are in flight (acc_alone == 0), 0 = never, 1 = always (M3DREG_LATE_SMALL)
     int acc_alone;               // 1 = no other batch of this process was in flight on the device when this one was enqueued: the reduction pass takes the larger grid (m3d_acc_blocks)
     int fallback_launch;         // 1 = k_nn_fallback is launched behind k_nn_iter<true>; 0 = the reduction pass walks what is left pending itself (M3DREG_FALLBACK)
     int ntile_max;               // tiles per pair the arrays below are laid out for

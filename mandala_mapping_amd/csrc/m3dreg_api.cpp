@@ -118,6 +118,7 @@ struct m3dreg_handle {
     int fallback_mode = 0;         // M3DREG_FALLBACK at m3dreg_create: 0 auto, 1 launch, 2 fold
     bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
     uint32_t coop_seen = 0;
+    int late_small = -1;           // M3DREG_LATE_SMALL at m3dreg_create
     bool batch_alone = true;       // the batch being enqueued found no other batch of this process in flight on the device (g_batches_in_flight)
     bool fallback_hot = false;     // the last finished batch sent many queries past the tiles (more than 256 per pair and iteration): k_nn_fallback is launched again
     size_t last_trace_n = 0;
@@ -680,6 +681,7 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // last finished batch left many queries to it (batch_wait). Same bits either way.
     w.fallback_launch = (h->fallback_mode == 1 || (h->fallback_mode == 0 && h->fallback_hot)) ? 1 : 0;
     w.acc_alone = h->batch_alone ? 1 : 0;
+    w.late_small = h->late_small;
     // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels: 1 (default) = where the handle's last finished batch had a crowded target level (and on
     // a handle's first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level —, 0 = never
     // (crowded levels stay inside k_nn_iter<false>, eight passes per workgroup), 2 = always. A wrong guess costs time, never a bit: without the launch
@@ -871,6 +873,7 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_LEAN")) h->lean = atoi(v) != 0;
+    if (const char* v = getenv("M3DREG_LATE_SMALL")) h->late_small = atoi(v) < 0 ? -1 : (atoi(v) != 0);
     if (const char* v = getenv("M3DREG_FALLBACK")) h->fallback_mode = !strcmp(v, "launch") ? 1 : (!strcmp(v, "fold") ? 2 : 0);
     if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }
     if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }

@@ -635,6 +635,24 @@ def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkey
         _same_stats(st2[k], sto)
 
 
+@pytest.mark.parametrize("fuse_from", ["1", "8"])
+def test_small_footprint_late_kernel_and_its_overflow_list(reg, orc, monkeypatch, fuse_from):
+    """k_icp_late<.., SMALL> — what a handle launches when other batches are in flight — forced (M3DREG_LATE_SMALL=1): its LDS worklist holds 512 entries, the
+    rest goes to the workgroup's stretch of the tile records' array. fuse_from 1: the fused launch runs from the second iteration on, when nearly every
+    query is uncertified, so every workgroup overflows; 8: the shipped boundary. Same poses, traces and statistics as the oracle, bit for bit."""
+    monkeypatch.setenv("M3DREG_LATE_SMALL", "1")
+    monkeypatch.setenv("M3DREG_TILE_ITERS", fuse_from)
+    monkeypatch.setenv("M3DREG_FUSE_FROM", fuse_from)
+    src, tgt, _ = synth.hdl32_pair(1500, 4100, 4101, dx=0.25, dy=-0.1, dyaw_deg=2.0)
+    p = _params(leaf=0.1, iterations=12, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([src, tgt], source_only=[True, False])
+    T1, st1 = R.align(cs, ct)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True), trace_cap=16)
+    assert np.array_equal(R.trace()[:12], tr2[:12]) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+
+
 def test_batches_queued_behind_each_other_on_one_stream(reg, orc):
     """The bench's pipeline: several handles share ONE HIP stream, each holds a batch — bucketing (enqueue-only) and iterations of
     batch k+1 are queued behind batch k, nothing is waited for until every batch has been enqueued, and clouds go back to their
