@@ -369,7 +369,7 @@ __host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap
 __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
     const M3dBuild& B = builds[blockIdx.x];
     const int nblk = (B.n + 255) / 256;
-    __shared__ uint32_t sh[2][256];
+    __shared__ uint32_t sh[2][4];
     __shared__ uint32_t wv[M3D_ORDER_CAP];   // occupied voxels of every 256-point block (k_count_cells), for the block order below
     const bool want_order = B.order != nullptr && nblk <= M3D_ORDER_CAP;
     uint32_t carryV = 0, carryB = 0;
@@ -378,16 +378,19 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
         const int b = base + t;
         const uint32_t vV = b < nblk ? B.hist[2 * b] : 0u, vB = b < nblk ? B.hist[2 * b + 1] : 0u;
         if (want_order && b < nblk) wv[b] = vV;
-        sh[0][t] = vV; sh[1][t] = vB;
+        // inclusive scans of the two counts over the 256 threads: shuffles inside a wave, the wave totals through LDS (sixteen barriers of a
+        // Hillis-Steele scan in LDS before)
+        uint32_t iV = vV, iB = vB;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t uV = __shfl_up(iV, o), uB = __shfl_up(iB, o); if ((t & 63) >= o) { iV += uV; iB += uB; } }
+        if ((t & 63) == 63) { sh[0][t >> 6] = iV; sh[1][t >> 6] = iB; }
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            const uint32_t aV = t >= o ? sh[0][t - o] : 0u, aB = t >= o ? sh[1][t - o] : 0u;
-            __syncthreads();
-            sh[0][t] += aV; sh[1][t] += aB;
-            __syncthreads();
-        }
-        if (b < nblk) B.hist[2 * b] = carryV + sh[0][t] - vV;
-        carryV += sh[0][255]; carryB += sh[1][255];
+        uint32_t bV = 0, bB = 0, totV = 0, totB = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t a = sh[0][w], c = sh[1][w]; if (w < (t >> 6)) { bV += a; bB += c; } totV += a; totB += c; }
+        iV += bV; iB += bB;
+        if (b < nblk) B.hist[2 * b] = carryV + iV - vV;
+        carryV += totV; carryB += totB;
         __syncthreads();
     }
     if (t == 0) {
@@ -408,7 +411,20 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
         __syncthreads();
         for (int b = t; b < nblk; b += 256) atomicAdd(&bin[min(wv[b], 256u)], 1u);
         __syncthreads();
-        if (t == 0) { uint32_t run = 0; for (int k = 0; k <= 256; k++) { const uint32_t c = bin[k]; bin[k] = run; run += c; } }
+        {   // exclusive scan of the 257 bins: shuffles inside a wave, the four wave totals through LDS (one thread walking the bins was 257 dependent LDS
+            // round trips: 8 of this kernel's 10 us)
+            const uint32_t c = bin[t];
+            uint32_t inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+            __shared__ uint32_t wtot[4];
+            if ((t & 63) == 63) wtot[t >> 6] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int w = 0; w < (t >> 6); w++) before += wtot[w];
+            bin[t] = before + inc - c;
+            if (t == 255) bin[256] = before + inc;   // (bin 256 — blocks of 256 and more occupied voxels — starts behind all others; its own count is not needed)
+        }
         __syncthreads();
         for (int b = t; b < nblk; b += 256) B.order[atomicAdd(&bin[min(wv[b], 256u)], 1u)] = (uint32_t)b;
     }
