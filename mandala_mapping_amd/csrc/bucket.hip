@@ -632,8 +632,8 @@ extern "C" hipError_t m3d_debug_read_tb(unsigned long long* out, unsigned int* n
 #else
 #define TB_STAMP(k) ((void)0)
 #endif
-__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first) {
+    const M3dBuild& B = builds[blockIdx.y * row_stride + row_first];   // (a row per build, or — tiles on finest levels only, the default — per cloud: its last build)
     if (!B.thdr || !B.htab) return;
     const int nv = B.grid.n_valid;
     const int t = blockIdx.x, p0 = t * M3D_TILE_PTS;
@@ -957,8 +957,8 @@ __device__ __forceinline__ M3dLevelDev build_level(const M3dBuild& B) {
     return L;
 }
 
-__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud) {
+    const M3dBuild& B = builds[blockIdx.y * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build — a row per build started two workgroups in three for nothing)
     if (!B.mom) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if ((int)(blockIdx.x * blockDim.x) >= B.grid.n_valid) return;
@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 #define NRM_TRIP 32
 #endif
 __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread) {
-    const M3dBuild& B = builds[blockIdx.y];
+    const int ng_build = (int)blockIdx.y * grids_per_cloud;   // (one row per CLOUD, as in k_cell_moments)
+    const M3dBuild& B = builds[ng_build];
     if (!B.mom) return;
     // eight lanes per occupied voxel, one BUCKET of the 27-voxel neighbourhood each: the 3x3x3 voxels around a voxel lie in exactly 2x2x2
     // buckets, so one probe of the level's table per lane (both halves of the entry in one round trip) replaces the 27 dependent
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
                 vox[u] = lo;
             }
             for (int l = 1; l < grids_per_cloud; l++) {
-                const M3dBuild& LB = builds[blockIdx.y + l];
+                const M3dBuild& LB = builds[ng_build + l];
                 if (!LB.nrm_sorted) continue;
                 const uint32_t* inv = level_inverse(LB);
                 uint32_t pos[4];
@@ -1233,7 +1234,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 
 // the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid) {
+                                   int any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid) {
     const int n_builds = n_clouds * grids_per_cloud;
     const int max_passes = 4;   // a build whose keys need fewer skips the later ones on the device
     hipLaunchKernelGGL(k_grid_params, dim3((n_clouds + 63) / 64), dim3(64), 0, s, d_builds, n_clouds, grids_per_cloud);
@@ -1275,13 +1276,14 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
     M3D_DBG(s, "k_chunk_boxes");
     if (any_tiles) {
-        hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_builds), dim3(256), 0, s, d_builds);
+        if (any_tiles == 1) hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1);
+        else hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_builds), dim3(256), 0, s, d_builds, 1, 0);
         M3D_DBG(s, "k_tile_build");
     }
     if (any_normals) {
-        hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+        hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 1024), n_builds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
+        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 256), n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
     }
     return hipGetLastError();

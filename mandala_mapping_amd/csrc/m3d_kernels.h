@@ -68,7 +68,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 // n_builds = n_clouds * grids_per_cloud, the builds of a cloud are consecutive. No host input beyond sizes: the grid geometry, the
 // number of sort passes and the error state of every cloud are derived on the device.
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
-                                   bool any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid);   // pyramid: some build has fine >= 0
+                                   int any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid);   // any_tiles: 0 none, 1 only clouds' LAST builds (finest levels) have tiles, 2 any build may; pyramid: some build has fine >= 0
 hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const float4* nrm, int n, float* xyz, float* nxyz);
 
 // aggregate.hip

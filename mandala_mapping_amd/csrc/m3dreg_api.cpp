@@ -438,7 +438,8 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         D.xyz = cl[i]->xyz; D.aabb = aabb[i];
     }
     // ---- a3/a4/a9: one build descriptor per grid; only sizes, pointers and the leaf come from the host -------------------------
-    bool any_tiles = false, any_fine = false;
+    int any_tiles = 0;   // 0 none, 1 only clouds' last builds (finest levels: the default), 2 some other build too (M3DREG_TILES_ALL_LEVELS)
+    bool any_fine = false;
     for (size_t i = 0; i < k; i++) {
         m3dreg_cloud* c = cl[i];
         const bool no_normals = in[i].src_only;   // a source-only cloud: sorted, no normal grid, no normals
@@ -469,7 +470,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             if (!is_ng && no_normals && gidx - (want_normals ? 1 : 0) < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // nor the coarser levels of its pyramid: a registration streams a source in its FINEST level's order on every level (build_jobs)
             if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
             any_fine = any_fine || B.fine >= 0;
-            if (!is_ng && !no_normals && h->tiles && L.thdr) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = true; c->has_tiles = true; }
+            if (!is_ng && !no_normals && h->tiles && L.thdr) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = std::max(any_tiles, gidx == grids_per_cloud - 1 ? 1 : 2); c->has_tiles = true; }
         }
     }
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
