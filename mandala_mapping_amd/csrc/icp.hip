@@ -1991,7 +1991,7 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 int m3d_acc_blocks(int max_n_src, int n_pairs, bool alone) {
     static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : M3D_LATE_QPT; return (q >= 1 && q <= 64) ? q : M3D_LATE_QPT; }();
     static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
-    static const int fill = [] { const char* v = getenv("M3DREG_ACC_FILL"); return v ? atoi(v) : 1; }();   // 0: round 2's rule (A/B)
+    const int fill = [] { const char* v = getenv("M3DREG_ACC_FILL"); return v ? atoi(v) : 1; }();   // 0: round 2's rule (A/B; read at every call: scripts/stress_parity.py switches it between handles)
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
     if (fixed > 0) return fixed > b_min ? fixed : b_min;
     int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
@@ -2029,7 +2029,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max;
     {   // a work item of k_nn_tiles is one workgroup's pass over <= tile_chunk records: ONE 100 k-point pair makes 196 items of 512 for 256 CUs that hold three workgroups each
-        static const int forced = [] { const char* v = getenv("M3DREG_TILE_CHUNK"); const int c = v ? atoi(v) : 0; return (c == 512 || c == 256 || c == 128) ? c : 0; }();
+        const int forced = [] { const char* v = getenv("M3DREG_TILE_CHUNK"); const int c = v ? atoi(v) : 0; return (c == 512 || c == 256 || c == 128) ? c : 0; }();   // (read at every call, like M3DREG_ACC_FILL)
         const long long items = (long long)n_pairs * ((max_n_src + M3D_TILE_CHUNK - 1) / M3D_TILE_CHUNK);
         A.tile_chunk = forced ? forced : (items >= 768 ? M3D_TILE_CHUNK : M3D_TILE_CHUNK / 2);   // (config 3: 0.867 / 0.843 / 0.855 ms per registration with 512 / 256 / 128)
     } A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
