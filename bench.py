@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--pageable", action="store_true", help="--multi-devices / --from-host: hand over PAGEABLE host payloads (default: pinned, m3dreg_host_alloc)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this one even for --gpus 1 (what --gpus N > 1 does when torchrun did not): checks that "
                                                          "the launcher adds nothing to the measurement")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N without torchrun: seconds after which the launcher ends its rank processes")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="the block of --steps timed steps is repeated (each block bracketed by barrier + synchronize on both sides, exactly --steps steps) "
@@ -129,21 +130,52 @@ def launch_ranks(args):
     nor the library) — starts N fresh rank processes of this same script, one per device, with the environment torchrun would give them
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), so that every rank runs EXACTLY the per-rank code of the N = 1 line:
     device-resident payloads, the same steps in flight, rendezvous over RCCL, max-over-ranks timing, rank 0 prints the one JSON line.
-    Children are started (subprocess), never exec'ed into; this process only waits and returns the worst exit code."""
+    Children are started (subprocess), never exec'ed into. All of them are polled together: the first rank that exits with an error ends
+    the others (they would otherwise sit in the rendezvous / a barrier until the collective's timeout) and its code is this run's; an
+    overall --launch-timeout does the same for a run that hangs."""
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
+    # the port stays bound (SO_REUSEADDR, never listening) until the ranks have been started: nobody else is handed it by bind(0) in between
+    so = socket.socket()
+    so.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
     argv = [a for a in sys.argv[1:] if a != "--spawn"]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M3D_BENCH_RANK_PROCESS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))   # stdout / stderr inherited: rank 0's line is this run's line
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    if rc:
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M3D_BENCH_RANK_PROCESS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))   # stdout / stderr inherited: rank 0's line is this run's line
+    finally:
+        so.close()
+    rc, deadline = 0, time.monotonic() + args.launch_timeout
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = abs(r) or 1
+                print(f"[bench] rank process {procs.index(p)} exited with code {r}: ending the other ranks", file=sys.stderr)
+                break
+        if rc == 0 and live:
+            if time.monotonic() > deadline:
+                rc = 124
+                print(f"[bench] --launch-timeout {args.launch_timeout:.0f} s reached: ending the rank processes", file=sys.stderr)
+            else:
+                time.sleep(0.05)
+    if rc:   # the ranks this launcher started (exact PIDs), first politely
+        for p in live:
+            p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
         raise SystemExit(rc)
 
 
@@ -157,6 +189,11 @@ def main():
         return launch_ranks(args)
     if os.environ.get("M3D_BENCH_DRYRUN"):   # tests/test_bench_launcher.py: what a rank process is started with (no GPU, no torch)
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"argv": sys.argv[1:]}), flush=True)
+        fail_rank = os.environ.get("M3D_BENCH_DRYRUN_FAIL_RANK")   # (the launcher's failure path: that rank dies, the others "hang in the rendezvous")
+        if fail_rank is not None:
+            if os.environ.get("RANK") == fail_rank:
+                raise SystemExit(3)
+            time.sleep(300)
         return
     import torch
     import torch.distributed as dist

@@ -256,6 +256,10 @@ int m3dagg_add_cloud(m3dagg* a, const void* data, size_t n, size_t point_step, s
                      const double tf7[7]);
 /* rotLaserScanCallback (:256-288): ranges[i] at angle_min + i * angle_increment, z = 0 */
 int m3dagg_add_scan(m3dagg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf7[7]);
+/* (ABI 5) which function `point.x = cos(ang)*dist` (:281-282, float operands, unqualified call) resolves to: 0 (default) = C's
+ * double cos(double) — ang promoted, the product formed in double, rounded once into the float field: what GCC < 6 / the ROS1-era
+ * toolchains do; 1 = the float overload (cosf(ang) * dist in float: GCC >= 6 with the C++ <math.h> wrapper visible). */
+int m3dagg_set_scan_trig(m3dagg* a, int float_overload);
 /* getProgress (:119-124) in percent, isPointcloudReady (:95-103), currentAngularDistance, points kept so far */
 int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t* n_points);
 /* publishPointcloud (:194-212) without the publish: buckets the aggregate as an m3dreg_cloud, then clears and

@@ -29,7 +29,7 @@ EXPORTS = [
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
     "m3dreg_cloud_create_pc2",
-    "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
+    "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_set_scan_trig", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
@@ -92,6 +92,7 @@ def lib():
     L.m3dagg_destroy.argtypes = [vp]
     L.m3dagg_add_cloud.argtypes = [vp, vp, sz, sz, sz, sz, sz, f64p]
     L.m3dagg_add_scan.argtypes = [vp, f32p, sz, C.c_float, C.c_float, f64p]
+    L.m3dagg_set_scan_trig.argtypes = [vp, C.c_int]
     L.m3dagg_status.argtypes = [vp, f64p, C.POINTER(C.c_int), f64p, C.POINTER(sz)]
     L.m3dagg_take_cloud.argtypes = [vp, C.POINTER(vp)]
     L.m3dagg_restart.argtypes = [vp]
@@ -501,6 +502,10 @@ class Aggregator:
         buf = (C.c_char * len(msg.data)).from_buffer_copy(msg.data)
         t = np.asarray(tf7, np.float64)
         self._reg._check(lib().m3dagg_add_cloud(self._a, buf, msg.n, msg.point_step, ox, oy, oz, _ptr(t, C.c_double)), "m3dagg_add_cloud")
+
+    def set_scan_trig(self, float_overload: bool):
+        """which cos / sin m3d_aggregator.cpp:281-282 resolves to: False (default) = double cos(double), True = the float overload"""
+        self._reg._check(lib().m3dagg_set_scan_trig(self._a, int(bool(float_overload))), "m3dagg_set_scan_trig")
 
     def add_scan(self, ranges, angle_min, angle_increment, tf7):
         r = np.ascontiguousarray(ranges, np.float32)

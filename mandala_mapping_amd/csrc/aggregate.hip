@@ -19,7 +19,11 @@ __device__ __forceinline__ bool agg_point(const M3dAggArgs& A, int i, float4& pp
     } else {
         const float ang = A.angle_min + (float)i * A.angle_inc;   // :272
         const float dist = A.ranges[i];
-        px = cosf(ang) * dist; py = sinf(ang) * dist; pz = 0.0f;  // :281-283
+        // :281-283 `cos(ang)*dist` with float operands: mode 1 = C's double cos(double), the product formed in double and rounded once into the
+        // float field (the default: what the pre-GCC-6 toolchains of this ROS1 code resolve the unqualified call to); mode 2 = the float overload
+        if (A.mode == 1) { px = (float)(cos((double)ang) * (double)dist); py = (float)(sin((double)ang) * (double)dist); }
+        else { px = cosf(ang) * dist; py = sinf(ang) * dist; }
+        pz = 0.0f;
     }
     const double x = (double)px, y = (double)py, z = (double)pz;
     // tf::Transform::operator*(Vector3): basis row dot x + origin, all double (built with -ffp-contract=off)

@@ -73,7 +73,7 @@ hipError_t m3d_launch_export_sorted(hipStream_t s, const float4* pts, const floa
 
 // aggregate.hip
 struct M3dAggArgs {
-    int mode;                    // 0 = PointCloud2 payload, 1 = LaserScan ranges
+    int mode;                    // 0 = PointCloud2 payload, 1 = LaserScan ranges (cos / sin in double, product rounded once), 2 = LaserScan ranges (cosf / sinf)
     int n;
     const uint8_t* raw; int step, ox, oy, oz;
     const float* ranges; float angle_min, angle_inc;

@@ -293,12 +293,19 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
     c->xyz = k.take<float4>(n);
     for (int l = 0; l < P.n_levels; l++) {
         DevLevel& L = c->lv[l];
+        if (c->source_only && l < P.n_levels - 1) {   // the coarser levels of a source-only cloud are never built (create_clouds: B.n = 0): only their meta exists
+            L = DevLevel();
+            L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
+            continue;
+        }
         L.hcap = table_cap(n);
         L.bigcap = uint32_t(n / 65536 + 1);
         L.pts = k.take<float4>(n);
-        L.htab = k.take<M3dBucket>(L.hcap);
-        L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
-        L.cbox = k.take<float4>(2 * ((n + M3D_CHUNK - 1) / M3D_CHUNK));
+        if (!c->source_only) {   // (nobody searches a source-only cloud: no bucket table, no chunk boxes)
+            L.htab = k.take<M3dBucket>(L.hcap);
+            L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
+            L.cbox = k.take<float4>(2 * ((n + M3D_CHUNK - 1) / M3D_CHUNK));
+        } else { L.htab = nullptr; L.bigcum = nullptr; L.cbox = nullptr; L.hcap = 0; L.bigcap = 0; }
         L.order = k.take<uint32_t>((n + 255) / 256);
         // tiles only where they are used: a target's FINEST level. A pyramid's coarser levels hold too many points per bucket for an image (their tiles
         // ended up flagged, their searches in the global walk anyway) — not carving them saves 1.5 images of 56 KB per 512 points and a 1 MiB bitmap per
@@ -312,7 +319,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
             L.occ = k.take<uint32_t>(size_t(1) << (M3D_OCC_BITS - 5));
         } else { L.thdr = nullptr; L.timg = nullptr; L.timeta = nullptr; L.occ = nullptr; }
         L.keys = k.take<uint32_t>(n); L.skey = k.take<uint32_t>(n); L.perm = k.take<uint32_t>(n);
-        L.nrm = (P.metric == M3DREG_POINT_TO_PLANE) ? k.take<float4>(n) : nullptr;
+        L.nrm = (P.metric == M3DREG_POINT_TO_PLANE && !c->source_only) ? k.take<float4>(n) : nullptr;
         L.dyn = k.take<uint32_t>(sizeof(M3dLevelMeta) / 4);
     }
     return (k.off + 255) & ~size_t(255);
@@ -1161,6 +1168,7 @@ struct m3dagg {
     uint32_t* d_blocks = nullptr;
     uint8_t* d_stage = nullptr;    // staged message payload
     size_t capacity = 0, stage_bytes = 0, blocks_cap = 0;
+    int scan_trig_float = 0;       // m3dagg_set_scan_trig: 0 = cos(double) (default), 1 = the float overload
 };
 
 namespace {
@@ -1294,8 +1302,16 @@ int m3dagg_add_scan(m3dagg* a, const float* ranges, size_t n, float angle_min, f
     return m3d_guarded((a ? a->h : nullptr), "m3dagg_add_scan", [&]() -> int {
     if (!a || !ranges || !tf7 || n == 0 || n >= 0x7FFFFFFFull) return M3DREG_ERR_INVALID_ARG;
     M3dAggArgs A{};
-    A.mode = 1; A.n = int(n); A.angle_min = angle_min; A.angle_inc = angle_increment;
+    A.mode = a->scan_trig_float ? 2 : 1; A.n = int(n); A.angle_min = angle_min; A.angle_inc = angle_increment;
     return agg_add(a, A, ranges, n * sizeof(float), tf7);
+    });
+}
+
+int m3dagg_set_scan_trig(m3dagg* a, int float_overload) {
+    return m3d_guarded((a ? a->h : nullptr), "m3dagg_set_scan_trig", [&]() -> int {
+    if (!a || (float_overload != 0 && float_overload != 1)) return M3DREG_ERR_INVALID_ARG;
+    a->scan_trig_float = float_overload;
+    return M3DREG_OK;
     });
 }
 
@@ -1758,6 +1774,7 @@ int m3dreg_cloud_levels(const m3dreg_cloud* c) { return c ? c->n_levels : M3DREG
 int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m3dreg_grid_info* out) {
     return m3d_guarded(h, "m3dreg_cloud_grid_info", [&]() -> int {
     if (!h || !c || !out || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "grid_info: bad argument");
+    if (c->source_only && level < c->n_levels - 1) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "grid_info: the coarser levels of a source-only cloud are not built");
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
     const DevLevel& L = c->lv[level];
     memset(out, 0, sizeof(*out));
@@ -1775,6 +1792,7 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
                         float* sorted_xyz, float* normals) {
     return m3d_guarded(h, "m3dreg_cloud_export", [&]() -> int {
     if (!h || !c || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: bad argument");
+    if (c->source_only && level < c->n_levels - 1) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "cloud_export: the coarser levels of a source-only cloud are not built");
     if (normals && !c->has_normals) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_export: cloud has no normals");
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
     const DevLevel& L = c->lv[level];

@@ -205,9 +205,11 @@ def crowdedness(xyz, leaf=0.1):
     return float((cnt.astype(np.float64) ** 2).sum() / max(1, len(c)))
 
 
-def config5(n_scans=20, n_azimuth=3125, dedup=0.02):
+def config5(n_scans=22, n_azimuth=3125, dedup=0.01):
     """(live scan, map, T_gt, T_init): map = n_scans sweeps along a 10 m straight trajectory merged in the
-    frame of the first sweep and de-duplicated on a `dedup` grid (~2 M points at the defaults); live scan =
+    frame of the first sweep and de-duplicated on a `dedup` grid — 2 066 481 points at the defaults (BASELINE config 5 says
+    2 M: rounds 1-3 merged 20 sweeps on a 2 cm grid, which left 1.51 M; 20 sweeps hold 2.0 M returns before any
+    de-duplication, so the map takes 22 sweeps on a 1 cm grid); live scan =
     one more sweep 0.3 m / 0.2 m / 2 deg off the trajectory's midpoint; T_init = the midpoint pose itself (the
     odometry prior a map-based localiser starts from)."""
     P0 = sensor_pose(-5.0, 0.0, 0.0)

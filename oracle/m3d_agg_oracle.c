@@ -128,16 +128,28 @@ void orc_agg_add_cloud(orc_agg* a, const uint8_t* data, size_t n, size_t step, s
     }
 }
 
-/* rotLaserScanCallback :256-288 */
-void orc_agg_add_scan(orc_agg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf[7]) {
+/* rotLaserScanCallback :256-288.
+ * WHICH cos / sin: lines 281-282 read `point.x = cos(ang)*dist;` with `float ang, dist`, unqualified, in a file that includes no
+ * <cmath> / <math.h> itself (they arrive through the ROS headers) and has no using-directive. Two readings exist, and both are restated:
+ *   float_overload == 0 (the DEFAULT, what the toolchains this ROS1 code was written for do — GCC < 6 / libstdc++ whose <cmath> leaves only C's
+ *     `double cos(double)` in the global namespace): ang is promoted, cos runs in double, the product cos(ang) * dist is formed in double
+ *     (dist promoted) and rounded ONCE when it is stored into the float field;
+ *   float_overload == 1 (GCC >= 6 with the C++ <math.h> wrapper in sight: ::cos(float) exists and wins): cosf(ang) * dist in float.
+ * The two differ in the last bit of about a third of the coordinates. */
+void orc_agg_add_scan2(orc_agg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf[7], int float_overload) {
     double m[9], o[3], q[4];
     make_tf(tf, m, o, q);
     for (size_t i = 0; i < n; i++) {
         const float ang = angle_min + (float)i * angle_increment;   /* :272 (size_t -> float, float arithmetic) */
         const float dist = ranges[i];
-        const float x = cosf(ang) * dist, y = sinf(ang) * dist;     /* :281-283, z = 0 */
+        float x, y;                                                 /* :281-283, z = 0 */
+        if (float_overload) { x = cosf(ang) * dist; y = sinf(ang) * dist; }
+        else { x = (float)(cos((double)ang) * (double)dist); y = (float)(sin((double)ang) * (double)dist); }
         add_point(a, x, y, 0.0f, m, o, q);
     }
+}
+void orc_agg_add_scan(orc_agg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf[7]) {
+    orc_agg_add_scan2(a, ranges, n, angle_min, angle_increment, tf, 0);
 }
 
 size_t orc_agg_count(const orc_agg* a) { return a->n; }

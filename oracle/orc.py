@@ -51,6 +51,8 @@ def _lib(omp=False):
         L.orc_agg_add_cloud.restype = None
         L.orc_agg_add_scan.argtypes = [vp, f32p, C.c_size_t, C.c_float, C.c_float, f64p]
         L.orc_agg_add_scan.restype = None
+        L.orc_agg_add_scan2.argtypes = [vp, f32p, C.c_size_t, C.c_float, C.c_float, f64p, C.c_int]
+        L.orc_agg_add_scan2.restype = None
         L.orc_agg_count.argtypes = [vp]
         L.orc_agg_count.restype = C.c_size_t
         L.orc_agg_points.argtypes = [vp, f32p]
@@ -200,10 +202,11 @@ class Aggregator:
         t = np.asarray(tf7, np.float64)
         self._L.orc_agg_add_cloud(self._a, buf, msg.n, msg.point_step, ox, oy, oz, _ptr(t, C.c_double))
 
-    def add_scan(self, ranges, angle_min, angle_increment, tf7):
+    def add_scan(self, ranges, angle_min, angle_increment, tf7, float_overload=False):
+        """float_overload: which cos / sin `m3d_aggregator.cpp:281-282` resolves to (m3d_agg_oracle.c: orc_agg_add_scan2)"""
         r = np.ascontiguousarray(ranges, np.float32)
         t = np.asarray(tf7, np.float64)
-        self._L.orc_agg_add_scan(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double))
+        self._L.orc_agg_add_scan2(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double), int(bool(float_overload)))
 
     def status(self):
         return {"progress": self._L.orc_agg_progress(self._a), "ready": bool(self._L.orc_agg_ready(self._a)),

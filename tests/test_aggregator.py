@@ -91,16 +91,47 @@ def test_hip_aggregator_pointcloud_path_bit_exact(reg, orc):
     assert np.array_equal(a.points().view(np.uint32), o.points().view(np.uint32))
 
 
+def _scan_messages():
+    rng = np.random.default_rng(1)
+    return [(rng.uniform(0.3, 25.0, size=1081).astype(np.float32), head_tf(k, 20)) for k in range(20)]   # SICK LMS: 270 deg / 0.25 deg
+
+
+def test_oracle_laserscan_trig_readings_differ_in_the_last_bit(orc):
+    """`cos(ang)*dist` (m3d_aggregator.cpp:281-282): the double reading (default) and the float-overload reading are two different
+    restatements — about a third of the coordinates differ, by one float ulp of the coordinate."""
+    a, b = orc.Aggregator(BBOX), orc.Aggregator(BBOX)
+    for ranges, tf7 in _scan_messages()[:4]:
+        a.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7)
+        b.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7, float_overload=True)
+    pa, pb = a.points(), b.points()
+    assert len(pa) == len(pb) and 0.05 < (pa != pb).any(axis=1).mean() < 0.95
+    assert np.abs(pa - pb).max() <= 4 * 1.2e-7 * 25.0 * 1.5
+
+
 @pytest.mark.gpu
 def test_hip_aggregator_laserscan_path(reg, orc):
+    """The LaserScan path under the DEFAULT reading of m3d_aggregator.cpp:281-282 (double cos / sin, the product rounded once into the float
+    field: m3d_agg_oracle.c): bit-exact against the oracle — the device's and glibc's double cos / sin may differ in their last double bit, which
+    the rounding to float absorbs."""
     R = reg.Registrar(abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_POINT))
     a, o = reg.Aggregator(R, BBOX, capacity=100000), orc.Aggregator(BBOX)
-    rng = np.random.default_rng(1)
-    for k in range(20):
-        ranges = rng.uniform(0.3, 25.0, size=1081).astype(np.float32)       # SICK LMS: 270 deg / 0.25 deg
-        tf7 = head_tf(k, 20)
+    for ranges, tf7 in _scan_messages():
         a.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7)
         o.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7)
+    assert a.status() == o.status()
+    pa, po = a.points(), o.points()
+    assert len(pa) > 15000 and np.array_equal(pa.view(np.uint32), po.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_aggregator_laserscan_path_float_overload(reg, orc):
+    """The other reading (m3dagg_set_scan_trig(1): cosf / sinf in float), compared to 2 ulp: the device's cosf / sinf are not glibc's."""
+    R = reg.Registrar(abi.Params.make(leaf=0.25, iterations=5, metric=abi.POINT_TO_POINT))
+    a, o = reg.Aggregator(R, BBOX, capacity=100000), orc.Aggregator(BBOX)
+    a.set_scan_trig(True)
+    for ranges, tf7 in _scan_messages():
+        a.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7)
+        o.add_scan(ranges, np.float32(-2.3561945), np.float32(0.004363323), tf7, float_overload=True)
     sa, so = a.status(), o.status()
     assert sa["angle"] == so["angle"] and sa["ready"] == so["ready"] and sa["progress"] == so["progress"]
     pa, po = a.points(), o.points()

@@ -40,3 +40,22 @@ def test_the_launching_process_imports_neither_torch_nor_the_library():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "M3D_BENCH_RANK_PROCESS")}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
+
+
+def test_a_failing_rank_ends_the_others_and_its_code_is_the_run_s():
+    """the launcher polls all ranks; the first non-zero exit terminates the siblings (which would otherwise wait in the
+    rendezvous until the collective's timeout) and becomes the launcher's exit code — promptly."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "M3D_BENCH_RANK_PROCESS")}
+    env.update(M3D_BENCH_DRYRUN="1", M3D_BENCH_DRYRUN_FAIL_RANK="1")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 3 and time.monotonic() - t0 < 60, (r.returncode, r.stderr)
+    assert "rank process 1 exited with code 3" in r.stderr
+
+
+def test_the_launcher_s_overall_timeout():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "M3D_BENCH_RANK_PROCESS")}
+    env.update(M3D_BENCH_DRYRUN="1", M3D_BENCH_DRYRUN_FAIL_RANK="7")   # nobody fails: every rank "hangs"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-timeout", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr)

@@ -432,9 +432,9 @@ def test_batch_mixing_crowded_and_ordinary_coarse_levels(reg, orc, n_pairs):
 
 
 def test_config5_full_size_properties(reg):
-    """BASELINE config 5 at full size: ~2 M-point map vs 100 k live scan, multi-resolution voxel NN."""
+    """BASELINE config 5 at full size: 2 M-point map (2 066 481 points: 22 sweeps de-duplicated at 1 cm) vs 100 k live scan, multi-resolution voxel NN."""
     live, mp, Tgt, T0 = synth.config5()
-    assert len(mp) > 1_500_000
+    assert len(mp) >= 2_000_000
     p = _params(leaf=(0.4, 0.2, 0.1), iterations=(10, 10, 10), max_corr_dist=(1.0, 0.5, 0.3), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
     R = reg.Registrar(p)
     cs, ct = R.clouds([live, mp])
@@ -722,6 +722,64 @@ def test_config4_shard_full_size_properties(reg):
     for k in range(8):
         rot, tra = synth.pose_error(Tb[k], data[k][2])
         assert stb[k].status == abi.MAX_ITERATIONS and rot < 0.1 and tra < 0.006, (k, rot, tra)
+
+
+def _config4_shards(world=8, per_rank=8):
+    """the shards `bench.py --gpus 8` forms: LPT over the tabulated a-priori costs, 8 pairs per rank (bench.py main(), --shard lpt)"""
+    import json, os
+    from mandala_mapping_amd import sharding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    costs = json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json")))["costs"][: world * per_rank]
+    return sharding.lpt_assign(costs, world, capacity=per_rank)
+
+
+def test_config4_all_shards(reg):
+    """BASELINE config 4 as a whole: all 64 loop-closure pairs, in the eight LPT shards `bench.py --gpus 8` would hand to its ranks, one shard
+    at a time on this GPU (8 pairs x 100 000 rays per batch, the bench's parameters). Every pose lands inside BASELINE.md §3's bar, every
+    registration runs its 20 iterations, and for one pair of every shard — its most crowded one, the pair that sets the shard's time — the
+    batch result equals the single registration bit for bit."""
+    import json, os
+    p = _params(leaf=0.1, iterations=20, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    shards = _config4_shards()
+    assert sorted(k for s in shards for k in s) == list(range(64)) and all(len(s) == 8 for s in shards)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    costs = json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json")))["costs"]
+    worst = (0.0, 0.0)
+    for shard in shards:
+        data = [synth.config4_pair(k) for k in shard]
+        cl = R.clouds([c for src, tgt, _ in data for c in (src, tgt)], wait=False, source_only=[True, False] * 8)
+        Tb, stb = R.align_batch([(cl[2 * j], cl[2 * j + 1], None) for j in range(8)])
+        for j, k in enumerate(shard):
+            rot, tra = synth.pose_error(Tb[j], data[j][2])
+            assert stb[j].status == abi.MAX_ITERATIONS and stb[j].iterations == 20 and rot < 0.1 and tra < 0.006, (k, rot, tra, stb[j].as_dict())
+            worst = (max(worst[0], rot), max(worst[1], tra))
+        j = max(range(8), key=lambda j_: costs[shard[j_]])
+        cs, ct = R.clouds([data[j][0], data[j][1]], source_only=[True, False])
+        T1, st1 = R.align(cs, ct)
+        assert np.array_equal(T1, Tb[j]) and st1.n_corr == stb[j].n_corr, shard[j]
+        for c in list(cl) + [cs, ct]:
+            c.free()
+    print(f"config 4, 64 pairs: worst rotation error {worst[0]:.4f} deg, worst translation error {1e3 * worst[1]:.2f} mm")
+
+
+@pytest.mark.parametrize("which", ["config3", "config4_pair2", "config4_pair31"])
+def test_full_size_pairs_equal_the_oracle(reg, orc, which):
+    """BASELINE configs 3 and 4 at FULL size (100 000 rays per sweep) against the oracle, bit for bit: the single config-3 pair, an ordinary
+    config-4 pair (2: the lowest a-priori cost of the 64) and the most crowded one (31: 1.3 m from an obstacle, the highest cost) — bucketing of the
+    target, every per-iteration pose, the final pose and the statistics. The OpenMP build of the oracle takes about a second per pair."""
+    src, tgt, Tgt = synth.config3() if which == "config3" else synth.config4_pair(int(which[len("config4_pair"):]))
+    p = _params(leaf=0.1, iterations=20, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = reg.Registrar(p)
+    cs, ct = R.clouds([src, tgt], source_only=[True, False])
+    os_, ot = orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True)
+    _check_bucketing(ct, ot, 1)
+    T1, st1 = R.align(cs, ct)
+    T2, st2, tr2 = orc.align(p, os_, ot, trace_cap=32)
+    assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2)
+    _same_stats(st1, st2)
+    rot, tra = synth.pose_error(T1, Tgt)
+    assert rot < 0.1 and tra < 0.006, (rot, tra)
 
 
 def test_source_only_clouds_skip_the_normal_grid(reg, orc):
