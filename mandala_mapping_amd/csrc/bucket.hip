@@ -11,6 +11,21 @@
 // no MFMA (nothing here is a contraction).
 #include "m3d_kernels.h"
 
+// Workgroup -> (row, block) of the batched launches below (a row = one cloud or one grid of the batch; 1-D grids of rows * bpr workgroups).
+// Consecutive workgroups of a row go to consecutive XCDs (the dispatcher deals workgroups round-robin by linear id). Round 4 measured the
+// opposite — with a multiple of 8 rows, every row's workgroups on ONE XCD, so that a radix scatter's partly written lines or a finalize pass's
+// 1.6 MB gather set meet in one L2 —: every kernel of the pipeline got SLOWER, the pure streams too (k_voxel_keys 15.7 -> 21.6 us, k_finalize_level
+// 41 -> 77, k_tile_build 47 -> 74, k_rs_scatter 19.8 -> 23.9; bucketing 0.32 -> 0.49 ms per step, profiles/r04_xcd_rows.txt): eight XCDs walking
+// eight far-apart address streams lose more in DRAM locality than the L2s gain.
+struct M3dRB { int row, blk; };
+__device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr) {
+    const int id = (int)blockIdx.x;
+    M3dRB r;
+    r.row = id / bpr; r.blk = id - r.row * bpr;
+    (void)rows;
+    return r;
+}
+
 #define RS_THREADS 256
 #define RS_ROUNDS 8
 #define RS_TILE (RS_THREADS * RS_ROUNDS)
@@ -36,12 +51,13 @@ __device__ __forceinline__ float decode_field(const uint8_t* p, int is_f64, int 
 }
 
 // aabb (zero-initialised): [0..2] = max of ~ordered (i.e. the minimum), [3..5] = max of ordered, [6] = finite points
-__global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict__ descs) {
-    const M3dDecode D = descs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_decode_aabb(const M3dDecode* __restrict__ descs, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dDecode D = descs[rb.row];
     const int n = D.n;
     uint32_t mn[3] = { 0u, 0u, 0u }, mx[3] = { 0u, 0u, 0u };
     uint32_t cnt = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = rb.blk * (int)blockDim.x + (int)threadIdx.x; i < n; i += bpr * (int)blockDim.x) {
         float px, py, pz;
         if (!D.generic) {
             const uint8_t* p = D.raw + (size_t)i * D.step;
@@ -128,9 +144,10 @@ __global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int g
 }
 
 // ---- a3: voxel key per point ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
+    const int i = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= B.n) return;
     const float4 pi = B.xyz[i];
     const float px = pi.x, py = pi.y, pz = pi.z;
@@ -147,10 +164,11 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__
 
 // a coarser level of a pyramid starts its sort from the finest level's ORDER (M3dBuild::fine): the LSD passes are stable, so inside a
 // coarse voxel the points then lie in the finest level's Morton order
-__global__ __launch_bounds__(256) void k_rekey(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_rekey(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
     if (B.fine < 0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= B.n) return;
     const uint32_t v = builds[B.fine].perm_out[i];
     B.ka[i] = B.keys[v]; B.va[i] = v;
@@ -177,24 +195,25 @@ __device__ __forceinline__ uint32_t* level_inverse(const M3dBuild& B) { return B
 // (fused = the batch's clouds are small enough — at most RS_FUSED_TILES tiles — for every scatter workgroup to scan the counters it
 // needs itself: no k_rs_scan launch, counters stored [tile][digit] so that those reads coalesce)
 #define RS_FUSED_TILES 128
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused, int phase) {
-    const M3dBuild& B = builds[blockIdx.y];
-    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;   // phase 1: the grids that wait for their cloud's finest level
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
+    if (pass >= B.sort_passes || rb.blk >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;   // phase 1: the grids that wait for their cloud's finest level
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
     const int n = B.n, shift = 8 * pass;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int base = blockIdx.x * RS_TILE;
+    const int base = rb.blk * RS_TILE;
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int i = base + r * RS_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(kin[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (fused) B.hist[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
-    else B.hist[threadIdx.x * B.ntiles + blockIdx.x] = h[threadIdx.x];
+    if (fused) B.hist[rb.blk * 256 + threadIdx.x] = h[threadIdx.x];
+    else B.hist[threadIdx.x * B.ntiles + rb.blk] = h[threadIdx.x];
 }
 
 // Clouds of more than RS_FUSED_TILES sort tiles (262 k points: a map): exclusive scan of a build's 256 * ntiles counters, in place, by
@@ -248,9 +267,11 @@ __global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restric
     }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase) {
-    const M3dBuild& B = builds[blockIdx.y];
-    if (pass >= B.sort_passes || (int)blockIdx.x >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const int tile = rb.blk;
+    const M3dBuild& B = builds[rb.row];
+    if (pass >= B.sort_passes || tile >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
     const int n = B.n, shift = 8 * pass, ntiles = B.ntiles;
@@ -271,19 +292,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = scanned[(j + k) * 256 + t];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { total += v[k]; before += (j + k < (int)blockIdx.x) ? v[k] : 0u; }
+            for (int k = 0; k < 8; k++) { total += v[k]; before += (j + k < tile) ? v[k] : 0u; }
         }
-        for (; j < ntiles; j++) { const uint32_t v = scanned[j * 256 + t]; total += v; before += (j < (int)blockIdx.x) ? v : 0u; }
+        for (; j < ntiles; j++) { const uint32_t v = scanned[j * 256 + t]; total += v; before += (j < tile) ? v : 0u; }
         inc = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
         if (lane == 63) wsum[wave] = inc;
         goff = before;
-    } else goff = scanned[t * ntiles + blockIdx.x];
+    } else goff = scanned[t * ntiles + tile];
     for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
     __syncthreads();
     if (fused) { for (int w = 0; w < wave; w++) goff += wsum[w]; goff += inc - total; }
-    const int base = blockIdx.x * RS_TILE;
+    const int base = tile * RS_TILE;
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rank[RS_ROUNDS];
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -326,12 +347,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
 // (table geometry is derived on the device: no host round trip between the sort and the table build)
 // (occupied voxels and buckets are counted per 256-position block, without atomics: contended returning atomics on one
 // address retire at ~5 per microsecond on this chip — 1500 of them were the whole cost of every variant that used them)
-__global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
     const int n = B.n;
-    if ((int)(blockIdx.x * 256) >= n) return;
+    if (rb.blk * 256 >= n) return;
     const uint32_t* skey = sorted_keys(B);
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = rb.blk * 256 + (int)threadIdx.x;
     bool vh = false, bh = false;
     if (j < n) {
         const uint32_t k = skey[j];
@@ -346,8 +368,8 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = (uint32_t)__popcll(bv); red[threadIdx.x >> 6][1] = (uint32_t)__popcll(bb); }
     __syncthreads();
     if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block
-        B.hist[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        B.hist[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        B.hist[2 * rb.blk] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        B.hist[2 * rb.blk + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     }
 }
 
@@ -430,22 +452,23 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
     if (!B.htab) return;   // a source-only cloud has no table
     const uint32_t T2 = 2u * (B.dyn[1] + 1u);
     uint4* t = reinterpret_cast<uint4*>(B.htab);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T2; i += gridDim.x * blockDim.x)
+    for (uint32_t i = (uint32_t)rb.blk * blockDim.x + threadIdx.x; i < T2; i += (uint32_t)bpr * blockDim.x)
         t[i] = (i & 1u) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(M3D_INVALID_KEY, 0u, 0u, 0u);
     const uint32_t nb = 8u * B.bigcap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) B.bigcum[i] = 0u;
+    for (uint32_t i = (uint32_t)rb.blk * blockDim.x + threadIdx.x; i < nb; i += (uint32_t)bpr * blockDim.x) B.bigcum[i] = 0u;
     if (B.occ) {   // occupancy bitmap of the bucket positions: one bit per bucket key, when the grid is small enough
         const int kb = B.grid.cb[0] + B.grid.cb[1] + B.grid.cb[2];
         const bool ok = kb <= M3D_OCC_BITS;
-        if (blockIdx.x == 0 && threadIdx.x == 0) B.dyn[7] = ok ? 1u : 0u;
+        if (rb.blk == 0 && threadIdx.x == 0) B.dyn[7] = ok ? 1u : 0u;
         if (ok) {
             const uint32_t nw = kb > 5 ? (1u << (kb - 5)) : 1u;
-            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) B.occ[i] = 0u;
+            for (uint32_t i = (uint32_t)rb.blk * blockDim.x + threadIdx.x; i < nw; i += (uint32_t)bpr * blockDim.x) B.occ[i] = 0u;
         }
     }
 }
@@ -456,11 +479,12 @@ __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const 
     return m3d_bucket_key(g, ix >> 1, iy >> 1, iz >> 1);
 }
 
-__global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
+    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     const int n = B.n;
-    if ((int)(blockIdx.x * blockDim.x) >= n) return;   // block-uniform
+    if (rb.blk * (int)blockDim.x >= n) return;   // block-uniform
     const bool inb = j < n;
     const uint32_t* skey = sorted_keys(B);
     const uint32_t* sval = sorted_vals(B);
@@ -478,7 +502,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
         const unsigned long long bh = __ballot(vhead);
         if (lane == 0) s_wc[wave] = (uint32_t)__popcll(bh);
         __syncthreads();
-        uint32_t off = B.hist[2 * blockIdx.x];
+        uint32_t off = B.hist[2 * rb.blk];
 #pragma unroll
         for (int w = 0; w < 4; w++) if (w < wave) off += s_wc[w];
         if (vhead) {
@@ -514,9 +538,10 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
 // and of the empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0); when it is also
 // the last point of its BUCKET it writes the bucket's population and, should that exceed 16 bits, claims a bigcum row.
 // The 16-bit cum values of such a bucket are meaningless (and unused): k_bucket_big rewrites them as 32-bit rows.
-__global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
+    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     const int n = B.n;
     if (j >= n || !B.htab) return;   // (a source-only cloud has no table)
     const uint32_t* skey = B.skey_out;
@@ -561,14 +586,15 @@ __device__ __forceinline__ void bucket_big_point(const M3dBuild& B, int j) {
 
 // exact AABB of every M3D_CHUNK consecutive sorted (finite) points: the search tests a crowded voxel's chunks by their boxes
 // before it gathers them (min / max of floats: exact, order-independent)
-__global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
     // (the same launch rewrites the rows of buckets with more than 65535 points as 32-bit counts: normally there are none, and an
     // extra, empty launch cost its 5 us on every step's critical path)
-    if (B.htab && B.dyn[4] != 0u) bucket_big_point(B, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+    if (B.htab && B.dyn[4] != 0u) bucket_big_point(B, rb.blk * (int)blockDim.x + (int)threadIdx.x);
     if (!B.cbox) return;
     // four lanes per chunk, four points each (a lane's 16-B loads and its neighbours' fall into the same cache lines), xor-shuffle merge
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     const int c = t >> 2, sub = t & 3;
     const int nv = B.grid.n_valid;
     const bool chunk_ok = c * M3D_CHUNK < nv;              // uniform over the 4 lanes of a chunk
@@ -632,11 +658,12 @@ extern "C" hipError_t m3d_debug_read_tb(unsigned long long* out, unsigned int* n
 #else
 #define TB_STAMP(k) ((void)0)
 #endif
-__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first) {
-    const M3dBuild& B = builds[blockIdx.y * row_stride + row_first];   // (a row per build, or — tiles on finest levels only, the default — per cloud: its last build)
+__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row * row_stride + row_first];   // (a row per cloud: its last build — tiles on finest levels only)
     if (!B.thdr || !B.htab) return;
     const int nv = B.grid.n_valid;
-    const int t = blockIdx.x, p0 = t * M3D_TILE_PTS;
+    const int t = rb.blk, p0 = t * M3D_TILE_PTS;
     if (p0 >= nv) return;
     const int p1 = min(p0 + M3D_TILE_PTS, nv);
     // LDS: the candidate set is dead once the staged-bucket list exists: the voxel directory of the image being written lives there
@@ -648,7 +675,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     __shared__ uint32_t s_src[M3D_TILE_PCAP];     // sorted position of every staged point of the image being written
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_ip[M3D_TILE_MAXIMG];   // points | voxels << 16 of every image
-    __shared__ uint32_t s_cnt, s_over;
+    __shared__ uint32_t s_cnt, s_over, s_nv;
     const int tid = threadIdx.x;
     const M3dGrid& g = B.grid;
     const uint32_t hmask = B.dyn[1];
@@ -852,16 +879,21 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     const bool crowded = s_over != 0u;
     const uint32_t extra = s_cnt;
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
-    // 6. the images
+    // 6. the images: per image the list of its voxels {key, LDS position | population - 1 | staged bucket} and the copies of its points; per tile
+    // (in its first image) the table sorted position - LDS position of every staged bucket
     TB_STAMP(5);
+    {
+        int32_t* tdelta = reinterpret_cast<int32_t*>(B.timg + (size_t)t * M3D_TILE_IMG_BYTES + M3D_TILE_IMG_DELTA);
+#pragma unroll
+        for (int q = 0; q < SPT; q++) if (occ[q]) tdelta[tid + 256 * q] = (int32_t)gst[q] - (int32_t)off[q];
+    }
     for (uint32_t j = 0; j < n_img; j++) {
         const uint32_t image = j == 0u ? (uint32_t)t : extra + j - 1u;
         uint8_t* img = B.timg + (size_t)image * M3D_TILE_IMG_BYTES;
-        uint32_t* gidx = reinterpret_cast<uint32_t*>(img + M3D_TILE_IMG_GIDX);
         float4* ipts = reinterpret_cast<float4*>(img + M3D_TILE_IMG_PTS);
-        for (int i = tid; i < M3D_TILE_VS; i += 256) s_vk[i] = M3D_INVALID_KEY;
+        if (tid == 0) s_nv = 0u;
         __syncthreads();
-        // the occupied voxels of this image's buckets into its directory; the sorted position of every staged point
+        // the occupied voxels of this image's buckets into its list (any order: k_nn_tiles hashes them); the sorted position of every staged point
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
             if (!occ[q] || im[q] != j) continue;
@@ -872,12 +904,9 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
                 const uint32_t c1 = (uint32_t)(((sub < 4) ? cumA : cumB) >> (16 * (sub & 3))) & 0xFFFFu;
                 if (c1 > c0) {
                     const uint32_t vkey = (2u * cx + (uint32_t)(sub & 1)) | ((2u * cy + (uint32_t)((sub >> 1) & 1)) << sh1) | ((2u * cz + (uint32_t)(sub >> 2)) << sh2);
-                    uint32_t h = (vkey * 0x9E3779B1u) >> (32 - 11);
-                    static_assert(M3D_TILE_VS == 2048, "voxel directory hash: 11 bits");
-                    for (;;) {   // voxel keys are unique: a successful CAS owns the slot (at most VCAP of the VS slots are ever taken)
-                        if (atomicCAS(&s_vk[h], M3D_INVALID_KEY, vkey) == M3D_INVALID_KEY) { s_vv[h] = (off[q] + c0) | ((c1 - c0) << 16); break; }
-                        h = (h + 1u) & (M3D_TILE_VS - 1u);
-                    }
+                    const uint32_t vi = atomicAdd(&s_nv, 1u);   // (at most VCAP per image: the cut above)
+                    s_vk[vi] = vkey;
+                    s_vv[vi] = (off[q] + c0) | ((c1 - c0 - 1u) << 11) | ((uint32_t)(tid + 256 * q) << 22);
                 }
                 c0 = c1;
             }
@@ -894,17 +923,18 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; r++) pv[r] = B.pts[gsrc[r]];
 #pragma unroll
-                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; if (pp < np) { gidx[pp] = gsrc[r]; ipts[pp] = pv[r]; } }
+                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; if (pp < np) ipts[pp] = pv[r]; }
             }
         }
         if (j == 0u) TB_STAMP(7);
-        uint2* vslots = reinterpret_cast<uint2*>(img);
-        for (int i = tid; i < M3D_TILE_VS; i += 256) vslots[i] = make_uint2(s_vk[i], s_vv[i]);
-        if (tid == 0) B.timeta[image] = M3dTileImgMeta{ s_ip[j] & 0xFFFFu, (s_ip[j] >> 16) | (crowded ? 0x80000000u : 0u) };
+        uint2* vlist = reinterpret_cast<uint2*>(img);
+        const uint32_t nvx = s_nv;
+        for (uint32_t i = (uint32_t)tid; i < nvx; i += 256u) vlist[i] = make_uint2(s_vk[i], s_vv[i]);
+        if (tid == 0) B.timeta[image] = M3dTileImgMeta{ s_ip[j] & 0xFFFFu, nvx | (crowded ? 0x80000000u : 0u) };
         __syncthreads();
     }
     TB_STAMP(8);
-    if (tid == 0) *H = M3dTileHdr{ extra, n_img, 0u, (s_ip[0] & 0xFFFFu) | (crowded ? 0x80000000u : 0u) };
+    if (tid == 0) *H = M3dTileHdr{ extra, n_img, n_e << 16, (s_ip[0] & 0xFFFFu) | (crowded ? 0x80000000u : 0u) };
 #ifdef M3D_TB_STAMPS
     if (tid == 0 && tb_slot < 4096u) g_tb_stamp[tb_slot][9] = ((unsigned long long)n_img << 32) | n_e;
 #endif
@@ -957,11 +987,12 @@ __device__ __forceinline__ M3dLevelDev build_level(const M3dBuild& B) {
     return L;
 }
 
-__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud) {
-    const M3dBuild& B = builds[blockIdx.y * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build — a row per build started two workgroups in three for nothing)
+__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build — a row per build started two workgroups in three for nothing)
     if (!B.mom) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((int)(blockIdx.x * blockDim.x) >= B.grid.n_valid) return;
+    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
+    if (rb.blk * (int)blockDim.x >= B.grid.n_valid) return;
     const M3dLevelDev L = build_level(B);
     const M3dGrid& g = L.g;
     const int lane = threadIdx.x & 63;
@@ -1030,8 +1061,9 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 #ifndef NRM_TRIP
 #define NRM_TRIP 32
 #endif
-__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread) {
-    const int ng_build = (int)blockIdx.y * grids_per_cloud;   // (one row per CLOUD, as in k_cell_moments)
+__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const int ng_build = rb.row * grids_per_cloud;   // (one row per CLOUD, as in k_cell_moments)
     const M3dBuild& B = builds[ng_build];
     if (!B.mom) return;
     // eight lanes per occupied voxel, one BUCKET of the 27-voxel neighbourhood each: the 3x3x3 voxels around a voxel lie in exactly 2x2x2
@@ -1046,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ bu
     __shared__ long long s_sum[NRM_TRIP][10];
     __shared__ uint32_t s_head[NRM_TRIP + 1];   // first sorted position of the trip's voxels, and of the voxel after them
     __shared__ float4 s_nrm[NRM_TRIP];
-    for (uint32_t vb = blockIdx.x * (uint32_t)NRM_TRIP; vb < n_vox; vb += gridDim.x * (uint32_t)NRM_TRIP) {   // (block-uniform: barriers and shuffles inside)
+    for (uint32_t vb = (uint32_t)rb.blk * (uint32_t)NRM_TRIP; vb < n_vox; vb += (uint32_t)bpr * (uint32_t)NRM_TRIP) {   // (block-uniform: barriers and shuffles inside)
     for (int rnd = 0; rnd < NRM_TRIP / 32; rnd++) {
     const int li = rnd * 32 + wv * 8 + grp;   // voxel of this trip this group sums up
     const uint32_t v = vb + (uint32_t)li;
@@ -1227,7 +1259,7 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
     int blocks = (max_n + 1023) / 1024;   // ~4 points per thread, one atomic set per block
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_decode_aabb, dim3(blocks, n_clouds), dim3(256), 0, s, d_descs);
+    hipLaunchKernelGGL(k_decode_aabb, dim3(blocks * n_clouds), dim3(256), 0, s, d_descs, n_clouds, blocks);
     M3D_DBG(s, "k_decode_aabb");
     return hipGetLastError();
 }
@@ -1242,48 +1274,48 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     const int blocks = (max_n + 255) / 256;
     const int ntiles = m3d_sort_tiles(max_n);
     const int cb = blocks > 256 ? 256 : blocks;
-    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
     M3D_DBG(s, "k_voxel_keys");
     for (int phase = 0; phase < (pyramid ? 2 : 1); phase++) {
         if (phase == 1) {   // the coarser levels of pyramids: keyed in their cloud's finest-level order, then sorted (stable) by their own keys
-            hipLaunchKernelGGL(k_rekey, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+            hipLaunchKernelGGL(k_rekey, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
             M3D_DBG(s, "k_rekey");
         }
         for (int pass = 0; pass < max_passes; pass++) {
             const int fused = ntiles <= RS_FUSED_TILES ? 1 : 0;   // (ntiles = the batch's largest cloud)
-            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase);
+            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles);
             M3D_DBG(s, "k_rs_hist");
             if (!fused) {
                 hipLaunchKernelGGL(k_rs_scan_sums, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
                 hipLaunchKernelGGL(k_rs_scan_apply, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
                 M3D_DBG(s, "k_rs_scan");
             }
-            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles);
             M3D_DBG(s, "k_rs_scatter");
         }
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_count_cells, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_count_cells, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
     M3D_DBG(s, "k_count_cells");
     hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
     M3D_DBG(s, "k_table_params");
-    hipLaunchKernelGGL(k_clear_table, dim3(cb, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_clear_table, dim3(cb * n_builds), dim3(256), 0, s, d_builds, n_builds, cb);
     M3D_DBG(s, "k_clear_table");
-    hipLaunchKernelGGL(k_finalize_level, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_finalize_level, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
     M3D_DBG(s, "k_finalize_level");
-    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);
+    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
     M3D_DBG(s, "k_bucket_counts");
-    hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks, n_builds), dim3(256), 0, s, d_builds);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
+    hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
     M3D_DBG(s, "k_chunk_boxes");
     if (any_tiles) {
-        if (any_tiles == 1) hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1);
-        else hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n), n_builds), dim3(256), 0, s, d_builds, 1, 0);
+        hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n) * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1, n_clouds, m3d_tiles_of(max_n));
         M3D_DBG(s, "k_tile_build");
     }
     if (any_normals) {
-        hipLaunchKernelGGL(k_cell_moments, dim3(blocks, n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud);
+        hipLaunchKernelGGL(k_cell_moments, dim3(blocks * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, n_clouds, blocks);
         M3D_DBG(s, "k_cell_moments");
-        hipLaunchKernelGGL(k_normals, dim3(std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 256), n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
+        const int nb_n = std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 256);
+        hipLaunchKernelGGL(k_normals, dim3(nb_n * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread, n_clouds, nb_n);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
         M3D_DBG(s, "k_normals");
     }
     return hipGetLastError();

@@ -224,7 +224,7 @@ __device__ __forceinline__ int m3d_quant(float term, float scale) {
 // slot of H(k,l), k <= l, in the row-major upper triangle
 __host__ __device__ constexpr int hslot21(int k, int l) { return k * 6 - (k * (k - 1)) / 2 + (l - k); }
 
-// (to_lds: the block's sums go to that LDS array and nowhere else — k_icp_late<.., SMALL> parks its streaming loop's there while it walks; add_lds: sums parked that way are added)
+// (to_lds: the block's sums go to that LDS array and nowhere else; add_lds: sums parked that way are added)
 template <int NACC, typename ACC>
 __device__ __forceinline__ void block_reduce_to_global(const ACC& acc, long long* __restrict__ sums, long long* __restrict__ partial = nullptr,
                                                        long long* to_lds = nullptr, const long long* add_lds = nullptr) {
@@ -373,7 +373,7 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 // While a query stays in the same voxel its neighbourhood is the same set of (static) target voxels, so
 // "-2" is answered again without a single probe. Exact: a changed voxel simply re-runs the full search.
 #define M3D_NN_NONE_CACHED (-2)
-#define M3D_NN_PENDING (-3)   // a query k_nn_iter<lean> could not hand to a tile: walked by k_nn_fallback, or (no such launch) by the reduction pass's workgroup that owns it
+#define M3D_NN_PENDING (-3)   // a query k_nn_iter<lean> could not hand to a tile: walked by the reduction pass's workgroup that owns it
 #define M3D_LATE_QPT 7      // queries per thread at most in k_icp_late / k_accumulate_matches<.., true> (launch_iteration checks; m3d_acc_blocks sizes the grid for it)
 #define M3D_LATE_CAP (M3D_LATE_QPT * 256)   // their worklist: every query a workgroup owns, if it must (k_icp_late: 7 x 256 x 20 B + the reductions' arrays = 39 KB of LDS)
 #define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread) when the batch has enough of them to fill the GPU; else 256 (M3dNnArgs::tile_chunk: 2 lanes per record; M3DREG_TILE_CHUNK forces 512 / 256 / 128)
@@ -613,11 +613,13 @@ __device__ __forceinline__ m3d_u32x2 m3d_tile_find(m3d_lu2 vs, uint32_t key) {
     while (s.x != key && s.x != M3D_INVALID_KEY) { h = (h + 1u) & (M3D_TILE_VS - 1u); s = vs[h]; }
     return s;
 }
-// one staged voxel {first LDS position | population << 16} against the query: lane `sub` of the `step` lanes that share the query
-// scans every step-th point of it
-__device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, const uint32_t sub, const uint32_t step) {
-    const uint32_t t = sv & 0xFFFFu, n = sv >> 16;
+// one staged voxel (directory value sv: first LDS position | population - 1 | staged bucket, m3d_device.h) against the query: lane `sub` of the
+// `step` lanes that share the query scans every step-th point of it; bsv = the directory value of the voxel the best candidate came from
+__device__ __forceinline__ void m3d_tile_voxel(m3d_lf4 sp, uint32_t sv, float ux, float uy, float uz, unsigned long long& bkey, int& best, uint32_t& sec, uint32_t& bsv, const uint32_t sub, const uint32_t step) {
+    const uint32_t t = M3D_TILE_SV_POS(sv), n = M3D_TILE_SV_CNT(sv);
+    const unsigned long long k0 = bkey;
     m3d_tile_scan(sp, t + sub, t + n, ux, uy, uz, bkey, best, sec, step);
+    bsv = (bkey != k0) ? sv : bsv;
 }
 // phase 1 of the search, voxel B of the compile-time visiting order at offset (DX, DY, DZ): one unconditional directory probe (no
 // branch: 26 of them are in flight together); the voxel enters the lane's work mask when it exists, is not provably farther than
@@ -663,20 +665,22 @@ __device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float
     Q.bound = dmax2 * 1.0001f;
     if (seeded) Q.bound = fminf(Q.bound, dseed * 1.0001f);   // the previous match lies within these 27 voxels: it bounds the search before the first probe
 }
-// one staged image: returns the LDS position of a NEW best candidate, or -1 when the best so far stands.
+// one staged image: returns the SORTED position (in the level's pts array) of a NEW best candidate, or -1 when the best so far stands — a staged bucket is
+// one contiguous run in LDS and in the sorted order, delta[bucket] = sorted position - LDS position of its points (k_tile_build).
 // step > 1: `step` consecutive lanes (a power of two, at most 8) answer ONE query together — a query in a crowded stretch compares
 // against a thousand and more candidates while the scans are still centimetres apart (no box is provably farther than a
 // neighbour that far away): every lane scans its share of each voxel, the group agrees on the bound after the home voxel and on
 // the result at the end (xor-shuffles). All lanes of a group enter with the same Q and leave with the same Q.
-__device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d_lf4 sp, const int* kdelta, float ux, float uy, float uz, M3dTileQ& Q,
+__device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d_lf4 sp, const int* kdelta, const int* delta, float ux, float uy, float uz, M3dTileQ& Q,
                                                const uint32_t sub = 0u, const uint32_t step = 1u) {
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     int best = -1;
+    uint32_t bsv = 0u;
     const unsigned long long bkey0 = Q.bkey;
     // home voxel: every lane, no divergence; leaves the bound that prunes most of the other 26
     if (Q.G[0][1] + Q.G[1][1] + Q.G[2][1] == 0.f) {
         const m3d_u32x2 s = m3d_tile_find(vs, Q.key0);
-        if (s.x == Q.key0) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
+        if (s.x == Q.key0) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, bsv, sub, step);
         Q.bound = fminf(Q.bound, m3d_key_d2(Q.bkey) * 1.0001f);
     }
     if (step > 1u) for (uint32_t o = 1u; o < step; o <<= 1) Q.bound = fminf(Q.bound, __shfl_xor(Q.bound, (int)o));
@@ -724,12 +728,13 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
 #ifdef M3D_EXP_NOSCAN2   // (timing experiment only — WRONG results: the surviving voxels are looked up but their points are not compared)
             if (s.x == key) Q.sec = min(Q.sec, s.y);
 #else
-            if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, sub, step);
+            if (s.x == key) m3d_tile_voxel(sp, s.y, ux, uy, uz, Q.bkey, best, Q.sec, bsv, sub, step);
 #endif
             if (!more) break;
             key = key_n; h = h_n; s = s_n;
         }
     }
+    if (best >= 0) best += delta[M3D_TILE_SV_BKT(bsv)];   // LDS position -> sorted position
     if (step > 1u) {
         // the group's result: the smallest key; every other lane's NEW key lost to it (the old best, where a lane kept it, was
         // already counted as a loser by the lane that beat it)
@@ -980,7 +985,7 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
 #endif
 // LEAN (k_nn_iter<true>, the tile iterations of a level whose target has tiles): classify + bin ONLY — every query that must search goes
 // to its tile's slab however few they are, and the rare one that cannot (a tile that could not be staged, a full slab, more than 64
-// tiles in one workgroup) goes to the pair's fallback list, which k_nn_fallback walks. Without the two walks compiled in the kernel
+// tiles in one workgroup) is left M3D_NN_PENDING for the reduction pass's workgroup that streams it. Without the two walks compiled in the kernel
 // needs 41 VGPRs instead of 124: 7 waves per SIMD instead of 4 — worth 4-6 % of the headline, where three chains compete for the
 // register file (alone it is only 2-5 us faster per launch).
 template <bool LEAN>
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             const uint32_t hflags = hw[2], hmeta0 = hw[3];
             const uint32_t cnt = s_tn[tid];
             uint32_t base = atomicAdd(&tcnt[t0], cnt);
-            if (hflags != 0u) base = 0xFFFFFFFFu;
+            if ((hflags & M3D_TILE_OVERSIZE) != 0u) base = 0xFFFFFFFFu;
             else {
                 // work items of k_nn_tiles: one per chunk of the tile's records (512, or 64 for a tile with crowded voxels, whose
                 // queries cost ten times as much: they are spread over more workgroups); the append that covers a chunk's first
@@ -1157,11 +1162,8 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
             A.recd[r] = dseed;
         } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab (rare)
-            if constexpr (LEAN) {   // ... k_nn_fallback walks it
-                const uint32_t fslot = atomicAdd(&tcnt[A.ntile_max], 1u);   // (the counter behind the tiles'; the list holds every query of the pair if it must)
-                const size_t r = (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP + fslot;
-                A.rec[r] = make_float4(ux, uy, uz, __uint_as_float((uint32_t)i | (cls == 1 ? 0x80000000u : 0u)));
-                A.recd[r] = dseed;
+            if constexpr (LEAN) {   // ... the reduction pass walks it (k_accumulate_matches<.., true>)
+                atomicAdd(&tcnt[A.ntile_max], 1u);   // (the counter behind the tiles': "this pair has pending queries" — every workgroup of the reduction pass reads it)
                 out[i] = M3D_NN_PENDING;
             } else {                // ... walked here, in global memory
                 long long code = 0; float sec = 0.f;
@@ -1262,61 +1264,6 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     }
 }
 
-// k_nn_fallback: the queries k_nn_iter<true> could not bin, walked in global memory. Normally there are none: every workgroup reads
-// one counter and leaves. A few (a flagged tile here and there) are walked 8 lanes per query by the pair's first workgroups; many (a
-// level whose buckets hold more points than a tile image — the coarse levels of a dense map) one query per lane, all workgroups.
-#define M3D_FALLBACK_COOP_MAX 4096   // entries up to which the cooperative walk is used
-__global__ __launch_bounds__(256) void k_nn_fallback(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
-    int pair, blk;
-    m3d_map_block(n_pairs, bpp, pair, blk, A.rot);
-    const unsigned int nf = (A.tcnt + (size_t)pair * A.cnt_stride)[A.ntile_max];
-    if (nf == 0u) return;
-    const bool coop = nf <= (unsigned int)M3D_FALLBACK_COOP_MAX;
-    if ((coop ? 32u : 256u) * (unsigned int)blk >= nf) return;   // (block-uniform)
-    const M3dJob& J = jobs[pair];
-    const M3dPairState* st = A.states + pair;
-    if (st->done || (!first_of_level && st->level_done)) return;
-    const M3dGrid g = J.tgt.g;
-    const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
-    const m3d_gf4 pts = m3d_as_global(J.tgt.pts), cbox = m3d_as_global(J.tgt.cbox);
-    const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
-    const float dmax2 = J.dmax2;
-    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
-    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
-    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
-    const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP);
-    const float* recd = A.recd + (size_t)pair * A.rec_stride + (size_t)A.ntile_max * M3D_TILE_QCAP;
-    if (coop) {
-        const int sub = (int)threadIdx.x & 7;
-        for (unsigned int base = (unsigned int)blk * 32u; base < nf; base += 32u * (unsigned int)bpp) {   // (uniform per workgroup: the shuffles inside need every lane)
-            const unsigned int w = base + (threadIdx.x >> 3);
-            const bool act = w < nf;
-            const float4 r4 = act ? m3d_ld(rec, (size_t)w) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const uint32_t e = __float_as_uint(r4.w);
-            long long code; float sec;
-            const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, act && (e >> 31) != 0u, r4.x, r4.y, r4.z, act ? recd[w] : 0.f, sub, code, sec, 0);
-            if (act && sub == 0) {
-                const int qi = (int)(e & 0x7FFFFFFFu);
-                out[qi] = m;
-                if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
-                if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
-            }
-        }
-    } else {
-        for (unsigned int w = (unsigned int)blk * 256u + threadIdx.x; w < nf; w += 256u * (unsigned int)bpp) {
-            const float4 r4 = m3d_ld(rec, (size_t)w);
-            const uint32_t e = __float_as_uint(r4.w);
-            long long code = 0; float sec = 0.f;
-            const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, r4.x, r4.y, r4.z, dmax2, (e >> 31) != 0u, recd[w], code, sec, 0);
-            const int qi = (int)(e & 0x7FFFFFFFu);
-            out[qi] = m;
-            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
-            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, sec };
-        }
-    }
-    if (blk == 0 && threadIdx.x == 0) atomicAdd(&A.states[pair].ctr[1], nf);
-}
-
 // k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
 // the voxel directory and the tile's own + neighbouring buckets' points (one coalesced index stream, one 16-B gather per staged
 // point, all independent) — and answers every query record of the tile against it, one record per thread; a tile with several
@@ -1330,6 +1277,7 @@ static_assert(M3D_TILE_GRID % M3D_TILE_LISTS == 0, "every list is served by the 
 __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* __restrict__ jobs, int first_of_level, M3dNnArgs A) {
     __shared__ m3d_f32x4 s_pts[M3D_TILE_PCAP];
     __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
+    __shared__ int s_delta[M3D_TILE_ECAP];   // sorted position - LDS position of the points of every staged bucket of the tile (one table for all of its images)
     __shared__ int s_kd[32];
     const unsigned int wl = blockIdx.x & (unsigned int)(M3D_TILE_LISTS - 1);   // this workgroup's list of work items
     const unsigned int n_items = min(A.wcount[32u * wl], (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counters)
@@ -1378,21 +1326,40 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         for (unsigned int j = 0; j < H.n_img; j++) {
             const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
             const uint8_t* img = J.tgt.timg + (size_t)image * M3D_TILE_IMG_BYTES;
-            {   // stage
+            {   // stage: the voxel list is hashed into the LDS directory here (the image stores the list, not 16 KB of mostly empty slots)
                 if (j != 0u) __syncthreads();   // everybody is done with the previous image
-                const uint32_t meta = j == 0u ? H.meta0 : (J.tgt.timeta[image].n_points | (J.tgt.timeta[image].n_voxels & 0x80000000u));
-                const unsigned int n_points = meta & 0x7FFFFFFFu;
-                const m3d_gu4 gs = m3d_as_global(reinterpret_cast<const uint4*>(img));
+                const M3dTileImgMeta IM = J.tgt.timeta[image];
+                const unsigned int n_points = IM.n_points, n_vox = IM.n_voxels & 0x7FFFFFFFu;
+                const M3D_GLOBAL m3d_u32x2* gl = (const M3D_GLOBAL m3d_u32x2*)(const void M3D_GLOBAL*)img;
                 const m3d_gf4 gp = m3d_as_global(reinterpret_cast<const float4*>(img + M3D_TILE_IMG_PTS));
-                static_assert(M3D_TILE_VS * 8 == 2 * 16 * M3D_TILE_THREADS && M3D_TILE_PCAP == 4 * M3D_TILE_THREADS, "staging: two directory loads and four point loads per thread");
-                const uint4 v0 = m3d_ld(gs, (size_t)tid), v1 = m3d_ld(gs, (size_t)(tid + M3D_TILE_THREADS));
+                static_assert(M3D_TILE_VCAP <= 3 * M3D_TILE_THREADS && M3D_TILE_PCAP == 4 * M3D_TILE_THREADS && M3D_TILE_VS == 4 * M3D_TILE_THREADS && M3D_TILE_ECAP <= M3D_TILE_THREADS,
+                              "staging: at most three list entries, four points, four directory slots and one bucket delta per thread");
+                m3d_u32x2 vl[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); vl[r] = k < n_vox ? gl[k] : (m3d_u32x2){ M3D_INVALID_KEY, 0u }; }
                 float4 pv[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); pv[r] = k < n_points ? m3d_ld(gp, (size_t)k) : make_float4(0.f, 0.f, 0.f, 0.f); }
-                s_vs[2 * tid] = (m3d_u32x2){ v0.x, v0.y }; s_vs[2 * tid + 1] = (m3d_u32x2){ v0.z, v0.w };
-                s_vs[2 * (tid + M3D_TILE_THREADS)] = (m3d_u32x2){ v1.x, v1.y }; s_vs[2 * (tid + M3D_TILE_THREADS) + 1] = (m3d_u32x2){ v1.z, v1.w };
+                int dl = 0;
+                if (j == 0u && (unsigned int)tid < (H.flags >> 16)) dl = reinterpret_cast<const int*>(J.tgt.timg + (size_t)blk * M3D_TILE_IMG_BYTES + M3D_TILE_IMG_DELTA)[tid];
+                {   // empty directory (while the loads above are in flight)
+                    typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));
+                    __attribute__((address_space(3))) u32x4_lds* d4 = (__attribute__((address_space(3))) u32x4_lds*)s_vs;
+                    const u32x4_lds e4 = { M3D_INVALID_KEY, 0u, M3D_INVALID_KEY, 0u };
+                    d4[2 * tid] = e4; d4[2 * tid + 1] = e4;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    if (vl[r].x == M3D_INVALID_KEY) continue;
+                    uint32_t h = (vl[r].x * 0x9E3779B1u) >> (32 - 11);
+                    // voxel keys are unique: a successful CAS owns the slot (at most VCAP of the VS slots are ever taken)
+                    while (atomicCAS(reinterpret_cast<uint32_t*>(&s_vs[h]), M3D_INVALID_KEY, vl[r].x) != M3D_INVALID_KEY) h = (h + 1u) & (M3D_TILE_VS - 1u);
+                    reinterpret_cast<uint32_t*>(&s_vs[h])[1] = vl[r].y;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const unsigned int k = (unsigned int)(M3D_TILE_THREADS * r + tid); if (k < n_points) s_pts[k] = (m3d_f32x4){ pv[r].x, pv[r].y, pv[r].z, pv[r].w }; }
+                if (j == 0u && (unsigned int)tid < (H.flags >> 16)) s_delta[tid] = dl;
                 __syncthreads();
                 n_staged += n_points;
                 M3D_TBT_STAGED();
@@ -1402,9 +1369,9 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
 #ifdef M3D_EXP_NOSEARCH   // (timing experiment only — WRONG results: the floor of an item — records, staging, result writes — without the search)
                 const int b = -1;
 #else
-                const int b = m3d_tile_search(g, vs, sp, s_kd, r4.x, r4.y, r4.z, Q, sub, lstride);
+                const int b = m3d_tile_search(g, vs, sp, s_kd, s_delta, r4.x, r4.y, r4.z, Q, sub, lstride);
 #endif
-                if (b >= 0) m = (int)reinterpret_cast<const uint32_t*>(img + M3D_TILE_IMG_GIDX)[b];   // LDS position -> sorted position
+                if (b >= 0) m = b;   // (a sorted position already)
             }
             M3D_TBT_SEARCHED();
         }
@@ -1639,11 +1606,12 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
 }
 
-// WALK: no k_nn_fallback launch ran before this one (it costs its 5.3 us in every tile iteration for a list that is empty on ordinary
-// clouds): a query k_nn_iter<lean> left M3D_NN_PENDING is walked HERE, by the workgroup that streams it (so nobody else ever reads
-// its match in this launch), 8 lanes per query like k_icp_late's worklist, its residual added on the spot. Unseeded: a seed only
-// bounds the walk, the match is the same. The host picks per registration (nn_work): a handle whose last registration sent many
-// queries this way launches k_nn_fallback again — 391 workgroups per pair walk a long list faster than the 64 of this pass.
+// WALK (the tile iterations of a lean registration): a query k_nn_iter<lean> left M3D_NN_PENDING is walked HERE, by the workgroup that streams it
+// (so nobody else ever reads its match in this launch), its residual then added by the streaming loop like everybody's. Unseeded: a seed only
+// bounds the walk, the match is the same. Normally there are none (one counter read per workgroup); a few are walked 8 lanes per query like
+// k_icp_late's worklist; a workgroup that finds MANY (a target whose buckets hold more points than a tile image: every query of the pair is
+// pending) walks them one query per lane, all 256 lanes busy. (Rounds 2-3 had a launch of their own for this, k_nn_fallback — 5.3 us in every tile
+// iteration for a list that is empty on ordinary clouds — and, in round 3, a per-handle memory of whether the last batch had needed it: both gone.)
 template <int METRIC, bool WALK>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK: 133 VGPRs = 3 waves per SIMD, the walk's; forced to 128 = 4 waves with 5 spilled registers: headline and serial steps -0.5 %)
                                                                     const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
@@ -1701,21 +1669,36 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
             M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
             M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
             M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
-            const int sub = (int)threadIdx.x & 7;
-            for (int base = 0; base < nW; base += ICP_THREADS / 8) {   // uniform trip count: the shuffles inside need every lane
-                const int w = base + ((int)threadIdx.x >> 3);
-                const bool act = w < nW;
-                const int qi = act ? s_pend[w] : 0;
-                const float4 ps = m3d_ld(src, qi);
-                const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
-                const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
-                const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
-                long long code; float sec;
-                const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, J.dmax2, act, false, vx, vy, vz, 0.f, sub, code, sec, 0);
-                if (act && sub == 0) {
-                    out[qi] = mq;   // (read back by this workgroup only, below, behind the barrier)
+            if (nW > 2 * ICP_THREADS) {   // (uniform) many: one query per lane
+                for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
+                    const int qi = s_pend[w];
+                    const float4 ps = m3d_ld(src, qi);
+                    const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
+                    const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
+                    const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
+                    long long code = 0; float sec = 0.f;
+                    const int mq = m3d_nn27_walk(g, tab, pts, cbox, bigcum, vx, vy, vz, J.dmax2, false, 0.f, code, sec, 0);
+                    out[qi] = mq;
                     if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
                     if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
+                }
+            } else {
+                const int sub = (int)threadIdx.x & 7;
+                for (int base = 0; base < nW; base += ICP_THREADS / 8) {   // uniform trip count: the shuffles inside need every lane
+                    const int w = base + ((int)threadIdx.x >> 3);
+                    const bool act = w < nW;
+                    const int qi = act ? s_pend[w] : 0;
+                    const float4 ps = m3d_ld(src, qi);
+                    const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
+                    const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
+                    const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
+                    long long code; float sec;
+                    const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, J.dmax2, act, false, vx, vy, vz, 0.f, sub, code, sec, 0);
+                    if (act && sub == 0) {
+                        out[qi] = mq;   // (read back by this workgroup only, below, behind the barrier)
+                        if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
+                        if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
+                    }
                 }
             }
             if (threadIdx.x == 0 && nW > 0) atomicAdd(&st->ctr[1], (unsigned int)nW);
@@ -1766,7 +1749,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
 // walked 8 lanes per query (m3d_coop_query, the same code as k_nn_iter's), their residuals added by the group's first lane. Integer
 // sums: any order, same bits. The last workgroup of the pair solves, as in k_accumulate_matches.
 // (Round 1 tried this shape against a per-lane walk and a 27 + 6 + 22 us chain and dropped it; with the cooperative walk sharing its
-// crowded rows and the chain at 21 + 18 us of bandwidth-bound launches it pays.)
+// crowded rows and the chain at 21 + 18 us of bandwidth-bound launches it pays. Round 3 shipped a second, small-footprint variant for launches
+// that share the GPU with other batches — 0.8 % of the headline on one box, profiles/r04_zoo_ab.txt — round 4 removed it.)
 #ifdef M3D_LATE_STAMPS   // diagnosis build: wall-clock stamps (100 MHz) at k_icp_late's phase boundaries, every workgroup of the LAST launch (scripts/late_stamps.py)
 __device__ unsigned long long g_late_stamp[4096][8];
 extern "C" hipError_t m3d_debug_read_late(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_late_stamp), sizeof(unsigned long long) * 4096 * 8); }
@@ -1774,15 +1758,7 @@ extern "C" hipError_t m3d_debug_read_late(unsigned long long* out) { return hipM
 #else
 #define LATE_STAMP(k) ((void)0)
 #endif
-// SMALL (the launch is NOT alone on the device: other batches of the process are in flight): the footprint a workgroup takes from its CU matters more than
-// its own speed. The LDS worklist holds M3D_LATE_CAPS = 512 entries instead of every query the workgroup owns (14 instead of 39 KB: room for k_nn_tiles'
-// 49 KB workgroups of the other chains beside it; a steady-state launch has one or two entries per workgroup, the first fused one ~60, at most 164 on the
-// bench batch) — what does not fit goes to the workgroup's stretch of the tile records' array in global memory, which no late iteration uses —, and the
-// streaming loop's sums are reduced to LDS BEFORE the walk, the walked queries' residuals added in a pass of their own and reduced again (the walk with the
-// running sums live was the kernel's register peak: 157 VGPRs; this way 130). Headline +0.5 ... 0.9 % same-box; forced to 128 VGPRs (a fourth wave per SIMD)
-// it spills 16 bytes per lane and loses 0.7 % instead: scratch is what costs. Alone, the extra reduction costs a serial step 1 %: the other variant.
-#define M3D_LATE_CAPS 512
-template <int METRIC, bool SMALL>
+template <int METRIC>
 __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, M3dNnArgs A, long long* __restrict__ partials,
                                                           unsigned int* __restrict__ tickets, unsigned int seq, unsigned long long* __restrict__ progress) {
     int pair, blk;
@@ -1814,13 +1790,10 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     M3D_ACC<NACC> acc;
     acc.clear();
     __shared__ int s_cnt;
-    constexpr int CAPS = SMALL ? M3D_LATE_CAPS : M3D_LATE_CAP;
+    constexpr int CAPS = M3D_LATE_CAP;
     __shared__ int s_list[CAPS];                 // query index | seeded << 31
     __shared__ float s_wu[3][CAPS];              // its transformed position
-    __shared__ float s_wd[CAPS];                 // squared distance to its seed; SMALL: afterwards the match found (bits)
-    // SMALL: entries CAPS ... M3D_LATE_CAP - 1, same layout ({u, bits(query | seeded)}, seed distance / match), in this workgroup's stretch of the record arrays
-    float4* ov = SMALL ? A.rec + (size_t)pair * A.rec_stride + (size_t)blk * (M3D_LATE_CAP - M3D_LATE_CAPS) : nullptr;
-    float* ovd = SMALL ? A.recd + (size_t)pair * A.rec_stride + (size_t)blk * (M3D_LATE_CAP - M3D_LATE_CAPS) : nullptr;
+    __shared__ float s_wd[CAPS];                 // squared distance to its seed
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     LATE_STAMP(1);
@@ -1859,7 +1832,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
                 const int w = atomicAdd(&s_cnt, 1);
                 const int e = i | (cls == 1 ? (int)0x80000000u : 0);
                 if (w < CAPS) { s_list[w] = e; s_wu[0][w] = ux; s_wu[1][w] = uy; s_wu[2][w] = uz; s_wd[w] = dseed; }
-                else if (SMALL && w < M3D_LATE_CAP) { ov[w - CAPS] = make_float4(ux, uy, uz, __int_as_float(e)); ovd[w - CAPS] = dseed; }
             }
         }
     }
@@ -1868,7 +1840,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     const int nW = min(s_cnt, M3D_LATE_CAP);   // (the cap cannot be exceeded: see launch_iteration)
     if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;
     long long* my_partial = partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE;
-    if constexpr (!SMALL) {
+    {
         const int sub = (int)threadIdx.x & 7;
         for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
             const int w = base + ((int)threadIdx.x >> 3);
@@ -1893,47 +1865,6 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
         }
         LATE_STAMP(3);
         block_reduce_to_global<NACC>(acc, st->sums, my_partial);
-    } else {   // (also when the worklist is empty — it rarely is —: a branch around this block, with a reduction of its own, cost 83 VGPRs, 211 instead of 128)
-        __shared__ long long s_first[32];
-        block_reduce_to_global<NACC>(acc, nullptr, nullptr, s_first);
-        __threadfence_block();   // (overflow entries: written to global memory by this workgroup, read by it below)
-        __syncthreads();
-        const int sub = (int)threadIdx.x & 7;
-        for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
-            const int w = base + ((int)threadIdx.x >> 3);
-            const bool act = w < nW;
-            int e = 0; float vx = 0.f, vy = 0.f, vz = 0.f, ds = 0.f;
-            if (act) {
-                if (w < CAPS) { e = s_list[w]; vx = s_wu[0][w]; vy = s_wu[1][w]; vz = s_wu[2][w]; ds = s_wd[w]; }
-                else { const float4 o = ov[w - CAPS]; e = __float_as_int(o.w); vx = o.x; vy = o.y; vz = o.z; ds = ovd[w - CAPS]; }
-            }
-            const int qi = e & 0x7FFFFFFF;
-            long long code; float sec;
-            const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, e < 0, vx, vy, vz, ds, sub, code, sec, 0);
-            if (act && sub == 0) {
-                out[qi] = mq;
-                if (w < CAPS) s_wd[w] = __int_as_float(mq); else ovd[w - CAPS] = __int_as_float(mq);   // (the seed distance has been used: the slot carries the result to the pass below)
-                if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
-                if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        M3D_ACC<NACC> acc2;
-        acc2.clear();
-        for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
-            int mq; float vx, vy, vz;
-            if (w < CAPS) { mq = __float_as_int(s_wd[w]); vx = s_wu[0][w]; vy = s_wu[1][w]; vz = s_wu[2][w]; }
-            else { const float4 o = ov[w - CAPS]; mq = __float_as_int(ovd[w - CAPS]); vx = o.x; vy = o.y; vz = o.z; }
-            if (mq < 0) continue;
-            const float4 qm = m3d_ld(pts, (size_t)mq);
-            const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
-            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            m3d_accumulate_match<METRIC, NACC>(acc2, vx, vy, vz, qm, d2, nm, cx, cy, cz, S);
-        }
-        LATE_STAMP(3);
-        block_reduce_to_global<NACC>(acc2, st->sums, my_partial, nullptr, s_first);
     }
     LATE_STAMP(4);
 #ifdef M3D_LATE_STAMPS
@@ -1981,42 +1912,27 @@ hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, cons
 // ---- launchers ---------------------------------------------------------------------------------------
 // blocks per ticket group of the reduction pass's "last block" detection: ~sqrt(blocks)
 __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g * g < bpp) g++; return g; }
-// Workgroups per pair of the reduction pass (k_accumulate_matches, k_icp_late). Its streaming loop's time is trips x loaded latency, so what matters is
-// how many threads share the batch's queries: enough workgroups to put 2 on every CU (512: 8 pairs x 64 — 49, from "8 queries per thread", put two on
-// 136 CUs and one on 120 and the launch took what two take), 3 when the batch has the GPU to itself (`alone`: no other batch of this process in flight on
-// the device — 768 = 8 x 96: serial steps +2 %; with other chains in flight the third workgroup's registers are worth more to them: headline -3.7 %) —
-// whatever the number of pairs: ONE 100 k-point pair used to get 49 workgroups for 256 CUs, with 256 a registration takes 0.86 instead of 1.01 ms.
-// Bounds: at most 7 queries per thread (M3D_LATE_QPT: k_icp_late's worklist; the amortisation of the 29-term block reduction has little left to give beyond),
-// at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
-int m3d_acc_blocks(int max_n_src, int n_pairs, bool alone) {
-    static const int qpt = [] { const char* v = getenv("M3DREG_ACC_QPT"); const int q = v ? atoi(v) : M3D_LATE_QPT; return (q >= 1 && q <= 64) ? q : M3D_LATE_QPT; }();
-    static const int fixed = [] { const char* v = getenv("M3DREG_ACC_BPP"); return v ? atoi(v) : 0; }();
-    const int fill = [] { const char* v = getenv("M3DREG_ACC_FILL"); return v ? atoi(v) : 1; }();   // 0: round 2's rule (A/B; read at every call: scripts/stress_parity.py switches it between handles)
+// Workgroups per pair of the reduction pass (k_accumulate_matches, k_icp_late): a function of the batch alone. Its streaming loop's time is trips x
+// loaded latency, so what matters is how many threads share the batch's queries: enough workgroups to put 2 on every CU (512: 8 pairs x 64 — 49,
+// from "8 queries per thread", put two on 136 CUs and one on 120 and the launch took what two take) whatever the number of pairs: ONE 100 k-point
+// pair used to get 49 workgroups for 256 CUs, with 256 a registration takes 0.86 instead of 1.01 ms. (Round 3 also took a third workgroup per CU when
+// no other batch of the process was in flight — a process-global counter for 1 % of a serial step, profiles/r04_zoo_ab.txt: gone.)
+// Bounds: at most 7 queries per thread (M3D_LATE_QPT: k_icp_late's worklist; the amortisation of the 29-term block reduction has little left to give
+// beyond), at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
+int m3d_acc_blocks(int max_n_src, int n_pairs) {
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
-    if (fixed > 0) return fixed > b_min ? fixed : b_min;
-    int b = (max_n_src + 256 * qpt - 1) / (256 * qpt);
+    int b = (max_n_src + 256 * M3D_LATE_QPT - 1) / (256 * M3D_LATE_QPT);
     if (b < 1) b = 1;
     if (b < b_min) b = b_min;
     if (n_pairs <= 0) return b;
-    if (fill) {
-        const int target = alone ? 768 : 512;
-        int hi = max_n_src / 384; if (hi < b) hi = b;
-        int t = (target + n_pairs - 1) / n_pairs;
-        if (t > hi) t = hi;
-        if (t > b) b = t;
-        return b;
-    }
-    if ((b * n_pairs) % 256 != 0) {
-        const int up = ((b * n_pairs + 255) / 256) * 256;   // the next whole round of the 256 CUs
-        if (up % n_pairs == 0) {
-            const int bu = up / n_pairs;
-            if ((long long)bu * 256 * 5 <= (long long)max_n_src) b = bu;   // (still >= 5 queries per thread)
-        }
-    }
+    int hi = max_n_src / 384; if (hi < b) hi = b;
+    int t = (512 + n_pairs - 1) / n_pairs;
+    if (t > hi) t = hi;
+    if (t > b) b = t;
     return b;
 }
-int m3d_ticket_words(int n_pairs, int max_n_src) {   // (sized for the larger of the two grids)
-    const int bpp = m3d_acc_blocks(max_n_src, n_pairs, true), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
+int m3d_ticket_words(int n_pairs, int max_n_src) {
+    const int bpp = m3d_acc_blocks(max_n_src, n_pairs), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
     return n_pairs * (ng + 1) * 32;
 }
 
@@ -2028,10 +1944,11 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
     M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max;
-    {   // a work item of k_nn_tiles is one workgroup's pass over <= tile_chunk records: ONE 100 k-point pair makes 196 items of 512 for 256 CUs that hold three workgroups each
-        const int forced = [] { const char* v = getenv("M3DREG_TILE_CHUNK"); const int c = v ? atoi(v) : 0; return (c == 512 || c == 256 || c == 128) ? c : 0; }();   // (read at every call, like M3DREG_ACC_FILL)
+    {   // a work item of k_nn_tiles is one workgroup's pass over <= tile_chunk records: ONE 100 k-point pair makes 196 items of 512 for 256 CUs that hold three
+        // workgroups each — a batch that makes fewer than 768 such items publishes items of 256 records, two lanes per record (config 3: 0.85 / 0.83 ms per
+        // registration with 512 / 256, profiles/r04_zoo_ab.txt; 128: 0.855 in round 3). A function of the batch alone.
         const long long items = (long long)n_pairs * ((max_n_src + M3D_TILE_CHUNK - 1) / M3D_TILE_CHUNK);
-        A.tile_chunk = forced ? forced : (items >= 768 ? M3D_TILE_CHUNK : M3D_TILE_CHUNK / 2);   // (config 3: 0.867 / 0.843 / 0.855 ms per registration with 512 / 256 / 128)
+        A.tile_chunk = items >= 768 ? M3D_TILE_CHUNK : M3D_TILE_CHUNK / 2;
     } A.rec = w.rec; A.recd = w.recd; A.rec_stride = w.rec_stride; A.tcnt = w.tcnt; A.cnt_stride = w.cnt_stride;
     A.witems = w.witems; A.wcount = w.wcount; A.wcap = w.wcap;
     if (k0) (void)hipEventRecord(k0, s);    // the correspondence step (bench.py roofline)
@@ -2040,34 +1957,24 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     const int late = first_of_level < 0;
     const bool fused_ok = first_of_level == -2;   // -2: a late iteration that may run as one launch
     if (late) first_of_level = 0;
-    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs, w.acc_alone != 0);
+    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs);
     // A late iteration nobody brackets runs as ONE launch (k_icp_late). With an event bracket around the correspondence step (bench.py
     // samples some iterations; its untimed roofline step brackets all of them) the same iteration runs as the two-launch chain — same
     // bits — because the bracket's two halves do not exist inside a fused launch.
     if (fused_ok && !k0 && !k1 && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * M3D_LATE_QPT >= (long long)max_n_src) {
-        const int late_small = w.late_small;   // (M3DREG_LATE_SMALL at m3dreg_create) -1: the small-footprint variant when other batches are in flight; 0 / 1: never / always
-        // (the small variant's overflow entries live in the tile records' array: there must be one, and a stretch of it for every workgroup)
-        const bool small_ok = w.rec != nullptr && (long long)bpp_a * (M3D_LATE_CAP - M3D_LATE_CAPS) <= (long long)w.rec_stride;
-        const bool small = small_ok && (late_small < 0 ? !w.acc_alone : late_small != 0);
-#define M3D_LATE_LAUNCH(MET, SM) hipLaunchKernelGGL((k_icp_late<MET, SM>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress)
-        if (metric == 1) { if (small) M3D_LATE_LAUNCH(1, true); else M3D_LATE_LAUNCH(1, false); }
-        else { if (small) M3D_LATE_LAUNCH(0, true); else M3D_LATE_LAUNCH(0, false); }
-#undef M3D_LATE_LAUNCH
+        if (metric == 1) hipLaunchKernelGGL((k_icp_late<1>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress);
+        else hipLaunchKernelGGL((k_icp_late<0>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, A, partials, w.tickets, seq, progress);
         M3D_DBG(s, "k_icp_late");
         return;
     }
-    // the queries k_nn_iter<lean> cannot bin (M3D_NN_PENDING): walked by the reduction pass itself, or — a handle whose last registration had many — by a launch of their own
-    const bool lean_iter = w.tiles && !late && w.lean;
-    const bool walk_in_acc = lean_iter && !w.fallback_launch && fuse_solve && partials && (long long)bpp_a * ICP_THREADS * M3D_LATE_QPT >= (long long)max_n_src;   // (the pair's last workgroup zeroes the pending count: m3d_pair_tail)
+    // the queries k_nn_iter<lean> cannot bin (M3D_NN_PENDING) are walked by the reduction pass itself (its <.., true> instantiation) — which therefore
+    // must be the solving kind (the pair's last workgroup zeroes the pending count: m3d_pair_tail): the sums-only launch of m3dreg_debug_accumulate runs
+    // the full k_nn_iter
+    const bool lean_iter = w.tiles && !late && w.lean && fuse_solve && partials;
+    const bool walk_in_acc = lean_iter;
     if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
-        if (!walk_in_acc) {
-            // (the full grid although the list is normally empty: an empty launch costs 5.2 us whatever its grid — 1, 8, 32 or 391 workgroups per pair,
-            //  measured — and a one-level registration on a coarse grid sends EVERY query here: with 8 workgroups per pair it took ten times as long)
-            hipLaunchKernelGGL(k_nn_fallback, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
-            M3D_DBG(s, "k_nn_fallback");
-        }
     } else {
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");

@@ -66,16 +66,15 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 // Morton order, i.e. one compact patch of the scanned surface. Its IMAGE, built once per target by the bucketing pipeline
 // (k_tile_build), is what a workgroup must hold in LDS to answer every query that has an occupied bucket of the tile among the
 // 2x2x2 buckets of its 27-voxel neighbourhood: the tile's own buckets plus every occupied bucket within one bucket of them.
-//   vslots[M3D_TILE_VS]    open-addressing directory of the staged VOXELS: {voxel key, first LDS position | population << 16}
-//                          (all-ones key = empty); voxel key = ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2): a neighbour's key is
-//                          the query voxel's key plus a constant
+//   vlist[n_voxels]        the staged VOXELS, a compact list {voxel key, value}: value = first LDS position (11 bits) | population - 1 (11 bits) << 11 |
+//                          staged-bucket number << 22; voxel key = ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2): a neighbour's key is the query voxel's
+//                          key plus a constant. k_nn_tiles hashes the list into an M3D_TILE_VS-slot open-addressing directory IN LDS while it stages
+//                          (round 4; rounds 2-3 stored the 16 KB hashed directory itself: a third of an image's bytes, most of them empty slots)
 //   pts[n_points]          the staged points themselves {x, y, z, bits(input index)}, in LDS order: staging an image is two coalesced
-//                          streams (directory, points) — no gather, no index indirection on the critical path
-//   gidx[n_points]         sorted position (in the level's pts array) of every staged point: read once per answered query
-// A staged set that exceeds one image's capacities (a crowded stretch: a surface a metre from the sensor) is cut, bucket by bucket,
-// into several images (the first is image t, the others come from a pool behind the tiles' own images); the workgroup then stages
-// them one after the other and carries every query's best-so-far across them. Only a single bucket beyond an image's capacity (or an
-// exhausted pool) flags the tile; its queries take the global walk instead.
+//                          streams (voxel list, points) — no gather, no index indirection on the critical path
+//   delta[n_buckets]       (the tile's FIRST image only, one table for all of its images) sorted position - LDS position of the points of staged bucket b:
+//                          a staged bucket is one contiguous run in both orders, so the winner's sorted position is its LDS position + delta[bucket of its
+//                          voxel] — 2 KB per tile instead of one 4-byte sorted position per staged point (8 KB per image, read by a random 4-byte load per answer)
 #define M3D_TILE_PTS 512
 #define M3D_TILE_ECAP 512       // staged buckets per tile at most
 #define M3D_TILE_VS 2048        // slots of the voxel directory
@@ -86,13 +85,17 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 #define M3D_OCC_BITS 23         // the occupancy bitmap covers grids of up to 2^23 bucket positions (1 MiB per level)
 #define M3D_TILE_MAXIMG 32
 #define M3D_TILE_LISTS 8      // work-item lists of k_nn_tiles (one counter per list, each on its own 128-B line; list l is served by the workgroups with blockIdx & 7 == l)
-struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; meta0 = staged points of image t | crowded << 31
-struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points (k_nn_tiles then builds chunk boxes)
+struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; flags = M3D_TILE_OVERSIZE | staged buckets << 16; meta0 = staged points of image t | crowded << 31
+struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points
 static_assert(sizeof(M3dTileHdr) == 16 && sizeof(M3dTileImgMeta) == 8, "tile image layout");
 __host__ __device__ inline int m3d_tile_pool(int n_tiles) { return n_tiles / 2 + 8; }   // extra images per level
-#define M3D_TILE_IMG_PTS (M3D_TILE_VS * 8)                               // byte offsets inside an image
-#define M3D_TILE_IMG_GIDX (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 16)
-#define M3D_TILE_IMG_BYTES (M3D_TILE_VS * 8 + M3D_TILE_PCAP * 16 + M3D_TILE_PCAP * 4)
+#define M3D_TILE_IMG_PTS (M3D_TILE_VCAP * 8)                               // byte offsets inside an image: the voxel list first
+#define M3D_TILE_IMG_DELTA (M3D_TILE_VCAP * 8 + M3D_TILE_PCAP * 16)
+#define M3D_TILE_IMG_BYTES (M3D_TILE_VCAP * 8 + M3D_TILE_PCAP * 16 + M3D_TILE_ECAP * 4)   // 44 KB (rounds 2-3: 56 KB)
+#define M3D_TILE_SV_POS(sv) ((sv) & 0x7FFu)                                // directory value: first LDS position ...
+#define M3D_TILE_SV_CNT(sv) ((((sv) >> 11) & 0x7FFu) + 1u)                 // ... population ...
+#define M3D_TILE_SV_BKT(sv) ((sv) >> 22)                                   // ... staged-bucket number
+static_assert(M3D_TILE_PCAP <= 2048 && M3D_TILE_ECAP <= 512, "directory value fields");
 __host__ __device__ inline int m3d_tiles_of(int n) { return (n + M3D_TILE_PTS - 1) / M3D_TILE_PTS; }
 
 struct M3dLevelDev {       // what the NN / ICP kernels need from a target level

@@ -127,8 +127,8 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
     float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
-    int lane_min;                // a 256-query block with >= lane_min queries to search bins them / walks one query per lane, else 8 lanes per query (M3DREG_LANE_MIN)
-    long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src, n_pairs, true)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
+    int lane_min;                // a 256-query block with >= lane_min queries to search bins them / walks one query per lane, else 8 lanes per query
+    long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src, n_pairs)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass
     M3dPairState* states;        // [n_pairs] the batch's pair states (== jobs[pair].st)
     unsigned int* tickets;       // [m3d_ticket_words(n_pairs, max_n_src)] arrival counters of the reduction pass (zero between launches)
     int stride;
@@ -136,12 +136,9 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     int rot;                     // XCD rotation of the block -> pair map: differs between handles, so concurrent batches do not stack their k-th pairs on one XCD
     int tiles;                   // 1 = dense blocks bin their searches by target tile and k_nn_tiles answers them from LDS (M3DREG_TILES)
     int coop_kernel;             // 1 = this level is a coarser level of a pyramid: k_nn_coop is launched behind k_nn_iter<false> and answers the pairs whose target level is crowded
-    int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only) + k_nn_fallback; needs every target of the batch to have tiles (M3DREG_LEAN)
-    int late_small;              // k_icp_late's variant: -1 = the small-footprint one when other batches are in flight (acc_alone == 0), 0 = never, 1 = always (M3DREG_LATE_SMALL)
-    int acc_alone;               // 1 = no other batch of this process was in flight on the device when this one was enqueued: the reduction pass takes the larger grid (m3d_acc_blocks)
-    int fallback_launch;         // 1 = k_nn_fallback is launched behind k_nn_iter<true>; 0 = the reduction pass walks what is left pending itself (M3DREG_FALLBACK)
+    int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only; the reduction pass walks what it cannot bin); needs every target of the batch to have tiles (M3DREG_LEAN)
     int ntile_max;               // tiles per pair the arrays below are laid out for
-    float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP + stride] query records
+    float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP] query records
     float* recd;                 // same layout: squared distance to the seed
     unsigned long long rec_stride;
     unsigned int* tcnt;          // [n_pairs][cnt_stride] records per tile; zero between iterations
@@ -157,7 +154,7 @@ hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_p
                                     const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0, hipEvent_t k1);
 hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels);
 int m3d_ticket_words(int n_pairs, int max_n_src);
-int m3d_acc_blocks(int max_n_src, int n_pairs, bool alone);   // workgroups per pair of the reduction pass (alone = true: the larger grid, which sizes M3dNnWork::partials)
+int m3d_acc_blocks(int max_n_src, int n_pairs);   // workgroups per pair of the reduction pass
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w);
 hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, int32_t* out_cnt);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,

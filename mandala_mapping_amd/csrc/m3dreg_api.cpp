@@ -115,12 +115,8 @@ struct m3dreg_handle {
     M3dPairState* h_states = nullptr;  // pinned
     double* h_trace = nullptr;         // pinned
     size_t pending_pairs = 0;
-    int fallback_mode = 0;         // M3DREG_FALLBACK at m3dreg_create: 0 auto, 1 launch, 2 fold
     bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
     uint32_t coop_seen = 0;
-    int late_small = -1;           // M3DREG_LATE_SMALL at m3dreg_create
-    bool batch_alone = true;       // the batch being enqueued found no other batch of this process in flight on the device (g_batches_in_flight)
-    bool fallback_hot = false;     // the last finished batch sent many queries past the tiles (more than 256 per pair and iteration): k_nn_fallback is launched again
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
@@ -132,9 +128,9 @@ struct m3dreg_handle {
     int certify = 1;
     int xcd_rot = 0;                   // this handle's rotation of the block -> XCD map (handles created one after the other get 0, 3, 6, 1, ...)
     int lane_min = 32;                 // blocks with >= this many queries to search: one query per lane (throughput) instead of 8 lanes per query (latency) — 32 = one cooperative pass at most (two passes of 15 us each were the tail of iterations 4-9)
-    float seed_reach = 0.99f;          // M3DREG_SEED_REACH (tuning aid; any value in (0, 0.99] gives identical results)
+    float seed_reach = 0.99f;          // seeds farther than this many voxel edges are not used (any value in (0, 0.99] gives identical results)
     int tiles = 1;                     // 1 = dense search blocks go through the LDS-staged target tiles (k_nn_tiles); 0 = every search walks global memory (M3DREG_TILES, A/B)
-    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs) + k_nn_fallback when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
+    int lean = 1;                      // tile iterations run k_nn_iter<true> (classify + bin only, 41 VGPRs; what it cannot bin is walked by the reduction pass) when every target of the batch has tiles and the registration has one level (M3DREG_LEAN)
     bool batch_all_tiles = false;
     int fuse_from = 8;                 // from this iteration of a level on (and never before tile_iters) search and reduction are ONE launch, k_icp_late (M3DREG_FUSE_FROM, 0 = never)
     int tile_iters = 8;                // ... during the first tile_iters iterations of a level (M3DREG_TILE_ITERS): later the few searches left are walked by k_nn_iter itself
@@ -216,8 +212,6 @@ int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
         return M3DREG_OK;
     }
     void* p = nullptr;
-    static const bool dbg_pool = getenv("M3DREG_DEBUG_POOL") != nullptr;
-    if (dbg_pool) fprintf(stderr, "[m3dreg] pool miss: hipMalloc(%zu) (%zu blocks cached)\n", bytes, h->pool.size());
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {   // make room: drop the cache and retry once
         hipStreamSynchronize(h->stream);
@@ -310,8 +304,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         // tiles only where they are used: a target's FINEST level. A pyramid's coarser levels hold too many points per bucket for an image (their tiles
         // ended up flagged, their searches in the global walk anyway) — not carving them saves 1.5 images of 56 KB per 512 points and a 1 MiB bitmap per
         // level (a 2 M-point map: 330 MB per level) and two thirds of k_tile_build's work on a pyramid.
-        static const bool tiles_all_levels = [] { const char* v = getenv("M3DREG_TILES_ALL_LEVELS"); return v && atoi(v); }();
-        if (!c->source_only && (l == P.n_levels - 1 || tiles_all_levels)) {
+        if (!c->source_only && l == P.n_levels - 1) {
             const size_t nt = size_t(m3d_tiles_of(int(n))), ni = nt + size_t(m3d_tile_pool(int(nt)));
             L.thdr = k.take<M3dTileHdr>(nt);
             L.timg = k.take<uint8_t>(ni * M3D_TILE_IMG_BYTES);
@@ -610,7 +603,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | (unused) | cache (int64) | certificate state (float4)
         h->match_cap = cap;
     }
-    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs), true)) * M3D_PARTIAL_STRIDE;
+    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs))) * M3D_PARTIAL_STRIDE;
     if (n_part > h->partials_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_partials) hipFree(h->d_partials);
@@ -631,7 +624,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     h->match_pairs = n_pairs;
     if (h->tiles) {   // workspace of the LDS-staged search: per pair, query records per tile + the global-walk list, and their counters
         const size_t ntile = size_t(m3d_tiles_of(max_n_tgt));
-        const size_t rec_stride = ntile * M3D_TILE_QCAP + stride;   // the tiles' slabs, then the fallback list (k_nn_fallback: it holds every query of the pair if it must)
+        const size_t rec_stride = ntile * M3D_TILE_QCAP;   // the tiles' slabs
         const size_t cnt_stride = (ntile + 1 + 31) & ~size_t(31);
         if (n_pairs * rec_stride > h->rec_cap) {
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -666,11 +659,6 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     return M3DREG_OK;
 }
 
-// batches enqueued and not yet waited for, per device, over all handles of the process: a batch that finds none has the GPU to itself as far as this
-// library can tell, and its reduction pass takes the larger grid (m3d_acc_blocks). A wrong guess costs a few per cent, never a bit.
-static std::atomic<int> g_batches_in_flight[64];
-static std::atomic<int>& batches_in_flight(const m3dreg_handle* h) { return g_batches_in_flight[(h->device >= 0 && h->device < 64) ? h->device : 0]; }
-
 M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     M3dNnWork w{};
     w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
@@ -682,21 +670,15 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     w.rot = h->xcd_rot;
     // (lean per LEVEL: only on the finest level of a registration — a pyramid's coarse levels put more points into a bucket than a tile image holds,
     // their queries would all take the fallback list: config 5 with lean on every level took 6.5 instead of 5.9 ms)
-    static const int lean_levels = [] { const char* v = getenv("M3DREG_LEAN_LEVELS"); return v ? atoi(v) : 0; }();   // 0: one-level registrations only (default), 1: also the finest level of a pyramid — measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would send every query to the fallback list
-    const bool lean_here = h->params.n_levels == 1 || (lean_levels && level == h->params.n_levels - 1);
+    // (one-level registrations only; on the finest level of a pyramid it was measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would leave every query pending)
+    const bool lean_here = h->params.n_levels == 1;
     w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
-    // M3DREG_FALLBACK: launch = k_nn_fallback behind every k_nn_iter<true> (round 2's schedule), fold = never, auto (default) = only while the handle's
-    // last finished batch left many queries to it (batch_wait). Same bits either way.
-    w.fallback_launch = (h->fallback_mode == 1 || (h->fallback_mode == 0 && h->fallback_hot)) ? 1 : 0;
-    w.acc_alone = h->batch_alone ? 1 : 0;
-    w.late_small = h->late_small;
-    // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels: 1 (default) = where the handle's last finished batch had a crowded target level (and on
-    // a handle's first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level —, 0 = never
-    // (crowded levels stay inside k_nn_iter<false>, eight passes per workgroup), 2 = always. A wrong guess costs time, never a bit: without the launch
-    // k_nn_iter<false> answers the crowded pairs itself.
-    static const int coop_kernel = [] { const char* v = getenv("M3DREG_COOP_KERNEL"); return v ? atoi(v) : 1; }();
+    // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels, where the handle's last finished batch had a crowded target level (and on a handle's
+    // first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level. The ONE piece of
+    // adaptive state the library keeps (per handle, include/m3dreg.h "Threading"): a wrong guess costs time, never a bit — without the launch
+    // k_nn_iter<false> answers the crowded pairs itself, in eight passes per workgroup.
     const bool coop_level = level >= 0 && level < h->params.n_levels - 1;
-    w.coop_kernel = (coop_level && (coop_kernel == 2 || (coop_kernel == 1 && (!h->coop_known || ((h->coop_seen >> level) & 1u))))) ? 1 : 0;
+    w.coop_kernel = (coop_level && (!h->coop_known || ((h->coop_seen >> level) & 1u))) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
@@ -875,14 +857,10 @@ int m3dreg_create(const m3dreg_params* params, int device, void* stream, m3dreg_
     m3dreg_handle* h = new m3dreg_handle();
     h->device = device;
     h->params = *params;
-    { static std::atomic<int> created{0}; h->xcd_rot = (3 * created.fetch_add(1)) & 7; if (const char* v = getenv("M3DREG_XCD_ROT")) h->xcd_rot = atoi(v) & 7; }
-    if (const char* v = getenv("M3DREG_LANE_MIN")) { int q = atoi(v); if (q >= 1 && q <= 257) h->lane_min = q; }
+    { static std::atomic<int> created{0}; h->xcd_rot = (3 * created.fetch_add(1)) & 7; }   // (a creation counter, read once: which XCD a handle's k-th pair lands on — placement, not behaviour)
     if (const char* v = getenv("M3DREG_CERTIFY")) h->certify = atoi(v) ? 1 : 0;
-    if (const char* v = getenv("M3DREG_SEED_REACH")) { float q = float(atof(v)); if (q > 0.f && q <= 0.99f) h->seed_reach = q; }
     if (const char* v = getenv("M3DREG_TILES")) h->tiles = atoi(v) ? 1 : 0;
     if (const char* v = getenv("M3DREG_LEAN")) h->lean = atoi(v) != 0;
-    if (const char* v = getenv("M3DREG_LATE_SMALL")) h->late_small = atoi(v) < 0 ? -1 : (atoi(v) != 0);
-    if (const char* v = getenv("M3DREG_FALLBACK")) h->fallback_mode = !strcmp(v, "launch") ? 1 : (!strcmp(v, "fold") ? 2 : 0);
     if (const char* v = getenv("M3DREG_FUSE_FROM")) { int q = atoi(v); if (q >= 0) h->fuse_from = q; }
     if (const char* v = getenv("M3DREG_TILE_ITERS")) { int q = atoi(v); if (q >= 1) h->tile_iters = q; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
@@ -1029,7 +1007,6 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     int max_n_src = 0, max_n_tgt = 0;
     if ((rc = build_jobs(h, pairs, n_pairs, max_n_src, max_n_tgt))) return rc;
     const m3dreg_params& P = h->params;
-    h->batch_alone = batches_in_flight(h).load(std::memory_order_relaxed) == 0;
     if ((rc = ensure_match(h, n_pairs, max_n_src, max_n_tgt))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
@@ -1077,7 +1054,6 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
     // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
-    batches_in_flight(h).fetch_add(1, std::memory_order_relaxed);
     return M3DREG_OK;
     });
 }
@@ -1093,9 +1069,6 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
         if (stats) stats_from_state(S, &stats[i]);
     }
     {
-        unsigned long long past = 0, its = 0;
-        for (size_t i = 0; i < h->pending_pairs; i++) { past += h->h_states[i].ctr[1]; its += (unsigned long long)std::max(h->h_states[i].iters, 1); }
-        h->fallback_hot = past > 256ull * its;
         uint32_t seen = 0;
         for (size_t i = 0; i < h->pending_pairs; i++) seen |= h->h_states[i].coop_levels;
         h->coop_seen = seen; h->coop_known = true;
@@ -1103,7 +1076,6 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
     h->pending_pairs = 0;
-    batches_in_flight(h).fetch_sub(1, std::memory_order_relaxed);
     return M3DREG_OK;
     });
 }
@@ -2083,7 +2055,7 @@ void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<
     // leave the handle idle and give everything back, whatever happened above (a throw in the middle left earlier devices
     // with a pending batch, leaked the shard's clouds and returned while copies could still read the caller's payloads)
     if (touched) {
-        if (h->pending_pairs) { hipStreamSynchronize(h->stream); if (h->ev_used) drain_events(h); h->pending_pairs = 0; batches_in_flight(h).fetch_sub(1, std::memory_order_relaxed); }
+        if (h->pending_pairs) { hipStreamSynchronize(h->stream); if (h->ev_used) drain_events(h); h->pending_pairs = 0; }
         else hipStreamSynchronize(h->stream);
     }
     for (m3dreg_cloud* c : clouds) if (c) free_cloud(h, c);

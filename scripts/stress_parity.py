@@ -22,10 +22,8 @@ for case in range(n_cases):
     p = abi.Params.make(leaf=(2 * leaf, leaf) if two else leaf, iterations=(5, 8) if two else int(rng.integers(6, 14)),
                         max_corr_dist=(4 * leaf, 2.5 * leaf) if two else float(rng.choice([2.5, 4.0])) * leaf, metric=metric,
                         normal_leaf=max(0.3, 2 * leaf), eps_rot=float(rng.choice([0.0, 1e-6])), eps_trans=float(rng.choice([0.0, 1e-6])))
-    # the schedules the library otherwise picks by itself, pinned at random per case: every combination must give the same bits
-    sched = {"M3DREG_LATE_SMALL": str(rng.choice(["-1", "0", "1"])), "M3DREG_FALLBACK": str(rng.choice(["auto", "launch", "fold"])),
-             "M3DREG_COOP_KERNEL": str(rng.choice(["0", "1", "2"])), "M3DREG_ACC_FILL": str(rng.choice(["0", "1"])),
-             "M3DREG_TILE_CHUNK": str(rng.choice(["0", "512", "256", "128"])), "M3DREG_FUSE_FROM": str(rng.choice(["8", "2", "5"]))}
+    # the schedule switches that are left, pinned at random per case: every combination must give the same bits
+    sched = {"M3DREG_LEAN": str(rng.choice(["0", "1"])), "M3DREG_TILES": str(rng.choice(["1", "1", "0"])), "M3DREG_FUSE_FROM": str(rng.choice(["8", "2", "5"]))}
     sched["M3DREG_TILE_ITERS"] = sched["M3DREG_FUSE_FROM"]
     os.environ.update(sched)
     R = binding.Registrar(p)

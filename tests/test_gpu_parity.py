@@ -602,17 +602,14 @@ def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
     _same_stats(st1, st2)
 
 
-@pytest.mark.parametrize("blob", [(30000, 0.12), (2600, 0.05)])   # more / fewer fallback queries than k_nn_fallback walks cooperatively (4096)
-@pytest.mark.parametrize("lean", ["0", "1", "launch"])
+@pytest.mark.parametrize("blob", [(30000, 0.12), (2600, 0.05)])   # many / few queries past the tiles: the reduction pass walks them one per lane / eight lanes per query
+@pytest.mark.parametrize("lean", ["0", "1"])
 def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkeypatch, lean, blob):
     """M3DREG_LEAN=1 (default): the tile iterations run k_nn_iter<true> (classify + bin only), and what it cannot bin is walked by the
-    reduction pass's workgroups (M3DREG_FALLBACK=auto on a handle that has not seen many such queries, or =fold) or by k_nn_fallback
-    (=launch, or auto after a batch with many: the SECOND batch below); 0: the full k_nn_iter, which walks what it does not bin. A crowded
-    pair (queries past the tiles) and an ordinary one in one batch, 14 iterations (tiles, then fused late iterations): same poses and
-    statistics, equal to the oracle's."""
-    monkeypatch.setenv("M3DREG_LEAN", "0" if lean == "0" else "1")
-    if lean == "launch":
-        monkeypatch.setenv("M3DREG_FALLBACK", "launch")
+    reduction pass's workgroups (k_accumulate_matches<.., true>: a workgroup with many pending queries one per lane, with few eight lanes per
+    query); 0: the full k_nn_iter, which walks what it does not bin. A crowded pair (queries past the tiles) and an ordinary one in one batch,
+    14 iterations (tiles, then fused late iterations), twice on one handle: same poses and statistics, equal to the oracle's."""
+    monkeypatch.setenv("M3DREG_LEAN", lean)
     def blob_cloud(seed):   # a cube so full that some 20 cm bucket holds more points than a tile image (2048): its tile is flagged
         rng = np.random.default_rng(seed)
         return np.concatenate([_crowded_cloud(seed), np.array([2.0, -1.0, 0.4]) + rng.uniform(0, blob[1], (blob[0], 3))]).astype(np.float32)
@@ -625,8 +622,8 @@ def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkey
     cs_c, ct_c, cs_o, ct_o = R.clouds([src_c, tgt_c, src_o, tgt_o], source_only=[True, False, True, False])
     T, st = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])
     tile_searches, walked = R.counters()
-    assert tile_searches > 0 and walked > 0   # (the flagged tile's queries were walked: by the reduction pass, by k_nn_fallback or by the full k_nn_iter)
-    T2, st2 = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])   # (auto: the handle has now seen how many queries go past the tiles)
+    assert tile_searches > 0 and walked > 0   # (the flagged tile's queries were walked: by the reduction pass or by the full k_nn_iter)
+    T2, st2 = R.align_batch([(cs_c, ct_c, None), (cs_o, ct_o, None)])   # (a handle's second batch is scheduled like its first)
     assert R.counters()[1] > 0
     for k, (s_, t_) in enumerate(((src_c, tgt_c), (src_o, tgt_o))):
         To, sto, _ = orc.align(p, orc.Cloud(p, s_, source_only=True, omp=True), orc.Cloud(p, t_, omp=True))
@@ -636,11 +633,9 @@ def test_lean_and_full_correspondence_kernels_are_bit_identical(reg, orc, monkey
 
 
 @pytest.mark.parametrize("fuse_from", ["1", "8"])
-def test_small_footprint_late_kernel_and_its_overflow_list(reg, orc, monkeypatch, fuse_from):
-    """k_icp_late<.., SMALL> — what a handle launches when other batches are in flight — forced (M3DREG_LATE_SMALL=1): its LDS worklist holds 512 entries, the
-    rest goes to the workgroup's stretch of the tile records' array. fuse_from 1: the fused launch runs from the second iteration on, when nearly every
-    query is uncertified, so every workgroup overflows; 8: the shipped boundary. Same poses, traces and statistics as the oracle, bit for bit."""
-    monkeypatch.setenv("M3DREG_LATE_SMALL", "1")
+def test_fused_launches_from_the_second_iteration_on(reg, orc, monkeypatch, fuse_from):
+    """k_icp_late with its LDS worklist full: fuse_from 1 — the fused launch runs from the second iteration on, when nearly every query is uncertified and
+    goes through the workgroup's worklist (up to 7 x 256 entries); 8: the shipped boundary. Same poses, traces and statistics as the oracle, bit for bit."""
     monkeypatch.setenv("M3DREG_TILE_ITERS", fuse_from)
     monkeypatch.setenv("M3DREG_FUSE_FROM", fuse_from)
     src, tgt, _ = synth.hdl32_pair(1500, 4100, 4101, dx=0.25, dy=-0.1, dyaw_deg=2.0)
