@@ -749,11 +749,38 @@ __device__ __forceinline__ int m3d_tile_search(const M3dGrid& g, m3d_lu2 vs, m3d
     return best;
 }
 
+// ---- the per-query record kept between the iterations of a level: 8 bytes {match, certificate word} (rounds 1-3: a 4-byte match and a 16-byte
+// state {u0.xyz, sec} in two arrays — 20 bytes read per query and iteration by the classifying kernels, two scattered sectors written per answered search).
+// certificate word = bits of `sec` (a non-negative float: 31 bits) >> 4, << 5 | iteration of the query's last real search & 31. Dropping the four low
+// mantissa bits rounds the lower bound DOWN: valid, 2^-19 weaker. Where the query was at that search, u0, is not stored: it is R0 p + t0 with the
+// float pose of that iteration, which the pair's pose RING keeps for 32 iterations (written by k_patch_jobs for the first iteration of a batch and by
+// the solve for every following one) — the same fma chain on the same floats: the same bits as the stored u0 of rounds 1-3. A record whose slot
+// is the running iteration's own is 32 iterations old (the slot has been overwritten): it certifies nothing and the query searches again.
+typedef int m3d_i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int m3d_cert_pack(float sec, int itq) { return (int)(((__float_as_uint(sec) >> 4) << 5) | (uint32_t)itq); }
+__device__ __forceinline__ int m3d_cert_pack_bits(uint32_t sec_bits, int itq) { return (int)(((sec_bits >> 4) << 5) | (uint32_t)itq); }
+// {u0.xyz, sec} of a record (ring: the pair's pose ring, LDS or global; p: the query's source point); a stale record gets sec = 0 (certifies nothing)
+template <typename RING>
+__device__ __forceinline__ m3d_f32x4 m3d_cert_state(int cert, int itq, RING ring, const float4& p) {
+    const int k0 = cert & 31;
+    const float* r = &ring[12 * k0];
+    const float x = fmaf(r[0], p.x, fmaf(r[1], p.y, fmaf(r[2], p.z, r[9])));
+    const float y = fmaf(r[3], p.x, fmaf(r[4], p.y, fmaf(r[5], p.z, r[10])));
+    const float z = fmaf(r[6], p.x, fmaf(r[7], p.y, fmaf(r[8], p.z, r[11])));
+    const float sec = (k0 == itq) ? 0.f : __uint_as_float(((uint32_t)cert >> 5) << 4);
+    return (m3d_f32x4){ x, y, z, sec };
+}
+#define M3D_RING_FLOATS (32 * 12)
+// the pair's pose ring into LDS (every thread calls it; the caller's next barrier publishes it)
+__device__ __forceinline__ void m3d_ring_to_lds(float* s_ring, const float* ring_global) {
+    if (threadIdx.x < M3D_RING_FLOATS / 4) reinterpret_cast<float4*>(s_ring)[threadIdx.x] = reinterpret_cast<const float4*>(ring_global)[threadIdx.x];
+}
+
 struct M3dNnArgs {
-    int* match; int match_stride;      // per pair: result of every query (see the encoding above)
+    int2* match; int match_stride;     // per pair: {match, certificate word} of every query (see the encoding above; m3d_cert_pack)
     long long* cache;                  // per pair: voxel code of the "-2" verdicts (same stride as match)
-    float4* state;                     // per pair: {u0.xyz, sec}: where the query was at its last real search and the squared
-                                       //           lower bound of every non-best candidate seen there (NN certificate)
+    const float* ring;                 // per pair [32][12]: the float poses {R row-major, t} of the last 32 iterations of the pair (slot = iteration & 31): where a
+                                       //           query WAS at its last real search is recomputed from the pose of that iteration (NN certificate)
     int certify;                       // 1 = use the NN certificates (default); 0 = always search (A/B, M3DREG_CERTIFY)
     float seed_reach;                  // seeds farther than this many voxel edges are not used (<= 0.99)
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
@@ -792,9 +819,9 @@ struct M3dNnArgs {
     const m3d_gf4 src = m3d_as_global(J.src);                                                               \
     const float dmax2 = J.dmax2;                                                                            \
     const int n = J.n_src;                                                                                  \
-    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);     \
-    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);      \
-    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+    const int itq = st->iters & 31;             /* this iteration's slot of the pose ring */                \
+    M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);     \
+    M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
 
 // k_nn_iter: the whole correspondence step of one iteration in ONE launch. A block owns 256 consecutive queries of a pair.
 //   1. classify (no search): a query whose previous match is still PROVABLY the exact argmin (NN certificate) is done, so is
@@ -811,15 +838,15 @@ struct M3dNnArgs {
 // 1 = needs a seeded search, 2 = needs a full search; dseed = squared distance to the previous match (cls 1, certified);
 // certified = the previous match stands (q1 = that point, for the caller's residual).
 // (s0 = state[i] and q1 = pts[mp] are passed in: callers that handle several queries per thread load them for all of them first)
-__device__ __forceinline__ int m3d_classify_loaded(const M3dGrid& g, M3D_GLOBAL int* out, const M3D_GLOBAL long long* cache, int i, int mp, float ux,
+__device__ __forceinline__ int m3d_classify_loaded(const M3dGrid& g, M3D_GLOBAL m3d_i32x2* out, const M3D_GLOBAL long long* cache, int i, int mp, float ux,
                                                    float uy, float uz, float dmax2, int certify, float seed_reach, const m3d_f32x4& s0,
                                                    const float4& q1, float& dseed, bool& certified, int sit) {
     certified = false;
-    if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i] = -1; return 0; }
+    if (!m3d_finite3(ux, uy, uz)) { if (mp != -1) out[i].x = -1; return 0; }
     const float f1x = m3d_cell_f(ux, g.mn[0], g.inv_leaf), f1y = m3d_cell_f(uy, g.mn[1], g.inv_leaf), f1z = m3d_cell_f(uz, g.mn[2], g.inv_leaf);
     const bool in_range = (f1x >= -1.0f && f1x <= (float)g.dims[0]) && (f1y >= -1.0f && f1y <= (float)g.dims[1]) &&
                           (f1z >= -1.0f && f1z <= (float)g.dims[2]);
-    if (!in_range) { if (mp != -1) out[i] = -1; return 0; }
+    if (!in_range) { if (mp != -1) out[i].x = -1; return 0; }
     if (mp == M3D_NN_NONE_CACHED) {
         const long long code = (long long)((int)f1x + 1) | ((long long)((int)f1y + 1) << 16) | ((long long)((int)f1z + 1) << 32);
         const int cls = (code == cache[i]) ? 0 : 2;
@@ -849,13 +876,14 @@ __device__ __forceinline__ int m3d_classify_loaded(const M3dGrid& g, M3D_GLOBAL 
     if (certified) M3D_STAT(sit, 1);
     return certified ? 0 : (seedable ? 1 : 2);
 }
-// one query per thread: load what the certificate needs, then classify
-__device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_GLOBAL int* out, const M3D_GLOBAL long long* cache,
-                                            const M3D_GLOBAL m3d_f32x4* state, int i, int mp, float ux, float uy, float uz, float dmax2,
+// one query per thread: e = its record {match, certificate word} (loaded by the caller beside the source point p), s_ring = the pair's pose ring in LDS
+__device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_GLOBAL m3d_i32x2* out, const M3D_GLOBAL long long* cache,
+                                            const float* s_ring, int itq, const float4& p, int i, const m3d_i32x2 e, float ux, float uy, float uz, float dmax2,
                                             int certify, float seed_reach, float& dseed, bool& certified, float4& q1, int sit) {
+    const int mp = e.x;
     m3d_f32x4 s0 = (m3d_f32x4){ 0.f, 0.f, 0.f, 0.f };
     q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mp >= 0) { s0 = state[i]; q1 = m3d_ld(pts, (size_t)mp); }
+    if (mp >= 0) { q1 = m3d_ld(pts, (size_t)mp); s0 = m3d_cert_state(e.y, itq, s_ring, p); }
     return m3d_classify_loaded(g, out, cache, i, mp, ux, uy, uz, dmax2, certify, seed_reach, s0, q1, dseed, certified, sit);
 }
 
@@ -1011,18 +1039,20 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     (void)sit;
     int cls = 0;   // 0 = done, 1 = seeded search, 2 = full search
     float ux = 0.f, uy = 0.f, uz = 0.f, dseed = 0.f;
-    int mp = -1;
+    __shared__ float s_ring[M3D_RING_FLOATS];   // the pair's pose ring (the certificates recompute where a query was at its last search)
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
+    if (i < n) { p = m3d_ld(src, i); if (!first_of_level) e = out[i]; }
+    if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform; the loads above are in flight across it)
     if (i < n) {
-        const float4 p = m3d_ld(src, i);
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
         if (first_of_level) {
-            if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i] = -1;
+            if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i].x = -1;
         } else {
-            mp = out[i];
             bool certified; float4 q1;
-            cls = m3d_classify(g, pts, out, cache, state, i, mp, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, sit);
+            cls = m3d_classify(g, pts, out, cache, s_ring, itq, p, i, e, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, sit);
         }
     }
     // how many queries of this block need a search?
@@ -1051,7 +1081,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         int tile = -2;   // -2 = nothing to file, -1 = global-walk list, >= 0 = tile
         if (cls != 0) {
             M3dQuery Q;
-            if (!m3d_query_setup(g, ux, uy, uz, Q)) out[i] = -1;
+            if (!m3d_query_setup(g, ux, uy, uz, Q)) out[i].x = -1;
             else {
                 // the 2x2x2 buckets of the (unrestricted) neighbourhood: ANY occupied one names a tile that stages them all; the home
                 // bucket is probed first (it is the occupied one for two queries in three), the others together, only when it is empty
@@ -1094,8 +1124,8 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     none = hkey == M3D_INVALID_KEY;
                 }
                 if (none) {   // no occupied bucket around the query: answered here (what the walk would find: nothing, not even a point)
-                    if (cls == 1) out[i] = -1;   // (cannot happen: a seed lies in one of these buckets)
-                    else { out[i] = M3D_NN_NONE_CACHED; cache[i] = m3d_voxel_code(Q); }
+                    if (cls == 1) out[i].x = -1;   // (cannot happen: a seed lies in one of these buckets)
+                    else { out[i].x = M3D_NN_NONE_CACHED; cache[i] = m3d_voxel_code(Q); }
                 } else {
                     uint32_t slot = m3d_hash_slot(hkey, g.hshift);
                     uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
@@ -1164,13 +1194,12 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         } else if (tile == -1) {   // a flagged tile (one bucket beyond an image) or a full slab (rare)
             if constexpr (LEAN) {   // ... the reduction pass walks it (k_accumulate_matches<.., true>)
                 atomicAdd(&tcnt[A.ntile_max], 1u);   // (the counter behind the tiles': "this pair has pending queries" — every workgroup of the reduction pass reads it)
-                out[i] = M3D_NN_PENDING;
+                out[i].x = M3D_NN_PENDING;
             } else {                // ... walked here, in global memory
                 long long code = 0; float sec = 0.f;
                 const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
-                out[i] = m;
+                out[i] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
                 if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-                if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
                 atomicAdd(&A.states[pair].ctr[1], 1u);
             }
         }
@@ -1183,9 +1212,8 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         if (cls != 0) {
             long long code = 0; float sec = 0.f;
             const int m = m3d_nn27_walk(g, tab, pts, cbox, bigcum, ux, uy, uz, dmax2, cls == 1, dseed, code, sec, sit);
-            out[i] = m;
+            out[i] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
             if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-            if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
         }
 #ifdef M3D_BLOCKTIME
         __syncthreads();
@@ -1212,9 +1240,8 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
         if (tid == 0) M3D_STAT(sit, 15);
         const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, (e & 256) != 0, vx, vy, vz, act ? s_wd[q] : 0.f, sub, code, sec, sit);
         if (act && sub == 0) {
-            out[qi] = m;
+            out[qi] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
-            if (m >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
         }
     }
 #ifdef M3D_BLOCKTIME
@@ -1242,25 +1269,27 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     const int i = blk * 32 + (tid >> 3);
     int cls = 0;
     float ux = 0.f, uy = 0.f, uz = 0.f, dseed = 0.f;
+    __shared__ float s_ring[M3D_RING_FLOATS];
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
+    if (i < n) { p = m3d_ld(src, i); if (!first_of_level) e = out[i]; }
+    if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform)
     if (i < n) {
-        const float4 p = m3d_ld(src, i);
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
         if (first_of_level) {
-            if (m3d_finite3(ux, uy, uz)) cls = 2; else if (sub == 0) out[i] = -1;
+            if (m3d_finite3(ux, uy, uz)) cls = 2; else if (sub == 0) out[i].x = -1;
         } else {
-            const int mp = out[i];
             bool certified; float4 q1;
-            cls = m3d_classify(g, pts, out, cache, state, i, mp, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, 0);   // (the eight lanes of a group store the same correction, if any)
+            cls = m3d_classify(g, pts, out, cache, s_ring, itq, p, i, e, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, 0);   // (the eight lanes of a group store the same correction, if any)
         }
     }
     long long code; float sec;
     const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, 0);
     if (cls != 0 && sub == 0) {
-        out[i] = m;
+        out[i] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
         if (m == M3D_NN_NONE_CACHED) cache[i] = code;
-        if (m >= 0) state[i] = (m3d_f32x4){ ux, uy, uz, sec };
     }
 }
 
@@ -1292,7 +1321,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const unsigned int chunk = item.y >> 20;
         const M3dJob& J = jobs[pair];
         const M3dPairState* st = A.states + pair;
-        (void)st;
+        const int itq = st->iters & 31;
         M3D_TBT_BEGIN();
         const M3dGrid g = J.tgt.g;
         const float dmax2 = J.dmax2;
@@ -1301,9 +1330,8 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const bool sparse = (H.meta0 >> 31) != 0u;   // a tile with crowded voxels: 64 records per item, eight lanes per record (m3d_tile_search)
         const unsigned int cs = sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)A.tile_chunk;
         const unsigned int lstride = M3D_TILE_THREADS / cs;
-        M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+        M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
         M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
-        M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
         if (!first_item) __syncthreads();   // everybody is done with the previous item's LDS
         if (tid < 27) {   // key offset of voxel b of the visiting order (m3d_tile_search): dx + dy * 2^sh1 + dz * 2^sh2
             const int ord[27] = { 13, 12, 14, 10, 16, 4, 22, 9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26 };   // index = (dx+1) + 3 (dy+1) + 9 (dz+1)
@@ -1380,9 +1408,8 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             const float d2 = m3d_key_d2(Q.bkey);
             // "nothing at all in the 27 voxels" may be cached only when every existing voxel was looked up and found empty
             if (!(m >= 0 && d2 <= dmax2)) m = (seeded || m >= 0 || Q.sec != M3D_INF_BITS) ? -1 : M3D_NN_NONE_CACHED;
-            out[qi] = m;
+            out[qi] = (m3d_i32x2){ m, m3d_cert_pack_bits(Q.sec, itq) };   // ONE 8-byte store per answer (rounds 2-3: a 4-byte match and a 16-byte state, two sectors)
             if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
-            if (m >= 0) state[qi] = (m3d_f32x4){ r4.x, r4.y, r4.z, __uint_as_float(Q.sec) };
         }
         const unsigned int n_done = min(cs, qn - min(qn, chunk * cs));
         if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
@@ -1506,6 +1533,10 @@ __device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_lev
         if (rc >= 0) { st->status = rc; done = 1; }
         else {
             for (int i = 0; i < 16; i++) st->T[i] = T[i];
+            if (J.ring) {   // the float pose the NEXT iteration will use (m3d_load_pose's rounding), for the certificates of the iterations after it
+                float* r = J.ring + 12 * ((it + 1) & 31);
+                for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) r[3 * rr + c] = (float)T[c * 4 + rr]; r[9 + rr] = (float)T[12 + rr]; }
+            }
             if (th2 < J.eps_rot2 && tr2 < J.eps_trans2) {
                 if (J.last_level) { st->status = 0; done = 1; }
                 else level_done = 1;
@@ -1615,7 +1646,6 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
 template <int METRIC, bool WALK>
 __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK: 133 VGPRs = 3 waves per SIMD, the walk's; forced to 128 = 4 waves with 5 spilled registers: headline and serial steps -0.5 %)
                                                                     const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level,
-                                                                    const int* __restrict__ match, int match_stride,
                                                                     long long* __restrict__ partials, unsigned int* __restrict__ tickets,
                                                                     M3dPairState* __restrict__ states, unsigned int seq, unsigned long long* __restrict__ progress, int fuse_solve, int rot,
                                                                     unsigned int* __restrict__ gw_cnt, int gw_stride, int gw_n, unsigned int* __restrict__ wcount, M3dNnArgs A) {
@@ -1643,7 +1673,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
     const int n = J.n_src;
-    const int* in = (WALK ? A.match : match) + (size_t)pair * match_stride;   // (WALK writes matches: not through the __restrict__ parameter)
+    const int2* in = A.match + (size_t)pair * A.match_stride;
     const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
     // NB queries per trip, every load of a stage issued before the first use: the pass is a chain of
     // dependent gathers (match -> point, normal), so its speed is the number of them in flight
@@ -1659,16 +1689,16 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
             if (threadIdx.x == 0) s_pn = 0;
             __syncthreads();
             for (int i = blk * ICP_THREADS + (int)threadIdx.x; i < n; i += stride)
-                if (in[i] == M3D_NN_PENDING) { const int w = atomicAdd(&s_pn, 1); if (w < M3D_LATE_CAP) s_pend[w] = i; }
+                if (in[i].x == M3D_NN_PENDING) { const int w = atomicAdd(&s_pn, 1); if (w < M3D_LATE_CAP) s_pend[w] = i; }
             __syncthreads();
             const int nW = min(s_pn, M3D_LATE_CAP);
             const M3dGrid g = L.g;
             const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(L.htab));
             const m3d_gf4 cbox = m3d_as_global(L.cbox);
             const m3d_gu32 bigcum = m3d_as_global(L.bigcum);
-            M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+            M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
             M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
-            M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+            const int itq = st->iters & 31;
             if (nW > 2 * ICP_THREADS) {   // (uniform) many: one query per lane
                 for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
                     const int qi = s_pend[w];
@@ -1678,9 +1708,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
                     const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
                     long long code = 0; float sec = 0.f;
                     const int mq = m3d_nn27_walk(g, tab, pts, cbox, bigcum, vx, vy, vz, J.dmax2, false, 0.f, code, sec, 0);
-                    out[qi] = mq;
+                    out[qi] = (m3d_i32x2){ mq, m3d_cert_pack(sec, itq) };
                     if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
-                    if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
                 }
             } else {
                 const int sub = (int)threadIdx.x & 7;
@@ -1695,9 +1724,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
                     long long code; float sec;
                     const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, J.dmax2, act, false, vx, vy, vz, 0.f, sub, code, sec, 0);
                     if (act && sub == 0) {
-                        out[qi] = mq;   // (read back by this workgroup only, below, behind the barrier)
+                        out[qi] = (m3d_i32x2){ mq, m3d_cert_pack(sec, itq) };   // (read back by this workgroup only, below, behind the barrier)
                         if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
-                        if (mq >= 0) state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
                     }
                 }
             }
@@ -1713,7 +1741,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
         int m[NB]; float4 p[NB], q[NB], nq[NB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i] : -1; }
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i].x : -1; }
 #pragma unroll
         for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
@@ -1781,9 +1809,11 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
     const float dmax2 = J.dmax2;
     const int n = J.n_src;
-    M3D_GLOBAL int* out = (M3D_GLOBAL int*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
+    const int itq = st->iters & 31;
+    M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
     M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
-    M3D_GLOBAL m3d_f32x4* state = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)(A.state + (size_t)pair * A.match_stride);
+    __shared__ float s_ring[M3D_RING_FLOATS];
+    m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS);   // (published by the barrier below)
     const float cx = g.center[0], cy = g.center[1], cz = g.center[2];
     const float S[6] = { J.S[0], J.S[1], J.S[2], J.S[3], J.S[4], J.S[5] };
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
@@ -1803,9 +1833,9 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     constexpr int NB = M3D_LATE_NB;
     const int stride = bpp * ICP_THREADS;
     for (int i0 = blk * ICP_THREADS + (int)threadIdx.x; i0 < n; i0 += NB * stride) {
-        int m[NB]; float4 p[NB], q[NB], nq[NB]; m3d_f32x4 s0[NB];
+        int m[NB], ce[NB]; float4 p[NB], q[NB], nq[NB]; m3d_f32x4 s0[NB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? out[i] : -1; }
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; const m3d_i32x2 e = (i < n) ? out[i] : (m3d_i32x2){ -1, 0 }; m[k] = e.x; ce[k] = e.y; }
 #pragma unroll
         for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
@@ -1814,8 +1844,9 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
             const size_t mm = (size_t)max(m[k], 0);
             s0[k] = (m3d_f32x4){ 0.f, 0.f, 0.f, 0.f }; q[k] = make_float4(0.f, 0.f, 0.f, 0.f); nq[k] = q[k];
             if (i < n && m[k] >= 0) {
-                s0[k] = state[i]; q[k] = m3d_ld(pts, mm);
+                q[k] = m3d_ld(pts, mm);
                 if (METRIC == 1) nq[k] = m3d_ld(nrm, mm);
+                s0[k] = m3d_cert_state(ce[k], itq, s_ring, p[k]);   // {u0, sec}: where the query was at its last search, from that iteration's pose
             }
         }
 #pragma unroll
@@ -1851,10 +1882,9 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
             long long code; float sec;
             const int mq = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, act, e < 0, vx, vy, vz, act ? s_wd[w] : 0.f, sub, code, sec, 0);
             if (act && sub == 0) {
-                out[qi] = mq;
+                out[qi] = (m3d_i32x2){ mq, m3d_cert_pack(sec, itq) };
                 if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
                 if (mq >= 0) {
-                    state[qi] = (m3d_f32x4){ vx, vy, vz, sec };
                     const float4 qm = m3d_ld(pts, (size_t)mq);
                     const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
@@ -1942,7 +1972,7 @@ int m3d_ticket_words(int n_pairs, int max_n_src) {
 static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, const M3dNnWork& w,
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
-    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.state = w.state; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
+    M3dNnArgs A; A.match = w.match; A.match_stride = w.stride; A.cache = w.cache; A.ring = w.ring; A.certify = w.certify; A.seed_reach = w.seed_reach; A.coop_kernel = w.coop_kernel; A.lane_min = w.lane_min; A.states = w.states; A.rot = w.rot;
     A.tiles = w.tiles && first_of_level >= 0; A.ntile_max = w.ntile_max;
     {   // a work item of k_nn_tiles is one workgroup's pass over <= tile_chunk records: ONE 100 k-point pair makes 196 items of 512 for 256 CUs that hold three
         // workgroups each — a batch that makes fewer than 768 such items publishes items of 256 records, two lanes per record (config 3: 0.85 / 0.83 ms per
@@ -1990,7 +2020,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     }
     if (k1) (void)hipEventRecord(k1, s);
     unsigned int* gw = w.tiles ? w.tcnt : nullptr;   // the tiles' record counters and the work-item counter: zeroed here, behind their readers
-#define M3D_ACC_LAUNCH(MET, WK) hipLaunchKernelGGL((k_accumulate_matches<MET, WK>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, w.match, w.stride, partials, \
+#define M3D_ACC_LAUNCH(MET, WK) hipLaunchKernelGGL((k_accumulate_matches<MET, WK>), dim3(bpp_a * n_pairs), dim3(ICP_THREADS), 0, s, d_jobs, n_pairs, bpp_a, first_of_level, partials, \
                                                    w.tickets, w.states, seq, progress, fuse_solve, w.rot, gw, w.cnt_stride, w.ntile_max + (WK ? 0 : 1), w.wcount, A)
     if (metric == 1) { if (walk_in_acc) M3D_ACC_LAUNCH(1, true); else M3D_ACC_LAUNCH(1, false); }
     else { if (walk_in_acc) M3D_ACC_LAUNCH(0, true); else M3D_ACC_LAUNCH(0, false); }
@@ -2019,6 +2049,10 @@ __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pai
     int32_t e[6]; float S[6];
     m3d_fixed_exps(M->lbound, J.dmax, e, S);
     for (int k = 0; k < 6; k++) { J.exps[k] = e[k]; J.S[k] = S[k]; }
+    if (t < n_pairs && J.ring) {   // slot 0 of the pose ring: the pose the batch starts from (iters = 0)
+        const double* T = J.st->T;
+        for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) J.ring[3 * rr + c] = (float)T[c * 4 + rr]; J.ring[9 + rr] = (float)T[12 + rr]; }
+    }
     if (t < n_pairs && (M->err || MS->err)) {   // a cloud that could not be bucketed: the registration ends before it starts
         J.st->status = M3D_STATUS_BAD_CLOUD;
         J.st->done = 1;

@@ -123,9 +123,9 @@ hipError_t m3d_launch_map_insert(hipStream_t s, const M3dMapArgs& A);
 // icp.hip: one Gauss-Newton iteration = k_nn_iter (classify + search / bin), k_nn_tiles (binned searches from LDS), k_accumulate_matches
 // (residuals + reduction; its last block per pair also solves and updates the pose)
 struct M3dNnWork {               // workspace of the batch, all per pair with the same stride (a whole number of 256-query blocks)
-    int* match;                  // [n_pairs * stride] result of every query, kept between iterations (certified / seeds the next search)
+    int2* match;                 // [n_pairs * stride] {match, certificate word} of every query, kept between iterations (certified / seeds the next search)
     long long* cache;            // [n_pairs * stride] voxel of each cached "no point in the neighbourhood" verdict
-    float4* state;               // [n_pairs * stride] NN certificate state {u0.xyz, sec}
+    const float* ring;           // [n_pairs][32][12] pose rings (== jobs[pair].ring)
     int certify;                 // A/B switch of the certificates (M3DREG_CERTIFY)
     int lane_min;                // a 256-query block with >= lane_min queries to search bins them / walks one query per lane, else 8 lanes per query
     long long* partials;         // [n_pairs][m3d_acc_blocks(max_n_src, n_pairs)][M3D_PARTIAL_STRIDE] block partial sums of the reduction pass

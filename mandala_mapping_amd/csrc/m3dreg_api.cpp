@@ -110,6 +110,7 @@ struct m3dreg_handle {
     size_t cap_pairs = 0;
     M3dJob* d_jobs = nullptr;          // [levels][cap_pairs]
     M3dPairState* d_states = nullptr;  // [cap_pairs]
+    float* d_ring = nullptr;           // [cap_pairs][32][12] pose rings of the pairs (the NN certificates' "where was the query at its last search")
     double* d_trace = nullptr;         // [M3D_MAX_TRACE][16], first pair only
     M3dJob* h_jobs = nullptr;          // pinned
     M3dPairState* h_states = nullptr;  // pinned
@@ -563,12 +564,14 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->d_jobs) hipFree(h->d_jobs);       // jobs and states share one block on either side (one copy moves both)
     if (h->h_jobs) hipHostFree(h->h_jobs);
-    h->d_jobs = nullptr; h->d_states = nullptr; h->h_jobs = nullptr; h->h_states = nullptr; h->cap_pairs = 0;
+    if (h->d_ring) hipFree(h->d_ring);
+    h->d_jobs = nullptr; h->d_states = nullptr; h->h_jobs = nullptr; h->h_states = nullptr; h->d_ring = nullptr; h->cap_pairs = 0;
     size_t cap = n_pairs < 8 ? 8 : n_pairs;
     static_assert(sizeof(M3dJob) % 8 == 0, "the pair states follow the jobs in one block");
     const size_t block = sizeof(M3dJob) * cap * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * cap;
     HIPCHK(h, hipMalloc((void**)&h->d_jobs, block));
     HIPCHK(h, hipHostMalloc((void**)&h->h_jobs, block, hipHostMallocDefault));
+    HIPCHK(h, hipMalloc((void**)&h->d_ring, sizeof(float) * 32 * 12 * cap));
     h->d_states = reinterpret_cast<M3dPairState*>(h->d_jobs + cap * M3DREG_MAX_LEVELS);
     h->h_states = reinterpret_cast<M3dPairState*>(h->h_jobs + cap * M3DREG_MAX_LEVELS);
     if (!h->d_trace) {
@@ -600,7 +603,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         if (h->d_match) hipFree(h->d_match);
         h->d_match = nullptr; h->match_cap = 0;
         const size_t cap = n_pairs * stride + n_pairs * stride / 4;
-        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 8 * cap));   // match | (unused) | cache (int64) | certificate state (float4)
+        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // {match, certificate word} (8 B) | cache (int64)
         h->match_cap = cap;
     }
     const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs))) * M3D_PARTIAL_STRIDE;
@@ -661,9 +664,8 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
 
 M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     M3dNnWork w{};
-    w.match = h->d_match; w.stride = h->match_stride; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
+    w.match = reinterpret_cast<int2*>(h->d_match); w.stride = h->match_stride; w.ring = h->d_ring; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
-    w.state = reinterpret_cast<float4*>(h->d_match + 4 * h->match_cap);
     w.certify = h->certify;
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
@@ -729,6 +731,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
             J.eps_trans2 = P.eps_trans * P.eps_trans;
             J.pivot_rel_tol = P.pivot_rel_tol;
             J.st = h->d_states + i;
+            J.ring = h->d_ring + size_t(i) * 32 * 12;
             J.trace = (i == 0) ? h->d_trace : nullptr;
         }
         M3dPairState& S = h->h_states[i];
@@ -798,7 +801,7 @@ void release_handle(m3dreg_handle* h) {
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
-    for (void* p : { (void*)h->d_jobs, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt, (void*)h->d_witems }) if (p) hipFree(p);   // (the states live in the jobs' block)
+    for (void* p : { (void*)h->d_jobs, (void*)h->d_ring, (void*)h->d_trace, (void*)h->d_match, (void*)h->d_partials, (void*)h->d_tickets, (void*)h->d_rec, (void*)h->d_tcnt, (void*)h->d_witems }) if (p) hipFree(p);   // (the states live in the jobs' block)
     for (void* p : { (void*)h->h_jobs, (void*)h->h_trace, (void*)h->h_progress }) if (p) hipHostFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->staged) hipEventDestroy(h->staged);
