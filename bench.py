@@ -263,9 +263,14 @@ def main():
             t_ = json.load(open(tab))
             if t_.get("azimuth") == args.azimuth and len(t_["costs"]) >= world * B:
                 costs = t_["costs"][: world * B]
-        if costs is None:
+        if costs is None:   # any other workload: the cost estimate comes from the DEVICE (m3dreg_cloud_density: the bucketing pipeline's own sum of squared
+            # voxel populations) — every rank buckets all world * B pairs once, untimed, and reads the same numbers
             generated = {k: gen_pair(k) for k in range(world * B)}
-            costs = [synth.crowdedness(generated[k][0]) + synth.crowdedness(generated[k][1]) for k in range(world * B)]
+            costs = []
+            for k in range(world * B):
+                cs_, ct_ = reg.clouds([generated[k][0], generated[k][1]], source_only=[True, False])
+                costs.append(cs_.density() + ct_.density())
+                cs_.free(); ct_.free()
         pair_ids = sharding.lpt_assign(costs, world, capacity=B)[rank]
         generated = {k: generated[k] for k in pair_ids if k in generated}
     else:
@@ -380,7 +385,7 @@ def main():
     # The block of exactly K timed steps (barrier + synchronize on both sides) is repeated until the blocks add up to --min-seconds: 20 steps
     # are 23 ms, too short for anything outside this process (the driver's smi sampler) to see a busy GPU, and one block's value moves by a
     # few per cent with whatever else the box does in those milliseconds. Reported: the MEDIAN block (steps = K as asked).
-    blocks = []
+    blocks, blocks_local = [], []
     for r in regs:
         r.profile_read(4, reset=True)
     while True:
@@ -388,6 +393,8 @@ def main():
         host_log.clear()
         t0 = time.perf_counter()
         run_steps(K)
+        torch.cuda.synchronize()
+        blocks_local.append(time.perf_counter() - t0)   # this rank's OWN work: until its K steps are done, before it waits for the others in the closing barrier
         barrier()
         t1 = time.perf_counter()
         bt = t1 - t0
@@ -458,6 +465,13 @@ def main():
         del c_
         last["T"], last["st"] = last_T, last_st
     elapsed = sorted(blocks)[len(blocks) // 2]   # the median block (already the max over ranks)
+    per_rank = None
+    if world > 1:   # every rank's own block times beside the max-over-ranks figure: the loss to the slowest shard is visible in the line itself
+        mine = {"rank": rank, "pairs": [int(x) for x in pair_ids], "own_work_ms_median": 1e3 * sorted(blocks_local)[len(blocks_local) // 2],
+                "own_work_ms_min": 1e3 * min(blocks_local), "own_work_ms_max": 1e3 * max(blocks_local)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     # sanity of the timed work: poses against the generator's ground truth
     errs = [synth.pose_error(last["T"][i], gts[i]) for i in range(B)]
@@ -535,6 +549,10 @@ def main():
                          # kept for continuity with rounds 1-2 (same numbers as roofline.frac / roofline.alone):
                          "in_region": {"concurrent_chains": D, "avg_launch_ms": 1e3 * avg_launch_s, "achieved": in_region, "frac": in_region / HBM_PEAK_GBS, "launches_timed": launches}},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["per_rank_note"] = ("own_work_ms = a rank's K timed steps until ITS results are in (before the closing barrier); value divides by the block time = the "
+                                    "max over ranks, so (max - mean) / max of own_work_ms_median is the throughput lost to the slowest shard")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, host_pairs, args.iters, args.cpu_threads)
         if args.from_host:

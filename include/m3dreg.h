@@ -35,13 +35,15 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 4   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+#define M3DREG_ABI_VERSION 5   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
                                      M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
                                   3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
                                      exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
                                      m3dreg_debug_accumulate / _trace refuse to run while a batch is pending
                                   4: + m3dreg_host_alloc / _free / _register / _unregister (pinned payloads); m3dreg_multi_align runs one host thread
-                                     per device; m3dreg_default_params is a coarse-to-fine pyramid (see there) */
+                                     per device; m3dreg_default_params is a coarse-to-fine pyramid (see there)
+                                  5: + m3dreg_pair_desc.target_group (shared targets are co-located and bucketed once), m3dagg_set_scan_trig,
+                                     m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -210,18 +212,26 @@ void* m3dreg_get_stream(m3dreg_handle* h);
  * The consumer of this library is ONE process (m3d_husky_bringup.launch:13 starts one gpu_6dslam_node): a loop-closure batch is
  * spread over the devices it names, without torchrun and without a collective — the pairs are independent. m3dreg_multi_align
  * takes the raw payloads (a cloud lives on ONE device, so the sharding must come before the upload), assigns the pairs to the
- * devices longest-processing-time-first by their point counts (n_source + n_target, at most ceil(n_pairs / n_devices) pairs per
- * device), uploads and buckets every shard on its own device and stream (sources source-only), enqueues all registrations, and
+ * devices longest-processing-time-first by their point counts (n_source + n_target — a shared target (target_group) counted once, its
+ * pairs kept together —, at most ceil(n_pairs / n_devices) pairs per device where the groups allow it), uploads and buckets every shard on its own device and stream (sources source-only), enqueues all registrations, and
  * only then waits: the devices run concurrently, the results are gathered into the caller's arrays in PAIR order (a few hundred
  * bytes per pair over PCIe: no RCCL inside one process). `devices` may name a device more than once (several streams on it).
  * Results are bit-identical to m3dreg_align_batch on any one of the devices. */
 typedef struct m3dreg_multi m3dreg_multi;
-typedef struct m3dreg_pair_desc { m3dreg_cloud_desc source, target; float init_T[16]; } m3dreg_pair_desc;   /* source.source_only is implied */
+typedef struct m3dreg_pair_desc {
+    m3dreg_cloud_desc source, target;   /* source.source_only is implied */
+    float init_T[16];
+    int32_t target_group;               /* (ABI 5) 0 = this pair's target is its own; > 0: every pair of the call with this id registers against the SAME
+                                           reference cloud (identical target descriptors: loop-closure candidates against one submap): the
+                                           group is kept on one device and its target is uploaded and bucketed ONCE there */
+    int32_t reserved;
+} m3dreg_pair_desc;
 int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_devices, m3dreg_multi** out);
 int m3dreg_multi_destroy(m3dreg_multi* m);
 int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_pairs, float* out_T /* 16 * n_pairs */,
                        m3dreg_stats* stats /* n_pairs, may be NULL */, int32_t* device_of_pair /* n_pairs, may be NULL: where each pair ran */);
 const char* m3dreg_multi_last_error(const m3dreg_multi* m);
+int m3dreg_debug_multi_clouds(const m3dreg_multi* m);   /* tests: clouds uploaded + bucketed by the last m3dreg_multi_align (a target group's target counts once) */
 /* (ABI 4) Inside, every listed device has its own host thread, which uploads, buckets, registers and collects its shard, so the
  * devices' uploads and enqueues run side by side (one host thread + one HIP stream per device). The call itself is
  * synchronous and may be made from any ONE thread at a time per context. Host payloads cross PCIe from pinned memory: a payload
@@ -355,6 +365,11 @@ int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m
  *   sorted_keys[n], perm[n]   stable sort by key; perm[j] = input index of the j-th sorted point
  *   sorted_xyz[3n]            x,y,z of sorted points (interleaved)
  *   normals[3n]               unit normal per sorted point, (0,0,0) = invalid; only if has_normals */
+/* (ABI 5) mean population of the voxel a point of the cloud lies in, at `level` (sum over the occupied voxels of population^2 / finite points; derived by
+ * the bucketing pipeline on the device): what a query meets in its home voxel. Registration time on an MI355X follows it (0.72 ... 1.40 ms over the 64 pairs
+ * of BASELINE config 4, correlation 0.9): cost(pair) = density(source) + density(target) is the a-priori estimate a caller shards a batch by
+ * (mandala_mapping_amd/sharding.py lpt_assign; bench.py --gpus N). Waits for the cloud's bucketing. */
+int m3dreg_cloud_density(m3dreg_handle* h, const m3dreg_cloud* c, int level, double* out);
 int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint32_t* keys,
                         uint32_t* sorted_keys, int32_t* perm, float* sorted_xyz, float* normals);
 /* NN of arbitrary queries (already in the target frame; host float xyz interleaved) against one

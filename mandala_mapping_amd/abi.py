@@ -5,7 +5,7 @@ HIP library and to the CPU oracle in the parity tests.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LEVELS = 4
 NSUMS = 29
 
@@ -130,7 +130,7 @@ class Pair(C.Structure):
 
 
 class PairDesc(C.Structure):   # m3dreg_pair_desc (m3dreg_multi_align)
-    _fields_ = [("source", CloudDesc), ("target", CloudDesc), ("init_T", C.c_float * 16)]
+    _fields_ = [("source", CloudDesc), ("target", CloudDesc), ("init_T", C.c_float * 16), ("target_group", C.c_int32), ("reserved", C.c_int32)]
 
 
 class M3dregError(RuntimeError):

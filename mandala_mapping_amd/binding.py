@@ -28,12 +28,12 @@ EXPORTS = [
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
-    "m3dreg_cloud_create_pc2",
+    "m3dreg_cloud_create_pc2", "m3dreg_cloud_density",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_set_scan_trig", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
-    "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error",
+    "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error", "m3dreg_debug_multi_clouds",
     "m3dreg_debug_fail_alloc", "m3dreg_debug_throw",
     "m3dreg_debug_candidates", "m3dreg_host_alloc", "m3dreg_host_free", "m3dreg_host_register", "m3dreg_host_unregister",
 ]
@@ -83,6 +83,7 @@ def lib():
     L.m3dreg_host_unregister.argtypes = [vp]
     L.m3dreg_get_stream.restype = vp
     L.m3dreg_cloud_levels.argtypes = [vp]
+    L.m3dreg_cloud_density.argtypes = [vp, vp, C.c_int, f64p]
     L.m3dreg_cloud_grid_info.argtypes = [vp, vp, C.c_int, C.POINTER(abi.GridInfo)]
     L.m3dreg_cloud_export.argtypes = [vp, vp, C.c_int, u32p, u32p, i32p, f32p, f32p]
     L.m3dreg_debug_nn.argtypes = [vp, vp, C.c_int, f32p, sz, C.c_float, i32p, f32p]
@@ -117,10 +118,11 @@ def lib():
     L.m3dreg_multi_destroy.argtypes = [vp]
     L.m3dreg_multi_align.argtypes = [vp, C.POINTER(abi.PairDesc), sz, f32p, C.POINTER(abi.Stats), i32p]
     L.m3dreg_multi_last_error.argtypes = [vp]
+    L.m3dreg_debug_multi_clouds.argtypes = [vp]
     L.m3dreg_multi_last_error.restype = C.c_char_p
     L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
     L.m3dreg_debug_throw.argtypes = [C.c_int]
-    if L.m3dreg_abi_version() != abi.ABI_VERSION:
+    if L.m3dreg_abi_version() != abi.ABI_VERSION and not os.environ.get("M3DREG_LIB"):   # (M3DREG_LIB: an A/B against an older build, at the caller's risk)
         raise RuntimeError("libm3dreg.so ABI version mismatch")
     _lib = L
     return L
@@ -165,6 +167,13 @@ class Cloud:
     def status(self):
         """0, or the (negative) m3dreg_error the device found while bucketing this cloud; waits for the bucketing."""
         return lib().m3dreg_cloud_status(self._reg._h, self._p)
+
+    def density(self, level=None):
+        """mean population of the voxel a point lies in (m3dreg_cloud_density; default: the finest level) — the LPT cost estimate"""
+        d = C.c_double()
+        lv = lib().m3dreg_cloud_levels(self._p) - 1 if level is None else level
+        self._reg._check(lib().m3dreg_cloud_density(self._reg._h, self._p, lv, C.byref(d)), "cloud_density")
+        return d.value
 
     def grid_info(self, level=0):
         g = abi.GridInfo()
@@ -429,16 +438,25 @@ class MultiRegistrar:
         except Exception:
             pass
 
-    def describe(self, pairs, source_only=False, pinned=False):
+    def describe(self, pairs, source_only=False, pinned=False, groups=None):
         """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (descriptor array, buffers to keep alive): host PointCloud2 payloads, encoded the
         aggregator's way; source_only: the sources are only sorted (m3dreg_cloud_desc.source_only); pinned: the payloads live in
-        m3dreg_host_alloc memory (asynchronous DMA, no staging copy) instead of pageable memory."""
+        m3dreg_host_alloc memory (asynchronous DMA, no staging copy) instead of pageable memory; groups[i] > 0: the pairs with this id share ONE
+        target payload (m3dreg_pair_desc.target_group: the first pair's target array is encoded once and named by all of them)."""
         from .pointcloud2 import encode_xyz
         n = len(pairs)
         descs = (abi.PairDesc * n)()
         keep = []
+        shared = {}   # group id -> the descriptor fields of its (one) target payload
         for i, (src, tgt, T0) in enumerate(pairs):
-            for d, xyz, so in ((descs[i].source, src, source_only), (descs[i].target, tgt, False)):
+            gid = int(groups[i]) if groups is not None else 0
+            descs[i].target_group = gid
+            for d, xyz, so, is_tgt in ((descs[i].source, src, source_only, False), (descs[i].target, tgt, False, True)):
+                if is_tgt and gid > 0 and gid in shared:
+                    d.data, d.n, d.point_step = shared[gid]
+                    d.off_x, d.off_y, d.off_z = 0, 4, 8
+                    d.data_is_device = 0; d.source_only = 0
+                    continue
                 msg = encode_xyz(np.ascontiguousarray(xyz, np.float32))
                 if pinned:
                     buf = PinnedBuffer(len(msg.data))
@@ -452,6 +470,8 @@ class MultiRegistrar:
                 d.n = msg.n; d.point_step = msg.point_step
                 d.off_x, d.off_y, d.off_z = 0, 4, 8
                 d.data_is_device = 0; d.source_only = 1 if so else 0
+                if is_tgt and gid > 0:
+                    shared[gid] = (d.data, d.n, d.point_step)
             t0 = T_to_colmajor16(np.eye(4) if T0 is None else T0)
             for k in range(16):
                 descs[i].init_T[k] = float(t0[k])
@@ -468,9 +488,13 @@ class MultiRegistrar:
             raise abi.M3dregError(rc, "m3dreg_multi_align", lib().m3dreg_multi_last_error(self._m).decode())
         return np.stack([colmajor16_to_T(out[16 * i:16 * i + 16]) for i in range(n)]), list(st), dev
 
-    def align(self, pairs, source_only=False):
+    def clouds_bucketed(self):
+        """clouds uploaded + bucketed by the last align (a target group's target counts once)"""
+        return lib().m3dreg_debug_multi_clouds(self._m)
+
+    def align(self, pairs, source_only=False, groups=None):
         """pairs: [(src_xyz, tgt_xyz, T0 or None)] -> (poses [n, 4, 4], stats list, device of every pair)"""
-        descs, keep = self.describe(pairs, source_only)
+        descs, keep = self.describe(pairs, source_only, groups=groups)
         return self.align_described(descs)
 
 

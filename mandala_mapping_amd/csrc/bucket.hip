@@ -355,8 +355,9 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
     const uint32_t* skey = sorted_keys(B);
     const int j = rb.blk * 256 + (int)threadIdx.x;
     bool vh = false, bh = false;
+    uint32_t k = M3D_INVALID_KEY;
     if (j < n) {
-        const uint32_t k = skey[j];
+        k = skey[j];
         if (k != M3D_INVALID_KEY) {
             const uint32_t kp = j ? skey[j - 1] : M3D_INVALID_KEY;
             vh = (j == 0) || (kp != k);
@@ -364,12 +365,31 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
         }
     }
     __shared__ uint32_t red[4][2];
+    __shared__ float redf[4];
     const unsigned long long bv = __ballot(vh), bb = __ballot(bh);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = (uint32_t)__popcll(bv); red[threadIdx.x >> 6][1] = (uint32_t)__popcll(bb); }
+    // population of every voxel whose head lies in this block, squared and summed (M3dLevelMeta::sumsq): the next head inside the wave ends the run;
+    // the wave's last run is measured by a bisection of the sorted keys (one lane per wave)
+    float sq = 0.f;
+    if (vh) {
+        const int lane = (int)(threadIdx.x & 63u);
+        const unsigned long long later = lane == 63 ? 0ull : (bv >> (lane + 1));
+        int len;
+        if (later) len = __ffsll((long long)later);
+        else {
+            int lo = j, hi = n;   // skey[lo] == k; hi = the first position known not to hold k (keys are sorted: the run is [j, hi))
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (skey[mid] == k) lo = mid; else hi = mid; }
+            len = hi - j;
+        }
+        sq = (float)len * (float)len;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = (uint32_t)__popcll(bv); red[threadIdx.x >> 6][1] = (uint32_t)__popcll(bb); redf[threadIdx.x >> 6] = sq; }
     __syncthreads();
-    if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block
+    if (threadIdx.x == 0) {   // B.hist (free after the sort): [2 blk] = voxel heads, [2 blk + 1] = bucket heads of this block; behind them, [2 nblk + blk] = its sum of squares
         B.hist[2 * rb.blk] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         B.hist[2 * rb.blk + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        B.hist[2 * ((n + 255) / 256) + rb.blk] = __float_as_uint(((redf[0] + redf[1]) + redf[2]) + redf[3]);
     }
 }
 
@@ -396,8 +416,10 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
     const bool want_order = B.order != nullptr && nblk <= M3D_ORDER_CAP;
     uint32_t carryV = 0, carryB = 0;
     const int t = threadIdx.x;
+    float sq = 0.f;   // M3dLevelMeta::sumsq: the blocks' sums in a fixed order (a thread's blocks ascending, then a fixed reduction tree)
     for (int base = 0; base < nblk; base += 256) {
         const int b = base + t;
+        if (b < nblk) sq += __uint_as_float(B.hist[2 * nblk + b]);
         const uint32_t vV = b < nblk ? B.hist[2 * b] : 0u, vB = b < nblk ? B.hist[2 * b + 1] : 0u;
         if (want_order && b < nblk) wv[b] = vV;
         // inclusive scans of the two counts over the 256 threads: shuffles inside a wave, the wave totals through LDS (sixteen barriers of a
@@ -414,6 +436,14 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
         if (b < nblk) B.hist[2 * b] = carryV + iV - vV;
         carryV += totV; carryB += totB;
         __syncthreads();
+    }
+    {
+        __shared__ float sqw[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if ((t & 63) == 0) sqw[t >> 6] = sq;
+        __syncthreads();
+        if (t == 0) reinterpret_cast<M3dLevelMeta*>(B.dyn)->sumsq = ((sqw[0] + sqw[1]) + sqw[2]) + sqw[3];
     }
     if (t == 0) {
         uint32_t hmask; int hshift;

@@ -49,7 +49,9 @@ struct M3dLevelMeta {
     float mx[3];
     int32_t err;           // 0, or the m3dreg_error of the CLOUD (same value in every level's meta)
     int32_t bits[3];
-    int32_t pad[2];
+    float sumsq;           // sum over the occupied voxels of population^2 (float, fixed summation order): sumsq / n_valid = the mean population of the voxel a
+                           // point lies in — what a query meets in its home voxel, the a-priori cost of a registration (m3dreg_cloud_density; LPT sharding)
+    int32_t pad;
 };
 static_assert(sizeof(M3dLevelMeta) == 144, "M3dLevelMeta layout");
 

@@ -49,6 +49,7 @@ struct DevLevel {
     uint32_t* perm = nullptr;
     float4* nrm = nullptr;         // normals in this level's sorted order (point-to-plane)
     uint32_t n_cells_host = 0;     // valid once the cloud's meta data was fetched (fetch_meta)
+    float sumsq_host = 0.f;        // (same) sum of squared voxel populations
     uint32_t* dyn = nullptr;       // the level's M3dLevelMeta (144 B) in the cloud's block: grid geometry, table geometry, counts, error state —
                                    // all derived on the device; grid / bits / mx / lbound above are host COPIES, valid after fetch_meta
 };
@@ -518,6 +519,7 @@ int fetch_meta(m3dreg_handle* h, m3dreg_cloud* c) {
             HIPCHK(h, hipMemcpy(&M, c->lv[l].dyn, sizeof(M), hipMemcpyDeviceToHost));
             DevLevel& L = c->lv[l];
             L.n_cells_host = M.dyn[0];
+            L.sumsq_host = M.sumsq;
             L.grid = M.g;
             L.grid.hmask = M.dyn[1];
             L.grid.hshift = int32_t(M.dyn[2]);
@@ -1763,6 +1765,16 @@ int m3dreg_cloud_grid_info(m3dreg_handle* h, const m3dreg_cloud* c, int level, m
     });
 }
 
+int m3dreg_cloud_density(m3dreg_handle* h, const m3dreg_cloud* c, int level, double* out) {
+    return m3d_guarded(h, "m3dreg_cloud_density", [&]() -> int {
+    if (!h || !c || !out || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "cloud_density: bad argument");
+    if (c->source_only && level < c->n_levels - 1) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "cloud_density: the coarser levels of a source-only cloud are not built");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
+    *out = c->n_valid > 0 ? double(c->lv[level].sumsq_host) / double(c->n_valid) : 0.0;
+    return M3DREG_OK;
+    });
+}
+
 int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint32_t* keys, uint32_t* sorted_keys, int32_t* perm,
                         float* sorted_xyz, float* normals) {
     return m3d_guarded(h, "m3dreg_cloud_export", [&]() -> int {
@@ -1976,12 +1988,15 @@ struct m3dreg_multi {
     std::vector<std::unique_ptr<MultiWorker>> workers;   // one per entry of `devices` (a device may appear more than once: several streams on it)
     std::vector<int> devices;
     std::string err;
+    size_t last_clouds = 0;   // clouds uploaded and bucketed by the last m3dreg_multi_align (m3dreg_debug_multi_clouds)
 };
 
 namespace {
 // Longest-processing-time-first with a capacity per device (what mandala_mapping_amd/sharding.py lpt_assign does for the ranks of a
 // torchrun job): heaviest pair first, onto the least loaded device that still has room; ties to the lower index.
-void lpt_assign(const std::vector<double>& cost, int n_dev, size_t capacity, std::vector<int>& dev_of) {
+// A UNIT is what must stay together: one pair, or all pairs of a target group (size[u] pairs). A unit that no device has room for under the
+// capacity (a group larger than ceil(n_pairs / n_devices)) goes to the least loaded device regardless.
+void lpt_assign(const std::vector<double>& cost, const std::vector<size_t>& size, int n_dev, size_t capacity, std::vector<int>& dev_of) {
     std::vector<size_t> order(cost.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
@@ -1989,13 +2004,20 @@ void lpt_assign(const std::vector<double>& cost, int n_dev, size_t capacity, std
     std::vector<size_t> count(size_t(n_dev), 0);
     dev_of.assign(cost.size(), 0);
     for (size_t i : order) {
-        int best = -1;
-        for (int d = 0; d < n_dev; d++)
-            if (count[size_t(d)] < capacity && (best < 0 || load[size_t(d)] < load[size_t(best)])) best = d;
+        int best = -1, any = 0;
+        for (int d = 0; d < n_dev; d++) {
+            if (load[size_t(d)] < load[size_t(any)]) any = d;
+            if (count[size_t(d)] + size[i] <= capacity && (best < 0 || load[size_t(d)] < load[size_t(best)])) best = d;
+        }
+        if (best < 0) best = any;
         dev_of[i] = best;
         load[size_t(best)] += cost[i];
-        count[size_t(best)]++;
+        count[size_t(best)] += size[i];
     }
+}
+bool same_payload(const m3dreg_cloud_desc& a, const m3dreg_cloud_desc& b) {
+    return a.data == b.data && a.n == b.n && a.point_step == b.point_step && a.off_x == b.off_x && a.off_y == b.off_y && a.off_z == b.off_z &&
+           (a.data_is_device != 0) == (b.data_is_device != 0);
 }
 int mfail(m3dreg_multi* m, int code, const std::string& msg) { if (m) { try { m->err = msg; } catch (...) {} } return code; }
 
@@ -2006,7 +2028,7 @@ bool host_ptr_is_pinned(const void* p) {
 }
 
 // what one worker does with its shard; everything it allocates is released on every path out, and its handle is idle when it returns
-struct ShardResult { int rc = M3DREG_OK; std::string msg; std::vector<float> T; std::vector<m3dreg_stats> st; };
+struct ShardResult { int rc = M3DREG_OK; std::string msg; std::vector<float> T; std::vector<m3dreg_stats> st; size_t n_clouds = 0; };
 void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<size_t>& idx, ShardResult& R) {
     m3dreg_handle* h = w->h;
     std::vector<m3dreg_cloud*> clouds;
@@ -2014,17 +2036,29 @@ void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<
     auto fail_with = [&](int rc, const char* what) { R.rc = rc; try { R.msg = std::string("device ") + std::to_string(w->device) + ": " + what; } catch (...) {} };
     try {
         const size_t k = idx.size();
-        std::vector<m3dreg_cloud_desc> descs(2 * k);
+        // the shard's clouds: every pair's source, and every DISTINCT target — the pairs of a target group (m3dreg_pair_desc.target_group > 0) share
+        // one cloud, uploaded and bucketed once; src_of / tgt_of: the cloud of pair j
+        std::vector<m3dreg_cloud_desc> descs;
+        std::vector<size_t> src_of(k), tgt_of(k);
+        descs.reserve(2 * k);
+        for (size_t j = 0; j < k; j++) {
+            const m3dreg_pair_desc& P = pairs[idx[j]];
+            m3dreg_cloud_desc d = P.source; d.source_only = 1;
+            src_of[j] = descs.size(); descs.push_back(d);
+            size_t t = size_t(-1);
+            if (P.target_group > 0)
+                for (size_t j2 = 0; j2 < j && t == size_t(-1); j2++) if (pairs[idx[j2]].target_group == P.target_group) t = tgt_of[j2];
+            if (t == size_t(-1)) { d = P.target; d.source_only = 0; t = descs.size(); descs.push_back(d); }
+            tgt_of[j] = t;
+        }
+        const size_t nc = descs.size();
         // pageable host payloads go through this worker's pinned staging block
         size_t need = 0;
-        std::vector<size_t> off(2 * k, size_t(-1));
-        for (size_t j = 0; j < k; j++)
-            for (int c = 0; c < 2; c++) {
-                m3dreg_cloud_desc d = c == 0 ? pairs[idx[j]].source : pairs[idx[j]].target;
-                d.source_only = c == 0 ? 1 : 0;
-                descs[2 * j + size_t(c)] = d;
-                if (!d.data_is_device && d.data && d.n && !host_ptr_is_pinned(d.data)) { off[2 * j + size_t(c)] = need; need += (d.n * d.point_step + 255) & ~size_t(255); }
-            }
+        std::vector<size_t> off(nc, size_t(-1));
+        for (size_t i = 0; i < nc; i++) {
+            const m3dreg_cloud_desc& d = descs[i];
+            if (!d.data_is_device && d.data && d.n && !host_ptr_is_pinned(d.data)) { off[i] = need; need += (d.n * d.point_step + 255) & ~size_t(255); }
+        }
         if (need > w->pinned_bytes) {
             if (w->pinned) { hipStreamSynchronize(h->stream); hipHostFree(w->pinned); w->pinned = nullptr; w->pinned_bytes = 0; }
             alloc_point();
@@ -2032,20 +2066,21 @@ void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<
             else w->pinned_bytes = need + need / 4;
         }
         if (w->pinned && need <= w->pinned_bytes)
-            for (size_t i = 0; i < 2 * k; i++)
+            for (size_t i = 0; i < nc; i++)
                 if (off[i] != size_t(-1)) {
                     uint8_t* dst = static_cast<uint8_t*>(w->pinned) + off[i];
                     memcpy(dst, descs[i].data, descs[i].n * descs[i].point_step);
                     descs[i].data = dst;
                 }   // (no pinned memory to be had: the payloads go as they are — a synchronous pageable copy, still correct)
-        clouds.assign(2 * k, nullptr);
+        clouds.assign(nc, nullptr);
+        R.n_clouds = nc;
         touched = true;
         int rc = m3dreg_cloud_create_batch_async(h, descs.data(), descs.size(), clouds.data());
         if (rc != M3DREG_OK) fail_with(rc, h->err.c_str());
         else {
             std::vector<m3dreg_pair> pr(k);
             for (size_t j = 0; j < k; j++) {
-                pr[j].source = clouds[2 * j]; pr[j].target = clouds[2 * j + 1];
+                pr[j].source = clouds[src_of[j]]; pr[j].target = clouds[tgt_of[j]];
                 memcpy(pr[j].init_T, pairs[idx[j]].init_T, sizeof(float) * 16);
             }
             R.T.assign(16 * k, 0.f); R.st.assign(k, m3dreg_stats{});
@@ -2114,13 +2149,24 @@ int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_
     std::string msg;
     try {
         alloc_point();
-        std::vector<double> cost(n_pairs);
-        for (size_t i = 0; i < n_pairs; i++) cost[i] = double(pairs[i].source.n) + double(pairs[i].target.n);
+        // units of the assignment: a pair, or a whole target group (its target counted once: it is uploaded and bucketed once)
+        std::vector<size_t> unit_of(n_pairs), usize;
+        std::vector<double> cost;
+        std::vector<int32_t> ugroup; std::vector<size_t> ufirst;
+        for (size_t i = 0; i < n_pairs; i++) {
+            const int32_t gid = pairs[i].target_group;
+            if (gid < 0) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: negative target_group");
+            size_t u = size_t(-1);
+            if (gid > 0) for (size_t q = 0; q < ugroup.size() && u == size_t(-1); q++) if (ugroup[q] == gid) u = q;
+            if (u == size_t(-1)) { u = cost.size(); cost.push_back(double(pairs[i].target.n)); usize.push_back(0); ugroup.push_back(gid > 0 ? gid : -1); ufirst.push_back(i); }
+            else if (!same_payload(pairs[ufirst[u]].target, pairs[i].target)) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: the pairs of a target_group must name the same target payload");
+            unit_of[i] = u; cost[u] += double(pairs[i].source.n); usize[u]++;
+        }
         std::vector<int> dev_of;
-        lpt_assign(cost, n_dev, (n_pairs + size_t(n_dev) - 1) / size_t(n_dev), dev_of);
+        lpt_assign(cost, usize, n_dev, (n_pairs + size_t(n_dev) - 1) / size_t(n_dev), dev_of);
         idx.assign(size_t(n_dev), std::vector<size_t>());
         res.assign(size_t(n_dev), ShardResult());
-        for (size_t i = 0; i < n_pairs; i++) idx[size_t(dev_of[i])].push_back(i);
+        for (size_t i = 0; i < n_pairs; i++) idx[size_t(dev_of[unit_of[i]])].push_back(i);
         // every device's worker takes its shard: uploads, bucketing, registrations and the wait for them run side by side
         for (int d = 0; d < n_dev; d++, posted++) {
             if (idx[size_t(d)].empty()) continue;
@@ -2134,8 +2180,10 @@ int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_
     // whatever was posted is waited for — also on the error paths: the workers read the caller's payloads and write into res
     for (int d = 0; d < posted && d < n_dev; d++) m->workers[size_t(d)]->wait();
     if (rc != M3DREG_OK) return mfail(m, rc, rc == M3DREG_ERR_OUT_OF_MEMORY ? "multi_align: host allocation failed" : "multi_align: unexpected exception");
+    m->last_clouds = 0;
     for (int d = 0; d < n_dev; d++) {
         const ShardResult& R = res[size_t(d)];
+        m->last_clouds += R.n_clouds;
         if (R.rc != M3DREG_OK) { if (rc == M3DREG_OK) { rc = R.rc; msg = R.msg; } continue; }
         for (size_t k = 0; k < idx[size_t(d)].size(); k++) {
             const size_t i = idx[size_t(d)][k];
@@ -2147,6 +2195,8 @@ int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_
     if (rc != M3DREG_OK) return mfail(m, rc, msg);
     return M3DREG_OK;
 }
+
+int m3dreg_debug_multi_clouds(const m3dreg_multi* m) { return m ? int(m->last_clouds) : M3DREG_ERR_INVALID_ARG; }
 
 // Pinned host memory for callers that do not link HIP: a payload that lives in it reaches the device by a truly asynchronous copy
 // (every cloud_create* entry point and m3dreg_multi_align recognise pinned ranges; pageable ones work too, at the price of a

@@ -45,6 +45,43 @@ def test_multi_context_equals_single_handle_batch(reg, orc):
     M.close()
 
 
+def test_target_groups_are_co_located_and_bucketed_once(reg, orc):
+    """m3dreg_pair_desc.target_group (ABI 5; SURVEY 8e: "pairs sharing the same reference cloud are co-located so bucketing is done once"): six
+    loop-closure candidates against two submaps over two device contexts — each group stays on one context, its target is uploaded and bucketed
+    once (8 clouds instead of 12), and every pose equals the ungrouped call's and the oracle's, bit for bit. Pairs of one group that name different
+    payloads are refused."""
+    p = abi.Params.make(leaf=0.2, iterations=8, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    tg = []
+    pairs, groups = [], []
+    for g in range(2):
+        _, tgt, _ = synth.hdl32_pair(400, 900 + g, 950 + g, base=(2.0 * g, 1.0, 10.0 * g))
+        tg.append(tgt)
+        for k in range(3):
+            src, _, Tgt = synth.hdl32_pair(400, 900 + g, 960 + 10 * g + k, dx=0.1 + 0.1 * k, dy=0.05 * k, dyaw_deg=1.0 + k, base=(2.0 * g, 1.0, 10.0 * g))
+            pairs.append((src, tgt, None)); groups.append(g + 1)
+    M = reg.MultiRegistrar(p, devices=[0, 0])
+    Tg, stg, _ = M.align(pairs, source_only=True, groups=groups)
+    assert M.clouds_bucketed() == 8
+    Tu, stu, _ = M.align(pairs, source_only=True)
+    assert M.clouds_bucketed() == 12
+    assert np.array_equal(Tg, Tu)
+    for i, (src, tgt, _) in enumerate(pairs):
+        To, sto, _ = orc.align(p, orc.Cloud(p, src, source_only=True), orc.Cloud(p, tgt))
+        assert np.array_equal(Tg[i], To) and stg[i].n_corr == sto.n_corr == stu[i].n_corr, i
+    # one group larger than a context's share (4 of 6 pairs, capacity 3): still together, still the same bits
+    g2 = [1, 1, 1, 0, 0, 0]
+    pr2 = [(pairs[i][0], tg[0], None) for i in range(3)] + pairs[3:]
+    T2, _, _ = M.align(pr2 + [(pairs[0][0], tg[0], None)], source_only=True, groups=g2 + [1])
+    assert M.clouds_bucketed() == 7 + 1 + 3 and np.array_equal(T2[:6], Tg) and np.array_equal(T2[6], Tg[0])
+    # different payloads under one group id
+    descs, keep = M.describe(pairs[:2], source_only=True)
+    descs[0].target_group = descs[1].target_group = 5
+    with pytest.raises(abi.M3dregError) as ei:
+        M.align_described(descs)
+    assert ei.value.code == abi.ERR_INVALID_ARG
+    M.close()
+
+
 def test_multi_align_survives_allocation_failures_and_takes_pinned_payloads(reg):
     """ADVICE r2: a std::bad_alloc anywhere inside m3dreg_multi_align (the caller's thread or a device thread, before or after
     something was enqueued) comes back as M3DREG_ERR_OUT_OF_MEMORY with every device's handle idle and every cloud released — the

@@ -777,6 +777,27 @@ def test_full_size_pairs_equal_the_oracle(reg, orc, which):
     assert rot < 0.1 and tra < 0.006, (rot, tra)
 
 
+def test_device_density_is_the_lpt_cost(reg):
+    """m3dreg_cloud_density (the bucketing pipeline's sum of squared voxel populations / finite points) equals synth.crowdedness — the numpy estimate the
+    LPT sharding of config 4 was tabulated with (mandala_mapping_amd/config4_costs.json) — for full targets and source-only clouds alike, and the table's
+    entries are what the device says."""
+    import json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    costs = json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json")))["costs"]
+    p = _params(leaf=0.1, iterations=2, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    R = reg.Registrar(p)
+    for k in (4, 31, 50):
+        src, tgt, _ = synth.config4_pair(k)
+        src = src.copy(); src[::997] = np.nan
+        cs, ct = R.clouds([src, tgt], source_only=[True, False])
+        ds, dt = cs.density(), ct.density()
+        assert abs(ds - synth.crowdedness(src)) < 1e-3 * ds and abs(dt - synth.crowdedness(tgt)) < 1e-3 * dt, (k, ds, dt)
+        assert abs(ds + dt - costs[k]) < 0.02 * costs[k], (k, ds + dt, costs[k])   # (the table was made from clouds without the NaNs)
+    two = _params(leaf=(0.4, 0.1), iterations=(2, 2), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4)
+    c2 = reg.Registrar(two).cloud(tgt)
+    assert abs(c2.density(0) - synth.crowdedness(tgt, 0.4)) < 1e-3 * c2.density(0) and abs(c2.density() - synth.crowdedness(tgt)) < 1e-3 * c2.density()
+
+
 def test_source_only_clouds_skip_the_normal_grid(reg, orc):
     """m3dreg_cloud_desc.source_only: a cloud that will only ever be a source is sorted but gets no normals (its normal-estimation grid
     is not built). Registering it gives exactly the oracle's poses; as a point-to-plane TARGET it is refused."""
