@@ -483,15 +483,26 @@ def main():
         avg_launch_s = (kern_ms / 1e3) / max(1, launches)
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = l2_hit = traffic_unc = None
+        traffic_source = None
+        live = measure_traffic(args) if (world == 1 and not args.no_extra and not args.no_cpu_baseline and args.workload == "config4") else None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if live is not None:
+            traffic, traffic_unc = live["correspondence_step_bytes_per_launch"], live["correspondence_step_bytes_per_launch_fetch_uncorrected"]
+            traffic_source = ("measured in this run: two child runs of this script under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, serial steps); `traffic` = FETCH_SIZE x 2 + "
+                              "WRITE_SIZE (the guide's gfx950 correction, calibrated for wide coalesced streaming reads), `traffic_fetch_uncorrected` = FETCH_SIZE + WRITE_SIZE: these kernels "
+                              "mix 16-B streams with 16-B gathers, for which the guide gives no calibration — the true figure lies between the two")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                traffic = sum(j.get(k, {}).get("hbm_bytes_per_iteration", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
-                traffic_unc = sum(j.get(k, {}).get("hbm_bytes_per_iteration_uncorrected", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
+                if live is None:
+                    traffic = sum(j.get(k, {}).get("hbm_bytes_per_iteration", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
+                    traffic_unc = sum(j.get(k, {}).get("hbm_bytes_per_iteration_uncorrected", 0.0) for k in ("k_nn_iter", "k_nn_tiles")) or None
+                    traffic_source = "committed: profiles/pmc_summary.json (rocprofv3 --pmc passes of scripts/profile_gpu.sh on the builder's box, NOT measured in this run: rocprofv3 was not usable here)"
                 l2_hit = {k: j[k]["l2_hit_rate"] for k in ("k_nn_iter", "k_nn_tiles", "k_accumulate_matches", "k_icp_late") if k in j and "l2_hit_rate" in j[k]} or None
             except Exception:
-                traffic = l2_hit = traffic_unc = None
+                if live is None:
+                    traffic = traffic_unc = None
+                l2_hit = None
         in_region = achieved
         alone = alg_bytes / (alone_ms / 1e3) / 1e9 if alone_ms > 0 else 0.0
         # one whole linearisation of the SHIPPED schedule (correspondence step + residuals + reduction + solve; fused k_icp_late launches included):
@@ -534,9 +545,7 @@ def main():
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches, "concurrent_chains": D,
                          "frac_source": "hipEvent brackets inside the timed region (every --event-every-th iteration), on the library's stream",
                          "traffic": traffic, "traffic_fetch_uncorrected": traffic_unc,
-                         "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_gpu.sh, not measured in this run); `traffic` = FETCH_SIZE x 2 + "
-                                           "WRITE_SIZE (the guide's gfx950 correction, calibrated for wide coalesced streaming reads), `traffic_fetch_uncorrected` = FETCH_SIZE + WRITE_SIZE: these kernels "
-                                           "mix 16-B streams with 16-B gathers, for which the guide gives no calibration — the true figure lies between the two",
+                         "traffic_source": traffic_source, "traffic_step": ({k: live[k] for k in ("step_bytes", "step_bytes_fetch_uncorrected", "per_kernel_MB_per_step", "note")} if live else None),
                          "l2_hit_rate": l2_hit,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gather_model": gather_model,
@@ -565,6 +574,50 @@ def main():
         dist.destroy_process_group()
 
 
+def measure_traffic(args):
+    """HBM-side bytes of the correspondence step and of a whole step, measured IN THIS RUN when rocprofv3 is on the box: two child runs of this script
+    (serial steps, no event brackets) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` — separate passes, nothing else traced, the program
+    itself behind `--` — read per kernel. FETCH_SIZE is doubled (the guide's gfx950 correction for wide coalesced reads; these kernels mix 16-B streams with
+    16-B gathers, for which it is uncalibrated: the uncorrected sum is reported beside it). Returns None when the tool is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if not tool:
+        return None
+    steps_timed = 3
+    per = {}
+    try:
+        for ci, ctr in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                cmd = [tool, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__),
+                       "--steps", str(steps_timed), "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--inflight", "1", "--queue-depth", "1", "--no-events", "--min-seconds", "0",
+                       "--iters", str(args.iters), "--azimuth", str(args.azimuth), "--pairs-per-gpu", str(args.pairs_per_gpu)]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+                files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return None
+                for f in files:
+                    for row in csv.DictReader(open(f)):
+                        k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                        e = per.setdefault(k, [0.0, 0.0, 0])
+                        e[ci] += float(row["Counter_Value"]) * 1024.0
+                        if ci == 0:
+                            e[2] += 1
+    except Exception:
+        return None
+    steps = steps_timed + 2   # + the step that sizes the workload and one warm-up step per handle
+    nn = [per.get(k, [0.0, 0.0, 0]) for k in ("k_nn_iter", "k_nn_tiles")]
+    launches = max(1, per.get("k_nn_tiles", [0, 0, 1])[2])   # the iterations that run the tile search: k_nn_iter + k_nn_tiles, one launch each
+    return {"correspondence_step_bytes_per_launch": (2.0 * sum(e[0] for e in nn) + sum(e[1] for e in nn)) / launches,
+            "correspondence_step_bytes_per_launch_fetch_uncorrected": (sum(e[0] for e in nn) + sum(e[1] for e in nn)) / launches,
+            "step_bytes": sum(2.0 * e[0] + e[1] for e in per.values()) / steps, "step_bytes_fetch_uncorrected": sum(e[0] + e[1] for e in per.values()) / steps,
+            "per_kernel_MB_per_step": {k: round((2.0 * e[0] + e[1]) / steps / 1e6, 1) for k, e in sorted(per.items(), key=lambda kv: -(2.0 * kv[1][0] + kv[1][1])) if 2.0 * e[0] + e[1] > 5e5},
+            "note": "k_nn_iter + k_nn_tiles of the iterations that run the tile search (the fused k_icp_late launches of the later iterations are in step_bytes)"}
+
+
 def extra_legs(args):
     """The other BASELINE configurations and the SURVEY 8d variants of the headline, each a CHILD run of this script on the same GPU
     right after the headline (a child process, started — never exec'ed — from this one; it prints its own JSON line)."""
@@ -579,6 +632,12 @@ def extra_legs(args):
         "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config5": ["--workload", "config5", "--steps", "10", "--warmup", "2"],
+        # the big-batch regime: B pairs per step in ONE launch chain — 64 = ALL of config 4 on one GPU (pairs 0 ... 63: also the ones next to
+        # obstacles, which rank 0's 8-pair shard does not hold) — with one chain (the kernels' own throughput: nothing else on the GPU) and with two in flight
+        "batch16": ["--pairs-per-gpu", "16", "--inflight", "2", "--queue-depth", "2", "--steps", "10", "--warmup", "3"],
+        "batch32": ["--pairs-per-gpu", "32", "--inflight", "2", "--queue-depth", "2", "--steps", "8", "--warmup", "2"],
+        "batch64_one_chain": ["--pairs-per-gpu", "64", "--inflight", "1", "--queue-depth", "1", "--steps", "6", "--warmup", "2"],
+        "batch64": ["--pairs-per-gpu", "64", "--inflight", "2", "--queue-depth", "2", "--steps", "6", "--warmup", "2"],
     }
     legs = {}
     for name, extra in runs.items():
@@ -592,6 +651,7 @@ def extra_legs(args):
             keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "ms_per_icp_iter_batch", "ms_per_icp_iter_batch_alone", "ms_bucketing_batch_alone",
                                       "iterations_executed_pair0", "max_rot_err_deg", "max_trans_err_m") if k in d}
             keep["workload"] = d.get("config", {}).get("workload")
+            keep["overlap"] = d.get("config", {}).get("overlap")
             if "roofline" in d:
                 keep["roofline"] = {k: d["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "unit", "alone", "iteration")}
             for k in ("levels", "map_points", "bucket_map_ms", "bucket_map_wall_ms", "registration_ms", "blocks"):

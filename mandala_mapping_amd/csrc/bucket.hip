@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
         int len;
         if (later) len = __ffsll((long long)later);
         else {
-            int lo = j, hi = n;   // skey[lo] == k; hi = the first position known not to hold k (keys are sorted: the run is [j, hi))
+            // skey[lo] == k; hi = a position known not to hold k (keys are sorted: the run is [j, hi)). Galloping first: a run nearly always ends within the next
+            // 64 positions (the same cache lines); a bisection of [j, n) from the start touched 17 lines all over the array per wave (+ 28 MB per step)
+            int lo = j, step = 64;
+            while (lo + step < n && skey[lo + step] == k) { lo += step; step *= 2; }
+            int hi = lo + step < n ? lo + step : n;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (skey[mid] == k) lo = mid; else hi = mid; }
             len = hi - j;
         }
@@ -946,14 +950,17 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
         if (j == 0u) TB_STAMP(6);
         {
             const uint32_t np = s_ip[j] & 0xFFFFu;
-            for (uint32_t q0 = 0; q0 < np; q0 += 1024u) {   // four independent gathers in flight per thread
-                uint32_t gsrc[4]; float4 pv[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; gsrc[r] = pp < np ? s_src[pp] : 0u; }
-#pragma unroll
-                for (int r = 0; r < 4; r++) pv[r] = B.pts[gsrc[r]];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const uint32_t pp = q0 + 256u * r + (uint32_t)tid; if (pp < np) ipts[pp] = pv[r]; }
+            const M3D_GLOBAL m3d_f32x4* gpts = (const M3D_GLOBAL m3d_f32x4*)(const void M3D_GLOBAL*)B.pts;
+            M3D_GLOBAL m3d_f32x4* gout = (M3D_GLOBAL m3d_f32x4*)(void M3D_GLOBAL*)ipts;
+            for (uint32_t q0 = 0; q0 < np; q0 += 1024u) {   // four independent gathers in flight per thread (vector registers: as an array of float4 structs the four
+                // points went through 64 bytes of scratch per lane, 80 with the rest: the kernel's only private memory)
+                const uint32_t pa = q0 + (uint32_t)tid, pb = pa + 256u, pc = pa + 512u, pd = pa + 768u;
+                const uint32_t ga = pa < np ? s_src[pa] : 0u, gb = pb < np ? s_src[pb] : 0u, gc = pc < np ? s_src[pc] : 0u, gd = pd < np ? s_src[pd] : 0u;
+                const m3d_f32x4 va = gpts[ga], vb = gpts[gb], vc = gpts[gc], vd = gpts[gd];
+                if (pa < np) gout[pa] = va;
+                if (pb < np) gout[pb] = vb;
+                if (pc < np) gout[pc] = vc;
+                if (pd < np) gout[pd] = vd;
             }
         }
         if (j == 0u) TB_STAMP(7);

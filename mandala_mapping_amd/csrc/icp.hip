@@ -643,7 +643,12 @@ struct M3dTileQ {
     uint32_t sec;               // bits of a squared lower bound of every non-winning candidate
     float bound;                // prune voxels whose box is farther than this
 };
-__device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float uy, float uz, float dmax2, bool seeded, float dseed, M3dTileQ& Q, long long& code_out) {
+// voxel code of a binned query (m3d_voxel_code's encoding; k_nn_iter filed it: -1 <= f <= dims)
+__device__ __forceinline__ long long m3d_tile_code(const M3dGrid& g, float ux, float uy, float uz) {
+    const int i0 = (int)m3d_cell_f(ux, g.mn[0], g.inv_leaf), i1 = (int)m3d_cell_f(uy, g.mn[1], g.inv_leaf), i2 = (int)m3d_cell_f(uz, g.mn[2], g.inv_leaf);
+    return (long long)(i0 + 1) | ((long long)(i1 + 1) << 16) | ((long long)(i2 + 1) << 32);
+}
+__device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float uy, float uz, float dmax2, bool seeded, float dseed, M3dTileQ& Q) {
     const float u[3] = { ux, uy, uz };
     int ic[3];
     const float inf = __uint_as_float(M3D_INF_BITS);
@@ -657,7 +662,6 @@ __device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float
         Q.G[a][1] = (ic[a] >= 0 && ic[a] < g.dims[a]) ? 0.f : inf;
         Q.G[a][2] = (ic[a] + 1 < g.dims[a]) ? gh * gh : inf;            // (ic + 1 >= 0 always)
     }
-    code_out = (long long)(ic[0] + 1) | ((long long)(ic[1] + 1) << 16) | ((long long)(ic[2] + 1) << 32);
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     Q.key0 = (uint32_t)ic[0] + ((uint32_t)ic[1] << sh1) + ((uint32_t)ic[2] << sh2);
     Q.bkey = ((unsigned long long)M3D_INF_BITS << 32) | 0xFFFFFFFFull;
@@ -1311,11 +1315,16 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
     const unsigned int wl = blockIdx.x & (unsigned int)(M3D_TILE_LISTS - 1);   // this workgroup's list of work items
     const unsigned int n_items = min(A.wcount[32u * wl], (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counters)
     const uint2* witems = A.witems + (size_t)wl * (size_t)A.wcap;
-    const int tid = (int)threadIdx.x;
+    const int tid0 = (int)threadIdx.x;
     const m3d_lu2 vs = (m3d_lu2)s_vs;
     const m3d_lf4 sp = (m3d_lf4)s_pts;
     bool first_item = true;
     for (unsigned int it = blockIdx.x / (unsigned int)M3D_TILE_LISTS; it < n_items; it += gridDim.x / (unsigned int)M3D_TILE_LISTS) {
+        // (the thread index is re-made per item behind an opaque barrier for the optimiser: with a loop-invariant tid the compiler hoists a dozen staging
+        // addresses out of the item loop and keeps them in VGPRs across the search — at 80 VGPRs that meant 32 bytes of scratch per lane, spilled and
+        // reloaded per item: 35 MB of WRITE traffic per launch, more than the results themselves)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
         const uint2 item = witems[it];
         const int pair = (int)item.x, blk = (int)(item.y & 0xFFFFFu);
         const unsigned int chunk = item.y >> 20;
@@ -1325,17 +1334,24 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         M3D_TBT_BEGIN();
         const M3dGrid g = J.tgt.g;
         const float dmax2 = J.dmax2;
-        const M3dTileHdr H = J.tgt.thdr[blk];
-        const unsigned int qn = min((A.tcnt + (size_t)pair * A.cnt_stride)[blk], (unsigned int)M3D_TILE_QCAP);
+        // (workgroup-uniform words, pinned to scalar registers: the compiler kept some of them in VGPRs — and then in scratch — across the images of an item)
+        M3dTileHdr H = J.tgt.thdr[blk];
+        H.extra = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.extra); H.n_img = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.n_img);
+        H.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.flags); H.meta0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.meta0);
+        const unsigned int qn = (unsigned int)__builtin_amdgcn_readfirstlane((int)min((A.tcnt + (size_t)pair * A.cnt_stride)[blk], (unsigned int)M3D_TILE_QCAP));
         const bool sparse = (H.meta0 >> 31) != 0u;   // a tile with crowded voxels: 64 records per item, eight lanes per record (m3d_tile_search)
-        const unsigned int cs = sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)A.tile_chunk;
+        const unsigned int cs = (unsigned int)__builtin_amdgcn_readfirstlane((int)(sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)A.tile_chunk));
         const unsigned int lstride = M3D_TILE_THREADS / cs;
         M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
         M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);
         if (!first_item) __syncthreads();   // everybody is done with the previous item's LDS
         if (tid < 27) {   // key offset of voxel b of the visiting order (m3d_tile_search): dx + dy * 2^sh1 + dz * 2^sh2
-            const int ord[27] = { 13, 12, 14, 10, 16, 4, 22, 9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25, 0, 2, 6, 8, 18, 20, 24, 26 };   // index = (dx+1) + 3 (dy+1) + 9 (dz+1)
-            const int v = ord[tid], dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
+            // the visiting order (home, faces, edges, corners; index = (dx+1) + 3 (dy+1) + 9 (dz+1)), five bits each, in three constants (a table in constant
+            // memory cost a 64-bit address held across the item loop)
+            const unsigned long long o0 = 13ull | 12ull << 5 | 14ull << 10 | 10ull << 15 | 16ull << 20 | 4ull << 25 | 22ull << 30 | 9ull << 35 | 11ull << 40 | 15ull << 45 | 17ull << 50 | 3ull << 55;
+            const unsigned long long o1 = 5ull | 21ull << 5 | 23ull << 10 | 1ull << 15 | 7ull << 20 | 19ull << 25 | 25ull << 30 | 0ull << 35 | 2ull << 40 | 6ull << 45 | 8ull << 50 | 18ull << 55;
+            const unsigned long long o2 = 20ull | 24ull << 5 | 26ull << 10;
+            const int v = (int)(((tid < 12 ? o0 : (tid < 24 ? o1 : o2)) >> (5 * (tid % 12))) & 31ull), dx = v % 3 - 1, dy = (v / 3) % 3 - 1, dz = v / 9 - 1;
             s_kd[tid] = dx + dy * (1 << (g.cb[0] + 1)) + dz * (1 << (g.cb[0] + g.cb[1] + 2));
         }
         const m3d_gf4 rec = m3d_as_global(A.rec + (size_t)pair * A.rec_stride + (size_t)blk * M3D_TILE_QCAP);
@@ -1349,7 +1365,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const float dseed = have ? recd[q] : 0.f;
         const uint32_t w = __float_as_uint(r4.w);
         const bool seeded = (w >> 31) != 0u;
-        M3dTileQ Q; long long code = 0;
+        M3dTileQ Q;
         int m = -1;
         for (unsigned int j = 0; j < H.n_img; j++) {
             const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
@@ -1393,7 +1409,11 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
                 M3D_TBT_STAGED();
             }
             if (have) {
-                if (j == 0u) m3d_tile_query(g, r4.x, r4.y, r4.z, dmax2, seeded, dseed, Q, code);
+                // (the query's geometry is derived HERE, behind the staging: hoisted above it — it only needs the record — its nine gap words lived across the
+                // staging's sixteen point registers and went to scratch)
+                float qx = r4.x, qy = r4.y, qz = r4.z;
+                asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+                if (j == 0u) m3d_tile_query(g, qx, qy, qz, dmax2, seeded, dseed, Q);
 #ifdef M3D_EXP_NOSEARCH   // (timing experiment only — WRONG results: the floor of an item — records, staging, result writes — without the search)
                 const int b = -1;
 #else
@@ -1404,12 +1424,16 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             M3D_TBT_SEARCHED();
         }
         if (have && sub == 0u) {
-            const int qi = (int)(w & 0x7FFFFFFFu);
+            // (the record is read AGAIN here — an L2 hit — instead of riding through the search in registers: query index, seeded flag and the voxel code
+            // of a "nothing around" verdict were the last values the kernel kept in scratch across the images of an item)
+            const float4 re = m3d_ld(rec, (size_t)q);
+            const uint32_t we = __float_as_uint(re.w);
+            const int qi = (int)(we & 0x7FFFFFFFu);
             const float d2 = m3d_key_d2(Q.bkey);
             // "nothing at all in the 27 voxels" may be cached only when every existing voxel was looked up and found empty
-            if (!(m >= 0 && d2 <= dmax2)) m = (seeded || m >= 0 || Q.sec != M3D_INF_BITS) ? -1 : M3D_NN_NONE_CACHED;
+            if (!(m >= 0 && d2 <= dmax2)) m = ((we >> 31) != 0u || m >= 0 || Q.sec != M3D_INF_BITS) ? -1 : M3D_NN_NONE_CACHED;
             out[qi] = (m3d_i32x2){ m, m3d_cert_pack_bits(Q.sec, itq) };   // ONE 8-byte store per answer (rounds 2-3: a 4-byte match and a 16-byte state, two sectors)
-            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = m3d_tile_code(g, re.x, re.y, re.z);
         }
         const unsigned int n_done = min(cs, qn - min(qn, chunk * cs));
         if (tid == 0) atomicAdd(&A.states[pair].ctr[0], n_done);
