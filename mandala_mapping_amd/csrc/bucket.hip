@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
     p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
     B.pts[j] = p;
+    if (B.src3) { B.src3[3 * (size_t)j] = p.x; B.src3[3 * (size_t)j + 1] = p.y; B.src3[3 * (size_t)j + 2] = p.z; }
     if (B.nrm_sorted) {   // a level that will carry normals: k_normals (the cloud's normal grid) writes them straight into this level's order
         if (valid) level_inverse(B)[oi] = (uint32_t)j;
         else B.nrm_sorted[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (non-finite points, sorted last, have none)

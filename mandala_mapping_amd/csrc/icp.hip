@@ -820,7 +820,7 @@ struct M3dNnArgs {
     const m3d_gf4 pts = m3d_as_global(J.tgt.pts);                                                           \
     const m3d_gf4 cbox = m3d_as_global(J.tgt.cbox);                                                         \
     const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);                                                    \
-    const m3d_gf4 src = m3d_as_global(J.src);                                                               \
+    const m3d_gf3 src = m3d_as_global3(J.src);                                                              \
     const float dmax2 = J.dmax2;                                                                            \
     const int n = J.n_src;                                                                                  \
     const int itq = st->iters & 31;             /* this iteration's slot of the pose ring */                \
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __shared__ float s_ring[M3D_RING_FLOATS];   // the pair's pose ring (the certificates recompute where a query was at its last search)
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
-    if (i < n) { p = m3d_ld(src, i); if (!first_of_level) e = out[i]; }
+    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level) e = out[i]; }
     if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform; the loads above are in flight across it)
     if (i < n) {
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     __shared__ float s_ring[M3D_RING_FLOATS];
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
-    if (i < n) { p = m3d_ld(src, i); if (!first_of_level) e = out[i]; }
+    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level) e = out[i]; }
     if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform)
     if (i < n) {
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
@@ -1698,7 +1698,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
     constexpr int NACC = (METRIC == 1) ? 29 : 17;
     const int n = J.n_src;
     const int2* in = A.match + (size_t)pair * A.match_stride;
-    const m3d_gf4 src = m3d_as_global(J.src), pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
+    const m3d_gf3 src = m3d_as_global3(J.src);
+    const m3d_gf4 pts = m3d_as_global(L.pts), nrm = m3d_as_global(L.nrm);
     // NB queries per trip, every load of a stage issued before the first use: the pass is a chain of
     // dependent gathers (match -> point, normal), so its speed is the number of them in flight
     constexpr int NB = 2;   // (4 in flight: 180 VGPRs = 2 waves per SIMD; 2: 154 = 3 waves, same duration alone, +1.7 % with three chains sharing the GPU;
@@ -1726,7 +1727,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
             if (nW > 2 * ICP_THREADS) {   // (uniform) many: one query per lane
                 for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
                     const int qi = s_pend[w];
-                    const float4 ps = m3d_ld(src, qi);
+                    const float4 ps = m3d_ld3(src, (size_t)qi);
                     const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
                     const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
                     const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
@@ -1741,7 +1742,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
                     const int w = base + ((int)threadIdx.x >> 3);
                     const bool act = w < nW;
                     const int qi = act ? s_pend[w] : 0;
-                    const float4 ps = m3d_ld(src, qi);
+                    const float4 ps = m3d_ld3(src, (size_t)qi);
                     const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
                     const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
                     const float vz = fmaf(R[6], ps.x, fmaf(R[7], ps.y, fmaf(R[8], ps.z, tt[2])));
@@ -1767,7 +1768,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
 #pragma unroll
         for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; m[k] = (i < n) ? in[i].x : -1; }
 #pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld3(src, (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const size_t mm = (size_t)max(m[k], 0);
@@ -1829,7 +1830,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     if (threadIdx.x < 16) t_pre = st->T[threadIdx.x];
     const M3dGrid g = J.tgt.g;
     const m3d_gu4 tab = m3d_as_global(reinterpret_cast<const uint4*>(J.tgt.htab));
-    const m3d_gf4 pts = m3d_as_global(J.tgt.pts), nrm = m3d_as_global(J.tgt.nrm), cbox = m3d_as_global(J.tgt.cbox), src = m3d_as_global(J.src);
+    const m3d_gf4 pts = m3d_as_global(J.tgt.pts), nrm = m3d_as_global(J.tgt.nrm), cbox = m3d_as_global(J.tgt.cbox);
+    const m3d_gf3 src = m3d_as_global3(J.src);
     const m3d_gu32 bigcum = m3d_as_global(J.tgt.bigcum);
     const float dmax2 = J.dmax2;
     const int n = J.n_src;
@@ -1861,7 +1863,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
 #pragma unroll
         for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; const m3d_i32x2 e = (i < n) ? out[i] : (m3d_i32x2){ -1, 0 }; m[k] = e.x; ce[k] = e.y; }
 #pragma unroll
-        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld(src, i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld3(src, (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const int i = i0 + k * stride;

@@ -134,7 +134,8 @@ struct M3dPairState {      // per-registration state, lives in HBM for the whole
 };
 
 struct M3dJob {            // one pair at one level
-    const float4* src;     // source points in the source cloud's own sorted order (finest level), n_src finite points
+    const float* src;      // source points {x, y, z} PACKED (12 bytes each: a registration streams them in four kernels of every iteration and never needs the
+                           // index word of the float4 array), in the source cloud's own sorted order (finest level), n_src finite points
     int32_t n_src;
     int32_t metric;
     M3dLevelDev tgt;
@@ -264,6 +265,14 @@ __device__ __forceinline__ uint4 m3d_ld(m3d_gu4 p, size_t i) { const m3d_u32x4 v
 __device__ __forceinline__ float4 m3d_ld(m3d_gf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 // streamed-once data (source points, per-query results): non-temporal so it does not evict the gathered
 // target points / bucket table from the XCD's 4 MiB L2 (one pair's gather set is ~2.6 MB)
+// packed {x, y, z} source points: one 12-byte load per lane (global_load_dwordx3; consecutive lanes: consecutive addresses)
+typedef float m3d_f32x3 __attribute__((ext_vector_type(3)));
+typedef const M3D_GLOBAL float* m3d_gf3;
+__device__ __forceinline__ m3d_gf3 m3d_as_global3(const float* p) { return (m3d_gf3)(const void M3D_GLOBAL*)p; }
+__device__ __forceinline__ float4 m3d_ld3(m3d_gf3 p, size_t i) {
+    const m3d_f32x3 v = *reinterpret_cast<const M3D_GLOBAL m3d_f32x3*>(p + 3 * i);   // (12-byte records: 4-byte aligned, which is all dwordx3 needs)
+    return make_float4(v.x, v.y, v.z, 0.f);
+}
 __device__ __forceinline__ float4 m3d_ld_stream(m3d_gf4 p, size_t i) { const m3d_f32x4 v = __builtin_nontemporal_load(&p[i]); return make_float4(v.x, v.y, v.z, v.w); }
 
 // slot of the bucket `key` or -1; `lo` receives the first half of its entry {key, start, count, big}

@@ -46,6 +46,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t* skey_out;          // [n] out: sorted keys
     uint32_t* perm_out;          // [n] out: permutation
     float4* pts;                 // [n] out
+    float* src3;                 // [3 n] out (a cloud's FINEST level, else null): the sorted points packed {x, y, z}: what a registration streams as its source
     M3dBucket* htab;             // [hcap] out (worst-case allocation; the used size is derived on the device)
     uint32_t hcap;
     uint32_t* bigcum;            // [bigcap][8] out

@@ -34,6 +34,7 @@ struct DevLevel {
     float mx[3]{};
     float lbound = 0.f;
     float4* pts = nullptr;
+    float* src3 = nullptr;         // finest level only: the sorted points packed {x, y, z} (the source stream of a registration)
     M3dBucket* htab = nullptr;
     uint32_t hcap = 0;             // allocated entries (worst case); the used size is grid.hmask + 1
     uint32_t* bigcum = nullptr;
@@ -297,6 +298,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.hcap = table_cap(n);
         L.bigcap = uint32_t(n / 65536 + 1);
         L.pts = k.take<float4>(n);
+        L.src3 = (l == P.n_levels - 1) ? k.take<float>(3 * n) : nullptr;
         if (!c->source_only) {   // (nobody searches a source-only cloud: no bucket table, no chunk boxes)
             L.htab = k.take<M3dBucket>(L.hcap);
             L.bigcum = k.take<uint32_t>(size_t(L.bigcap) * 8);
@@ -462,7 +464,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             B.xyz = c->xyz; B.aabb = aabb[i];
             B.grid.leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
-            B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.htab = L.htab; B.hcap = L.hcap;
+            B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.src3 = is_ng ? nullptr : L.src3; B.htab = L.htab; B.hcap = L.hcap;
             B.cbox = is_ng ? nullptr : L.cbox;
             B.blkw = W.blkw; B.order = is_ng ? nullptr : L.order;
             B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
@@ -721,7 +723,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
-            J.src = s->lv[s->n_levels - 1].pts; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
+            J.src = s->lv[s->n_levels - 1].src3; J.n_src = 0; J.metric = P.metric;   // n_src, tgt.g, exps, S: k_patch_jobs, from the clouds' device-side meta
             J.src_dyn = s->lv[s->n_levels - 1].dyn;
             J.src_order = s->lv[s->n_levels - 1].order; J.src_nblk = (s->n + 255) / 256;
             J.tgt = level_dev(t->lv[l], t->has_tiles && h->tiles);
