@@ -370,21 +370,35 @@ __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict_
     // population of every voxel whose head lies in this block, squared and summed (M3dLevelMeta::sumsq): the next head inside the wave ends the run;
     // the wave's last run is measured by a bisection of the sorted keys (one lane per wave)
     float sq = 0.f;
-    if (vh) {
+    {
         const int lane = (int)(threadIdx.x & 63u);
-        const unsigned long long later = lane == 63 ? 0ull : (bv >> (lane + 1));
-        int len;
-        if (later) len = __ffsll((long long)later);
-        else {
-            // skey[lo] == k; hi = a position known not to hold k (keys are sorted: the run is [j, hi)). Galloping first: a run nearly always ends within the next
-            // 64 positions (the same cache lines); a bisection of [j, n) from the start touched 17 lines all over the array per wave (+ 28 MB per step)
-            int lo = j, step = 64;
-            while (lo + step < n && skey[lo + step] == k) { lo += step; step *= 2; }
-            int hi = lo + step < n ? lo + step : n;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (skey[mid] == k) lo = mid; else hi = mid; }
-            len = hi - j;
+        // Only the wave's LAST run can reach beyond the wave: how many lanes of this wave it covers (its key is the last head's; the keys are sorted, so
+        // they are contiguous), and — when it covers the wave's last lane — how many of the NEXT 64 positions continue it: every lane looks at one of them
+        // (one coalesced load). Only a run that covers all of those too (a crowded voxel) gallops on from there, one lane.
+        const int last_head = bv ? 63 - __clzll((long long)bv) : 0;
+        const uint32_t k_last = (uint32_t)__shfl((int)k, last_head);
+        const unsigned long long eqm = __ballot(bv != 0ull && k == k_last);            // (valid keys only: a head's key is valid)
+        const bool reaches_end = (eqm >> 63) != 0ull;
+        const int jn = j + 64;
+        const bool same = reaches_end && jn < n && skey[jn] == k_last;
+        const unsigned long long sm = __ballot(same);
+        const int ext = (sm == ~0ull) ? 64 : __ffsll((long long)~sm) - 1;               // leading positions of the next 64 that continue the run
+        if (vh) {
+            const unsigned long long later = lane == 63 ? 0ull : (bv >> (lane + 1));
+            int len;
+            if (later) len = __ffsll((long long)later);
+            else {
+                len = (int)__popcll(eqm) + ext;                                          // (this lane IS the last head: the run's lanes are exactly eqm's bits)
+                if (ext == 64) {   // (rare) gallop on: skey[lo] == k, hi = a position known not to hold k
+                    int lo = j + len - 1, step = 64;
+                    while (lo + step < n && skey[lo + step] == k) { lo += step; step *= 2; }
+                    int hi = lo + step < n ? lo + step : n;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (skey[mid] == k) lo = mid; else hi = mid; }
+                    len = hi - j;
+                }
+            }
+            sq = (float)len * (float)len;
         }
-        sq = (float)len * (float)len;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
