@@ -1046,14 +1046,24 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     __shared__ float s_ring[M3D_RING_FLOATS];   // the pair's pose ring (the certificates recompute where a query was at its last search)
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
-    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level) e = out[i]; }
+    const m3d_gf4 prev = m3d_as_global(LEAN ? nullptr : J.prev_pts);   // (a lean registration has one level)
+    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level || (!LEAN && J.prev_pts)) e = out[i]; }
     if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform; the loads above are in flight across it)
     if (i < n) {
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
         if (first_of_level) {
-            if (m3d_finite3(ux, uy, uz)) cls = 2; else out[i].x = -1;
+            if (m3d_finite3(ux, uy, uz)) {
+                cls = 2;
+                if (!LEAN && J.prev_pts && e.x >= 0) {   // the coarser level's match seeds this level's first search when it lies inside the new neighbourhood
+                    const float4 q1 = m3d_ld(prev, (size_t)e.x);
+                    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+                    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float reach = A.seed_reach * g.leaf;
+                    if (dd1 < reach * reach) { cls = 1; dseed = dd1; }
+                }
+            } else out[i].x = -1;
         } else {
             bool certified; float4 q1;
             cls = m3d_classify(g, pts, out, cache, s_ring, itq, p, i, e, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, sit);
@@ -1276,14 +1286,24 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     __shared__ float s_ring[M3D_RING_FLOATS];
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
-    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level) e = out[i]; }
+    const m3d_gf4 prev = m3d_as_global(J.prev_pts);
+    if (i < n) { p = m3d_ld3(src, (size_t)i); if (!first_of_level || J.prev_pts) e = out[i]; }
     if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform)
     if (i < n) {
         ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
         uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
         uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
         if (first_of_level) {
-            if (m3d_finite3(ux, uy, uz)) cls = 2; else if (sub == 0) out[i].x = -1;
+            if (m3d_finite3(ux, uy, uz)) {
+                cls = 2;
+                if (J.prev_pts && e.x >= 0) {   // (as in k_nn_iter: the coarser level's match as a seed)
+                    const float4 q1 = m3d_ld(prev, (size_t)e.x);
+                    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+                    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float reach = A.seed_reach * g.leaf;
+                    if (dd1 < reach * reach) { cls = 1; dseed = dd1; }
+                }
+            } else if (sub == 0) out[i].x = -1;
         } else {
             bool certified; float4 q1;
             cls = m3d_classify(g, pts, out, cache, s_ring, itq, p, i, e, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, 0);   // (the eight lanes of a group store the same correction, if any)

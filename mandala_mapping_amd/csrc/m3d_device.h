@@ -151,6 +151,9 @@ struct M3dJob {            // one pair at one level
     const uint32_t* src_order; // the source's 256-point blocks, most crowded first: k_nn_iter starts its long-running blocks first (or null)
     const uint32_t* src_dyn;   // M3dLevelMeta of the source's finest level (n_src, error state): read by k_patch_jobs
     float dmax;                // max_corr_dist of this level (k_patch_jobs derives the fixed-point exponents from it and the target's lbound)
+    const float4* prev_pts;    // a level behind the first of a pyramid: the PREVIOUS level's sorted points (the matches the last iteration of that level left index
+                               // them): a query's old match, when it lies within one voxel edge of this level, bounds this level's first search (a seed
+                               // only bounds: same result); null on the first level
     float* ring;               // [32][12] the pair's pose ring (icp.hip: m3d_cert_state): float poses {R row-major, t} of its last 32 iterations
     int32_t coop_always;       // k_patch_jobs: 1 = the target level is crowded (more than M3D_COOP_DENSITY points per occupied voxel: a coarse level of a dense
                                // map): every search of k_nn_iter<false> is walked eight lanes per query and none is binned to tiles (they cannot be staged)

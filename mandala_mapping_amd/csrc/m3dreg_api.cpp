@@ -736,6 +736,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
             J.pivot_rel_tol = P.pivot_rel_tol;
             J.st = h->d_states + i;
             J.ring = h->d_ring + size_t(i) * 32 * 12;
+            J.prev_pts = (l > 0 && P.iterations[l - 1] > 0) ? t->lv[l - 1].pts : nullptr;   // (the coarser level ran: its last iteration left a match for every query)
             J.trace = (i == 0) ? h->d_trace : nullptr;
         }
         M3dPairState& S = h->h_states[i];
@@ -1894,6 +1895,7 @@ int m3dreg_debug_accumulate(m3dreg_handle* h, const m3dreg_cloud* source, const 
     int max_n_src = 0, max_n_tgt = 0;
     if ((rc = build_jobs(h, &p, 1, max_n_src, max_n_tgt))) return rc;
     if ((rc = ensure_match(h, 1, max_n_src, max_n_tgt))) return rc;
+    h->h_jobs[size_t(level) * h->cap_pairs].prev_pts = nullptr;   // (no coarser level ran before this launch: the match array holds nothing to seed from)
     const M3dJob* hj = &h->h_jobs[size_t(level) * h->cap_pairs];
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, hj, sizeof(M3dJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_states, h->h_states, sizeof(M3dPairState), hipMemcpyHostToDevice, h->stream));
