@@ -17,8 +17,13 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no exceptions cross the boundary, every function
  *     returns an int status (0 = M3DREG_OK, <0 = m3dreg_error).
- *   - One handle = one device + one HIP stream; a handle is not thread-safe, different handles are
- *     independent (no global mutable state).
+ *   - Threading: one handle = one device + one HIP stream + the state of one batch; a handle is not
+ *     thread-safe, different handles are independent. No global mutable state shapes a result or a
+ *     schedule (ABI 5; the only process-wide word is a creation counter that places a handle's pairs
+ *     on the XCDs). What a registration launches is a function of the batch — with one documented
+ *     exception, per handle: it remembers at which pyramid levels its last finished batch met a crowded
+ *     target and launches the crowded-level search kernel only there (a handle's first batch: at every
+ *     coarse level). A wrong guess costs microseconds, never a bit.
  *   - Poses map SOURCE-frame points into the TARGET frame: p_target = T * p_source.
  *   - All results are bit-reproducible: they do not depend on launch geometry, scheduling or
  *     atomics order (integer fixed-point normal-equation sums).
