@@ -777,6 +777,28 @@ def test_full_size_pairs_equal_the_oracle(reg, orc, which):
     assert rot < 0.1 and tra < 0.006, (rot, tra)
 
 
+@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
+def test_pose_ring_wraps_within_one_level(reg, orc, monkeypatch, metric):
+    """The 8-byte per-query record keeps the iteration of a query's last real search modulo 32 and recomputes where the query was from the pair's pose
+    ring (icp.hip: m3d_cert_state). 75 fixed iterations on ONE level: queries that stay certified for 32 iterations meet their own slot again — the record is
+    then stale by construction and the query must search — twice over. Every per-iteration pose equals the oracle's, with the fused late launches
+    and without them, through the tiles and through the global walk."""
+    src, tgt, _ = synth.hdl32_pair(500, 71, 72, dx=0.2, dy=0.05, dyaw_deg=1.5)
+    p = _params(leaf=0.15, iterations=75, max_corr_dist=0.5, metric=metric, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    T2, st2, tr2 = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True), trace_cap=128)
+    assert st2.iterations == 75
+    for env in ({}, {"M3DREG_FUSE_FROM": "0"}, {"M3DREG_TILES": "0", "M3DREG_LEAN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        R = reg.Registrar(p)
+        cs, ct = R.clouds([src, tgt], source_only=[True, False])
+        T1, st1 = R.align(cs, ct)
+        assert np.array_equal(R.trace(), tr2) and np.array_equal(T1, T2), env
+        _same_stats(st1, st2)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_device_density_is_the_lpt_cost(reg):
     """m3dreg_cloud_density (the bucketing pipeline's sum of squared voxel populations / finite points) equals synth.crowdedness — the numpy estimate the
     LPT sharding of config 4 was tabulated with (mandala_mapping_amd/config4_costs.json) — for full targets and source-only clouds alike, and the table's
