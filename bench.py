@@ -536,9 +536,11 @@ def main():
             "ms_bucketing_batch": buck_ms / max(1, buck_n), "ms_bucketing_batch_alone": alone_bucket_ms,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
             "iterations_executed_pair0": int(last["st"][0].iterations),
-            # ONE definition, kept from round to round: frac = the correspondence step INSIDE the timed region (what the timed region ran, several
-            # chains sharing the GPU, sampled brackets); `alone` = the same bracket with nothing else on the GPU; `iteration` = a whole linearisation
-            # of the shipped schedule (fused late launches included) on its algorithmic bytes
+            # roofline_definition_version 2 (rounds 3-4): frac = the correspondence step INSIDE the timed region (what the timed region ran, several chains
+            # sharing the GPU, sampled brackets); `alone` = the same bracket with nothing else on the GPU; `iteration` = a whole linearisation of the
+            # shipped schedule (fused late launches included) on its algorithmic bytes. Version 1 (rounds 1-2) printed the ALONE bracket as `frac`, and
+            # `value` was one timed region instead of the median block: compare frac across rounds 2 -> 3 through `alone`, not through `frac`.
+            "roofline_definition_version": 2,
             "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (+ k_nn_fallback where the handle launches it): the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
                                                     "runs as the launch chain; un-bracketed iterations >= 10 of a level run fused with the reduction as k_icp_late: see `iteration`)",
                          "achieved": in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": in_region / HBM_PEAK_GBS,
