@@ -278,34 +278,40 @@ __device__ __forceinline__ void m3d_accumulate_match(ACC& acc, float ux, float u
         Jv[0] = wy * nz - wz * ny; Jv[1] = wz * nx - wx * nz; Jv[2] = wx * ny - wy * nx;
         Jv[3] = nx; Jv[4] = ny; Jv[5] = nz;
         const float r = nx * ex + ny * ey + nz * ez;
-        // H(k,l), k <= l, at hslot21(k, l) (row-major upper triangle; scales: rot-rot S[0], rot-trans S[1], trans-trans S[2]); then g, ssr, count
-        acc.template add<0>(m3d_quant(Jv[0] * Jv[0], S[0]));
-        acc.template add<1>(m3d_quant(Jv[0] * Jv[1], S[0]));
-        acc.template add<2>(m3d_quant(Jv[0] * Jv[2], S[0]));
-        acc.template add<3>(m3d_quant(Jv[0] * Jv[3], S[1]));
-        acc.template add<4>(m3d_quant(Jv[0] * Jv[4], S[1]));
-        acc.template add<5>(m3d_quant(Jv[0] * Jv[5], S[1]));
-        acc.template add<6>(m3d_quant(Jv[1] * Jv[1], S[0]));
-        acc.template add<7>(m3d_quant(Jv[1] * Jv[2], S[0]));
-        acc.template add<8>(m3d_quant(Jv[1] * Jv[3], S[1]));
-        acc.template add<9>(m3d_quant(Jv[1] * Jv[4], S[1]));
-        acc.template add<10>(m3d_quant(Jv[1] * Jv[5], S[1]));
-        acc.template add<11>(m3d_quant(Jv[2] * Jv[2], S[0]));
-        acc.template add<12>(m3d_quant(Jv[2] * Jv[3], S[1]));
-        acc.template add<13>(m3d_quant(Jv[2] * Jv[4], S[1]));
-        acc.template add<14>(m3d_quant(Jv[2] * Jv[5], S[1]));
-        acc.template add<15>(m3d_quant(Jv[3] * Jv[3], S[2]));
-        acc.template add<16>(m3d_quant(Jv[3] * Jv[4], S[2]));
-        acc.template add<17>(m3d_quant(Jv[3] * Jv[5], S[2]));
-        acc.template add<18>(m3d_quant(Jv[4] * Jv[4], S[2]));
-        acc.template add<19>(m3d_quant(Jv[4] * Jv[5], S[2]));
-        acc.template add<20>(m3d_quant(Jv[5] * Jv[5], S[2]));
-        acc.template add<21>(m3d_quant(Jv[0] * r, S[3]));
-        acc.template add<22>(m3d_quant(Jv[1] * r, S[3]));
-        acc.template add<23>(m3d_quant(Jv[2] * r, S[3]));
-        acc.template add<24>(m3d_quant(Jv[3] * r, S[4]));
-        acc.template add<25>(m3d_quant(Jv[4] * r, S[4]));
-        acc.template add<26>(m3d_quant(Jv[5] * r, S[4]));
+        // H(k,l), k <= l, at hslot21(k, l) (row-major upper triangle; scales: rot-rot S[0], rot-trans S[1], trans-trans S[2]); then g, ssr, count.
+        // The scale of a term is folded into ONE of its factors: S = 2^e, so (a * b) * S and (a * S) * b are the same float wherever neither is subnormal
+        // or overflows — and a product that is subnormal before the scaling is below 2^-96 after it: both forms quantise to 0. 13 multiplies for 29.
+        const float a0 = Jv[0] * S[0], a1 = Jv[1] * S[0], a2 = Jv[2] * S[0];     // rot-rot
+        const float b0 = Jv[0] * S[1], b1 = Jv[1] * S[1], b2 = Jv[2] * S[1];     // rot-trans
+        const float c3 = Jv[3] * S[2], c4 = Jv[4] * S[2], c5 = Jv[5] * S[2];     // trans-trans
+        const float r3 = r * S[3], r4 = r * S[4];
+        acc.template add<0>((int)rintf(a0 * Jv[0]));
+        acc.template add<1>((int)rintf(a0 * Jv[1]));
+        acc.template add<2>((int)rintf(a0 * Jv[2]));
+        acc.template add<3>((int)rintf(b0 * Jv[3]));
+        acc.template add<4>((int)rintf(b0 * Jv[4]));
+        acc.template add<5>((int)rintf(b0 * Jv[5]));
+        acc.template add<6>((int)rintf(a1 * Jv[1]));
+        acc.template add<7>((int)rintf(a1 * Jv[2]));
+        acc.template add<8>((int)rintf(b1 * Jv[3]));
+        acc.template add<9>((int)rintf(b1 * Jv[4]));
+        acc.template add<10>((int)rintf(b1 * Jv[5]));
+        acc.template add<11>((int)rintf(a2 * Jv[2]));
+        acc.template add<12>((int)rintf(b2 * Jv[3]));
+        acc.template add<13>((int)rintf(b2 * Jv[4]));
+        acc.template add<14>((int)rintf(b2 * Jv[5]));
+        acc.template add<15>((int)rintf(c3 * Jv[3]));
+        acc.template add<16>((int)rintf(c3 * Jv[4]));
+        acc.template add<17>((int)rintf(c3 * Jv[5]));
+        acc.template add<18>((int)rintf(c4 * Jv[4]));
+        acc.template add<19>((int)rintf(c4 * Jv[5]));
+        acc.template add<20>((int)rintf(c5 * Jv[5]));
+        acc.template add<21>((int)rintf(Jv[0] * r3));
+        acc.template add<22>((int)rintf(Jv[1] * r3));
+        acc.template add<23>((int)rintf(Jv[2] * r3));
+        acc.template add<24>((int)rintf(Jv[3] * r4));
+        acc.template add<25>((int)rintf(Jv[4] * r4));
+        acc.template add<26>((int)rintf(Jv[5] * r4));
         acc.template add<27>(m3d_quant(r * r, S[5]));
         acc.template add<28>(1);
     } else {
