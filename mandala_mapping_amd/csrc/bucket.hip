@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__
     // 1. own bucket heads, in sorted order; their bucket coordinates (one point load per head)
     uint32_t nheads = 0;
 #pragma unroll
-    for (int r = 0; r < M3D_TILE_PTS / 256; r++) {
+    for (int r = 0; r < (M3D_TILE_PTS + 255) / 256; r++) {   // (any tile size: the last round is partial)
         const int j = p0 + r * 256 + tid;
         bool head = false;
         if (j < p1) { const uint32_t k = skey[j]; head = (j == 0) || ((skey[j - 1] >> 3) != (k >> 3)); }
