@@ -678,7 +678,10 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // their queries would all take the fallback list: config 5 with lean on every level took 6.5 instead of 5.9 ms)
     // (one-level registrations only; on the finest level of a pyramid it was measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would leave every query pending)
     const bool lean_here = h->params.n_levels == 1;
-    w.tiles = h->tiles; w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
+    // (tile images exist on a target's FINEST level only: on a pyramid's coarser levels nothing is ever binned, and an empty k_nn_tiles launch costs its 5 us in
+    // every one of their iterations — 16 launches of a config-5 registration, 60 of config 2's)
+    w.tiles = (h->tiles && (level < 0 || level == h->params.n_levels - 1)) ? 1 : 0;
+    w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
     // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels, where the handle's last finished batch had a crowded target level (and on a handle's
     // first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level. The ONE piece of
     // adaptive state the library keeps (per handle, include/m3dreg.h "Threading"): a wrong guess costs time, never a bit — without the launch
