@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -2047,15 +2048,18 @@ void run_shard(MultiWorker* w, const m3dreg_pair_desc* pairs, const std::vector<
         // one cloud, uploaded and bucketed once; src_of / tgt_of: the cloud of pair j
         std::vector<m3dreg_cloud_desc> descs;
         std::vector<size_t> src_of(k), tgt_of(k);
+        std::unordered_map<int32_t, size_t> group_cloud;   // target group -> its (one) cloud of this shard
         descs.reserve(2 * k);
         for (size_t j = 0; j < k; j++) {
             const m3dreg_pair_desc& P = pairs[idx[j]];
             m3dreg_cloud_desc d = P.source; d.source_only = 1;
             src_of[j] = descs.size(); descs.push_back(d);
             size_t t = size_t(-1);
-            if (P.target_group > 0)
-                for (size_t j2 = 0; j2 < j && t == size_t(-1); j2++) if (pairs[idx[j2]].target_group == P.target_group) t = tgt_of[j2];
-            if (t == size_t(-1)) { d = P.target; d.source_only = 0; t = descs.size(); descs.push_back(d); }
+            if (P.target_group > 0) { const auto f = group_cloud.find(P.target_group); if (f != group_cloud.end()) t = f->second; }
+            if (t == size_t(-1)) {
+                d = P.target; d.source_only = 0; t = descs.size(); descs.push_back(d);
+                if (P.target_group > 0) group_cloud[P.target_group] = t;
+            }
             tgt_of[j] = t;
         }
         const size_t nc = descs.size();
@@ -2159,13 +2163,17 @@ int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_
         // units of the assignment: a pair, or a whole target group (its target counted once: it is uploaded and bucketed once)
         std::vector<size_t> unit_of(n_pairs), usize;
         std::vector<double> cost;
-        std::vector<int32_t> ugroup; std::vector<size_t> ufirst;
+        std::vector<size_t> ufirst;
+        std::unordered_map<int32_t, size_t> unit_of_group;
         for (size_t i = 0; i < n_pairs; i++) {
             const int32_t gid = pairs[i].target_group;
             if (gid < 0) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: negative target_group");
             size_t u = size_t(-1);
-            if (gid > 0) for (size_t q = 0; q < ugroup.size() && u == size_t(-1); q++) if (ugroup[q] == gid) u = q;
-            if (u == size_t(-1)) { u = cost.size(); cost.push_back(double(pairs[i].target.n)); usize.push_back(0); ugroup.push_back(gid > 0 ? gid : -1); ufirst.push_back(i); }
+            if (gid > 0) { const auto f = unit_of_group.find(gid); if (f != unit_of_group.end()) u = f->second; }
+            if (u == size_t(-1)) {
+                u = cost.size(); cost.push_back(double(pairs[i].target.n)); usize.push_back(0); ufirst.push_back(i);
+                if (gid > 0) unit_of_group[gid] = u;
+            }
             else if (!same_payload(pairs[ufirst[u]].target, pairs[i].target)) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: the pairs of a target_group must name the same target payload");
             unit_of[i] = u; cost[u] += double(pairs[i].source.n); usize[u]++;
         }
