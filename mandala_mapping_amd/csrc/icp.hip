@@ -1387,8 +1387,18 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const bool have = q < qn;
         const uint32_t sub = (uint32_t)tid % lstride;   // (lstride lanes share a record: a whole number of groups per wave, idle groups only at the end of the item)
         // the record first: its loads are in flight while the image is staged
+#ifdef M3D_EXP_UNIFORM   // (timing experiment only — WRONG results: every lane of a wave searches lane 0's query: what would the search cost without divergence?)
+        float4 r4 = have ? m3d_ld(rec, (size_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r4.x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r4.x))); r4.y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r4.y)));
+        r4.z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r4.z)));
+        asm volatile("" : "+v"(r4.x), "+v"(r4.y), "+v"(r4.z));
+        float dseed = have ? recd[q] : 0.f;
+        dseed = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(dseed)));
+        asm volatile("" : "+v"(dseed));
+#else
         const float4 r4 = have ? m3d_ld(rec, (size_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float dseed = have ? recd[q] : 0.f;
+#endif
         const uint32_t w = __float_as_uint(r4.w);
         const bool seeded = (w >> 31) != 0u;
         M3dTileQ Q;
