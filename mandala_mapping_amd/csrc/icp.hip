@@ -419,18 +419,19 @@ typedef const __attribute__((address_space(3))) m3d_f32x4* m3d_lf4;
 __device__ __forceinline__ float4 m3d_ld(m3d_lf4 p, size_t i) { const m3d_f32x4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 // candidates [t, t1) of the sorted target points against the query: exact argmin on the packed (d2, input index) key.
+template <int G = 4>
 __device__ __forceinline__ void m3d_scan_range(m3d_gf4 pts, uint32_t t, const uint32_t t1, float ux, float uy, float uz, M3dWalk& W, int sit) {
-    for (; t < t1; t += 4) {
+    for (; t < t1; t += G) {
         M3D_BT_COUNT(W, bt_trips);
         M3D_STAT(sit, 12);
         M3D_STATW(sit, 14);
-        // four independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
+        // G (four; the dense cooperative walk: eight) independent 16-B gathers per wait; slots past the end of the run re-read its last point and count as +inf
         const uint32_t last = t1 - 1u - t;   // >= 0
-        uint32_t idx[4]; float4 c4[4];
+        uint32_t idx[G]; float4 c4[G];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { idx[j] = t + min((uint32_t)j, last); c4[j] = m3d_ld(pts, idx[j]); }
+        for (int j = 0; j < G; j++) { idx[j] = t + min((uint32_t)j, last); c4[j] = m3d_ld(pts, idx[j]); }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < G; j++) {
             const float ex = ux - c4[j].x, ey = uy - c4[j].y, ez = uz - c4[j].z;
             const float dd = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
             const uint32_t db = (j == 0 || (uint32_t)j <= last) ? __float_as_uint(dd) : M3D_INF_BITS;
@@ -796,7 +797,8 @@ struct M3dNnArgs {
     M3dPairState* states;              // [n_pairs] == jobs[pair].st: addressed from the kernel argument, so the pose loads do not wait for the job's
     int lane_min;                      // a block with at least this many queries to search walks one query per lane, else 8 lanes per query
     int rot;                           // XCD rotation of the block -> pair map (m3d_map_block)
-    int coop_kernel;                   // 1 = k_nn_coop follows this launch: the pairs whose target level is crowded (M3dJob::coop_always) are ITS work, k_nn_iter leaves them alone
+    int coop_kernel;                   // 1 = k_nn_coop follows this launch: the pairs whose target level is dense (M3dJob::coop_always) are ITS work, k_nn_iter leaves them alone;
+                                       // 2 = k_nn_coop is the only search kernel of the iteration (every pair of the handle's last batch was dense at this level)
     // the LDS-staged search: a block with many queries to search BINS them by the target tile that owns their home bucket
     // (k_nn_iter), k_nn_tiles then answers every tile's queries from LDS
     int tiles;                         // 1 = on
@@ -897,11 +899,137 @@ __device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_G
     return m3d_classify_loaded(g, out, cache, i, mp, ux, uy, uz, dmax2, certify, seed_reach, s0, q1, dseed, certified, sit);
 }
 
+// ---- the crowded rows of a query on a DENSE level (k_nn_coop: a map's coarse levels, > 48 points per voxel), by the 8 lanes of its group ------------------
+// The rows the lanes set aside (at most 4 each) go into a table in LDS and are treated as ONE list of chunks, 64 at a time:
+//   A  lane j loads the boxes of chunks j, j + 8, ... of the block (eight independent 32-B loads, two waits) and files the ones that are not
+//      provably farther than the bound in the group's survivor list (ballot + popcount: same slots in every run);
+//   B  the group picks the survivor whose box is nearest and compares its 16 points together, two per lane — one gather trip leaves a
+//      bound that is close to the final one;
+//   C  lane j takes survivors j, j + 8, ...: those still inside the bound are gathered eight points per wait, the others only leave their
+//      box distance in `sec`; the group agrees on the bound after every round.
+// Rounds 1-3 walked row after row, every lane its chunks j, j + 8, ... one after the other (box, wait, four gather trips of four, wait ...):
+// 40-60 dependent round trips per query at config 5's 0.4 m level, where this takes ~10. The candidates compared are the same kind of
+// set as before — a chunk is skipped only against a bound that some compared candidate met, every point is compared by exactly one lane —
+// so the argmin (and its tie rule) is the spec's; `sec` stays a lower bound of every non-winner.
+#define M3D_DENSE_SURV 64
+struct M3dCoopLds { uint2 rows[32]; uint2 surv[M3D_DENSE_SURV]; };   // per group: {first, end} sorted position of a row; {chunk | row << 27, bits of the box distance}
+__device__ __forceinline__ float m3d_group_min(float v) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float m3d_box_d2(const float4& mn, const float4& mx, float vx, float vy, float vz) {
+    const float dx = fmaxf(fmaxf(mn.x - vx, vx - mx.x), 0.f), dy = fmaxf(fmaxf(mn.y - vy, vy - mx.y), 0.f), dz = fmaxf(fmaxf(mn.z - vz, vz - mx.z), 0.f);
+    return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ void m3d_coop_dense_rows(m3d_gf4 pts, m3d_gf4 cbox, const M3dDefer& D, int hsub, float vx, float vy, float vz, M3dWalk& W, int sub, int g0,
+                                                    M3dCoopLds* gl, int sit) {
+    static_assert(M3D_CHUNK == 16, "two points per lane in step B, two gather trips of eight in step C");
+    const float inf = __uint_as_float(M3D_INF_BITS);
+    // the table of rows, the home bucket's lane first (its rows hold the answer most of the time): deterministic slots
+    const int rot = (sub - hsub) & 7;                  // this lane's place in the order
+    int rbase = 0;
+    uint32_t T = 0;                                    // chunks of all rows together
+    {
+        const int nd = D.n;
+        uint32_t nch = 0;
+        if (nd > 0) nch += (D.e0 - 1u) / M3D_CHUNK - D.b0 / M3D_CHUNK + 1u;
+        if (nd > 1) nch += (D.e1 - 1u) / M3D_CHUNK - D.b1 / M3D_CHUNK + 1u;
+        if (nd > 2) nch += (D.e2 - 1u) / M3D_CHUNK - D.b2 / M3D_CHUNK + 1u;
+        if (nd > 3) nch += (D.e3 - 1u) / M3D_CHUNK - D.b3 / M3D_CHUNK + 1u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                  // (8 shuffles each: lane order -> rotated order)
+            const int ndk = __shfl(nd, g0 + ((hsub + k) & 7));
+            const uint32_t nck = (uint32_t)__shfl((int)nch, g0 + ((hsub + k) & 7));
+            if (k < rot) rbase += ndk;
+            T += nck;
+        }
+        if (nd > 0) gl->rows[rbase] = make_uint2(D.b0, D.e0);
+        if (nd > 1) gl->rows[rbase + 1] = make_uint2(D.b1, D.e1);
+        if (nd > 2) gl->rows[rbase + 2] = make_uint2(D.b2, D.e2);
+        if (nd > 3) gl->rows[rbase + 3] = make_uint2(D.b3, D.e3);
+    }
+    if (T == 0u) return;                               // (uniform inside a group)
+    W.any_point = true;
+    __builtin_amdgcn_wave_barrier();
+    // this lane's cursor into the list of chunks: row, its first chunk, the list index of that chunk, its chunk count
+    int row = 0;
+    uint2 rr = gl->rows[0];
+    uint32_t rc0 = rr.x / M3D_CHUNK, rn = (rr.y - 1u) / M3D_CHUNK - rc0 + 1u, rp = 0u;
+#pragma unroll 1
+    for (uint32_t blk0 = 0; blk0 < T; blk0 += 64u) {   // (uniform inside a group)
+        uint32_t ns = 0;                               // survivors of this block (uniform inside a group)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t code[4]; float4 mn[4], mx[4]; bool val[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = blk0 + 8u * (uint32_t)(4 * half + j) + (uint32_t)sub;
+                val[j] = i < T;
+                uint32_t c = rc0;
+                if (val[j]) {
+                    while (i >= rp + rn) { rp += rn; row++; rr = gl->rows[row]; rc0 = rr.x / M3D_CHUNK; rn = (rr.y - 1u) / M3D_CHUNK - rc0 + 1u; }
+                    c = rc0 + (i - rp);
+                }
+                code[j] = c | ((uint32_t)row << 27);
+                mn[j] = m3d_ld(cbox, 2 * (size_t)c); mx[j] = m3d_ld(cbox, 2 * (size_t)c + 1);   // (an idle slot re-reads a box of the lane's row)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                M3D_BT_COUNT(W, bt_chunks);
+                const float bd = m3d_box_d2(mn[j], mx[j], vx, vy, vz);
+                const bool live = val[j] && !(bd > W.bound);
+                if (val[j] && !live) W.sec = min(W.sec, __float_as_uint(bd));
+                const uint32_t bits = (uint32_t)(__ballot(live) >> g0) & 0xFFu;
+                if (live) gl->surv[ns + (uint32_t)__popc(bits & ((1u << sub) - 1u))] = make_uint2(code[j], __float_as_uint(bd));
+                ns += (uint32_t)__popc(bits);
+            }
+        }
+        if (ns == 0u) continue;
+        __builtin_amdgcn_wave_barrier();
+        // B: the nearest survivor, by all eight lanes
+        uint32_t e_done = 0xFFFFFFFFu;
+        {
+            float mb = inf; uint32_t me = 0u;
+            for (uint32_t e = (uint32_t)sub; e < ns; e += 8u) { const float bd = __uint_as_float(gl->surv[e].y); if (bd < mb) { mb = bd; me = e; } }
+            const float gm = m3d_group_min(mb);
+            const uint32_t who = (uint32_t)(__ballot(mb == gm && mb < inf) >> g0) & 0xFFu;
+            if (who != 0u && !(gm > W.bound)) {
+                e_done = (uint32_t)__shfl((int)me, g0 + (__ffs((int)who) - 1));
+                const uint32_t cd = gl->surv[e_done].x;
+                const uint2 r2 = gl->rows[cd >> 27];
+                const uint32_t c = cd & 0x7FFFFFFu;
+                const uint32_t s0 = max(r2.x, c * M3D_CHUNK) + 2u * (uint32_t)sub, e0 = min(r2.y, (c + 1u) * M3D_CHUNK);
+                if (s0 < e0) m3d_scan_range<4>(pts, s0, min(s0 + 2u, e0), vx, vy, vz, W, sit);
+                W.bound = m3d_group_min(fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f));
+            }
+        }
+        // C: the other survivors, one per lane and round
+#pragma unroll 1
+        for (uint32_t e00 = 0; e00 < ns; e00 += 8u) {
+            const uint32_t e = e00 + (uint32_t)sub;
+            if (e < ns && e != e_done) {
+                const uint2 sv = gl->surv[e];
+                const float bd = __uint_as_float(sv.y);
+                if (bd > W.bound) W.sec = min(W.sec, sv.y);
+                else {
+                    const uint2 r2 = gl->rows[sv.x >> 27];
+                    const uint32_t c = sv.x & 0x7FFFFFFu;
+                    m3d_scan_range<8>(pts, max(r2.x, c * M3D_CHUNK), min(r2.y, (c + 1u) * M3D_CHUNK), vx, vy, vz, W, sit);
+                }
+            }
+            W.bound = m3d_group_min(fminf(W.bound, m3d_key_d2(W.bkey) * 1.0001f));
+        }
+        __builtin_amdgcn_wave_barrier();   // (the list is rewritten by the next block)
+    }
+}
+
 // One query walked by the 8 lanes of a group (sub = lane & 7 holds one bucket of the 2x2x2): nearest row of every bucket,
 // bound exchange, the other rows, shuffle merge. Every lane of the wave must call it (act = this group has a query);
 // returns the match (>= 0), -1 or M3D_NN_NONE_CACHED on every lane of the group; sec / code for the state arrays.
+template <bool DENSE = false>
 __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d_gf4 pts, m3d_gf4 cbox, m3d_gu32 bigcum, float dmax2, bool act, bool seeded,
-                                              float vx, float vy, float vz, float dseed, int sub, long long& code, float& sec, int sit) {
+                                              float vx, float vy, float vz, float dseed, int sub, long long& code, float& sec, int sit, M3dCoopLds* gl = nullptr) {
     M3dQuery Q;
     M3dWalk W; m3d_walk_init(W, dmax2);
     M3dDefer D; D.b0 = D.e0 = D.b1 = D.e1 = D.b2 = D.e2 = D.b3 = D.e3 = 0u; D.n = 0;
@@ -963,6 +1091,8 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
             hsub = hx | (hy << nbx) | (hz << (nbx + nby));
         }
         hsub = __shfl(hsub, g0);   // (group-uniform by construction; taken from the group's first lane so that an idle group agrees with itself too)
+        if (DENSE) m3d_coop_dense_rows(pts, cbox, D, hsub, vx, vy, vz, W, sub, g0, gl, sit);
+        else
 #pragma unroll 1
         for (int L0 = 0; L0 < 8; L0++) {
             const int L = (hsub + L0) & 7;
@@ -1279,7 +1409,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
 // level is not crowded (and k_nn_iter's where it is). Every lane of a group classifies its group's query (same addresses: one transaction).
 __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
     NN_SETUP();
-    if (!J.coop_always) return;   // (block-uniform)
+    if (A.coop_kernel != 2 && !J.coop_always) return;   // (block-uniform; 2: the only search kernel of this iteration, every pair is its work)
     {   // the crowded 256-point blocks first, like k_nn_iter: this workgroup is an eighth of one
         const uint32_t* ord = J.src_order;
         const int b256 = blk >> 3;
@@ -1316,7 +1446,8 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
         }
     }
     long long code; float sec;
-    const int m = m3d_coop_query(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, 0);
+    __shared__ M3dCoopLds s_coop[32];
+    const int m = m3d_coop_query<true>(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, 0, &s_coop[tid >> 3]);
     if (cls != 0 && sub == 0) {
         out[i] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
         if (m == M3D_NN_NONE_CACHED) cache[i] = code;
@@ -2062,9 +2193,14 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     // the queries k_nn_iter<lean> cannot bin (M3D_NN_PENDING) are walked by the reduction pass itself (its <.., true> instantiation) — which therefore
     // must be the solving kind (the pair's last workgroup zeroes the pending count: m3d_pair_tail): the sums-only launch of m3dreg_debug_accumulate runs
     // the full k_nn_iter
-    const bool lean_iter = w.tiles && !late && w.lean && fuse_solve && partials;
+    const bool lean_iter = w.tiles && !late && w.lean && fuse_solve && partials && A.coop_kernel != 2;
     const bool walk_in_acc = lean_iter;
-    if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
+    const bool coop_only = A.coop_kernel == 2;
+    if (coop_only) {   // a dense level (every pair's, by the handle's last batch): no classifying launch that finds nothing to do, no tile launch that finds no item
+        const int bpp_c = 8 * bpp_s;
+        hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A);
+        M3D_DBG(s, "k_nn_coop");
+    } else if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
     } else {
@@ -2076,7 +2212,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
             M3D_DBG(s, "k_nn_coop");
         }
     }
-    if (w.tiles && !late) {
+    if (w.tiles && !late && !coop_only) {
         hipLaunchKernelGGL(k_nn_tiles, dim3(M3D_TILE_GRID), dim3(M3D_TILE_THREADS), 0, s, d_jobs, first_of_level, A);
         M3D_DBG(s, "k_nn_tiles");
     }
@@ -2105,7 +2241,7 @@ __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pai
     g.hshift = (int32_t)M->dyn[2];
     J.tgt.g = g;
     if (M->dyn[7] == 0u) J.tgt.occ = nullptr;   // the grid has more bucket positions than the occupancy bitmap covers
-    J.coop_always = ((unsigned long long)(uint32_t)M->g.n_valid > (unsigned long long)M3D_COOP_DENSITY * (unsigned long long)M->dyn[0]) ? 1 : 0;
+    J.coop_always = m3d_dense_level((uint32_t)M->g.n_valid, M->dyn[0], (uint32_t)MS->g.n_valid) ? 1 : 0;
     if (J.coop_always) atomicOr(&J.st->coop_levels, 1u << (t / n_pairs));
     J.n_src = MS->g.n_valid;
     int32_t e[6]; float S[6];

@@ -155,13 +155,24 @@ struct M3dJob {            // one pair at one level
                                // them): a query's old match, when it lies within one voxel edge of this level, bounds this level's first search (a seed
                                // only bounds: same result); null on the first level
     float* ring;               // [32][12] the pair's pose ring (icp.hip: m3d_cert_state): float poses {R row-major, t} of its last 32 iterations
-    int32_t coop_always;       // k_patch_jobs: 1 = the target level is crowded (more than M3D_COOP_DENSITY points per occupied voxel: a coarse level of a dense
-                               // map): every search of k_nn_iter<false> is walked eight lanes per query and none is binned to tiles (they cannot be staged)
+    int32_t coop_always;       // k_patch_jobs: 1 = the target level is DENSE for this source (m3d_dense_level): every search is walked eight lanes per query,
+                               // nearest chunk first (k_nn_coop), none is walked by one lane and none is binned to tiles
     int32_t pad_;
 };
+// A target level is dense when a query's 27 voxels hold hundreds of candidates — more than M3D_COOP_DENSITY points per occupied voxel (a coarse level of a
+// pyramid) — or when it holds more than M3D_COOP_DENSITY_MAP points per voxel AND the target is a map, M3D_COOP_MAP_RATIO times the source and more: a tile
+// image is then staged for two dozen queries instead of five hundred, and one lane walks a hundred candidates alone. Measured (profiles/r04_dense_levels.txt):
+// config 5's 0.2 m level (35 per voxel) 0.070 -> 0.050 ms per iteration, its 0.1 m level (8 per voxel, 2 M : 100 k) 87 + 183 -> 50 us for the first
+// iteration; config 2's 0.8 m level (70 k : 70 k) gains 4 %, its 0.4 m level (10 per voxel) would LOSE 5 %: hence the ratio.
 #ifndef M3D_COOP_DENSITY
-#define M3D_COOP_DENSITY 48
+#define M3D_COOP_DENSITY 24
 #endif
+#define M3D_COOP_DENSITY_MAP 6
+#define M3D_COOP_MAP_RATIO 4
+__host__ __device__ inline bool m3d_dense_level(uint32_t n_tgt, uint32_t occupied_voxels, uint32_t n_src) {
+    const unsigned long long n = n_tgt, v = occupied_voxels;
+    return n > (unsigned long long)M3D_COOP_DENSITY * v || (n > (unsigned long long)M3D_COOP_DENSITY_MAP * v && n >= (unsigned long long)M3D_COOP_MAP_RATIO * (unsigned long long)n_src);
+}
 
 // ---- spec primitives shared by every kernel (operation order is normative) --------
 __device__ __forceinline__ bool m3d_finite3(float x, float y, float z) {

@@ -121,6 +121,7 @@ struct m3dreg_handle {
     size_t pending_pairs = 0;
     bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
     uint32_t coop_seen = 0;
+    uint32_t coop_all = 0;         // ... and the levels at which EVERY pair of that batch had one
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
@@ -687,8 +688,10 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level. The ONE piece of
     // adaptive state the library keeps (per handle, include/m3dreg.h "Threading"): a wrong guess costs time, never a bit — without the launch
     // k_nn_iter<false> answers the crowded pairs itself, in eight passes per workgroup.
-    const bool coop_level = level >= 0 && level < h->params.n_levels - 1;
-    w.coop_kernel = (coop_level && (!h->coop_known || ((h->coop_seen >> level) & 1u))) ? 1 : 0;
+    // (round 4: on every level, the finest included — a 2 M-point map is dense for a 100 k-point scan at 0.1 m too, m3d_dense_level — and alone where every
+    // pair of the last batch was dense: k_nn_coop answers ordinary pairs as well, only slower)
+    const bool coop_level = level >= 0;
+    w.coop_kernel = !coop_level ? 0 : (h->coop_known && ((h->coop_all >> level) & 1u)) ? 2 : (!h->coop_known || ((h->coop_seen >> level) & 1u)) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
@@ -1081,9 +1084,9 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
         if (stats) stats_from_state(S, &stats[i]);
     }
     {
-        uint32_t seen = 0;
-        for (size_t i = 0; i < h->pending_pairs; i++) seen |= h->h_states[i].coop_levels;
-        h->coop_seen = seen; h->coop_known = true;
+        uint32_t seen = 0, all = 0xFFFFFFFFu;
+        for (size_t i = 0; i < h->pending_pairs; i++) { seen |= h->h_states[i].coop_levels; all &= h->h_states[i].coop_levels; }
+        h->coop_seen = seen; h->coop_all = h->pending_pairs ? all : 0u; h->coop_known = true;
     }
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
