@@ -342,6 +342,12 @@ def test_config5_dense_map_multiresolution(reg, orc):
     _same_stats(st1, st2)
     rot, tra = synth.pose_error(T1, Tgt)
     assert rot < 0.05 and tra < 0.01, (rot, tra)
+    # the SAME handle again: it now knows at which levels every pair of its last batch had a dense target (m3d_dense_level: the coarse levels of this map),
+    # and k_nn_coop is the only search kernel of their iterations (no classifying launch, no tile launch) — a different schedule, the same bits
+    for _ in range(2):
+        T3, st3 = R.align(cs, ct, T0)
+        assert np.array_equal(R.trace(), tr2) and np.array_equal(T3, T2)
+        _same_stats(st3, st2)
 
 
 def test_exact_distance_ties_go_to_the_lowest_input_index(reg, orc, monkeypatch):
