@@ -541,8 +541,8 @@ def main():
             # shipped schedule (fused late launches included) on its algorithmic bytes. Version 1 (rounds 1-2) printed the ALONE bracket as `frac`, and
             # `value` was one timed region instead of the median block: compare frac across rounds 2 -> 3 through `alone`, not through `frac`.
             "roofline_definition_version": 2,
-            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles (+ k_nn_fallback where the handle launches it): the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
-                                                    "runs as the launch chain; un-bracketed iterations >= 10 of a level run fused with the reduction as k_icp_late: see `iteration`)",
+            "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles: the correspondence step of one Gauss-Newton iteration, one event bracket (a bracketed iteration "
+                                                    "runs as the launch chain; un-bracketed iterations >= 8 of a level run fused with the reduction as k_icp_late: see `iteration`)",
                          "achieved": in_region, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": in_region / HBM_PEAK_GBS,
                          "avg_launch_ms": 1e3 * avg_launch_s, "launches_timed": launches, "concurrent_chains": D,
                          "frac_source": "hipEvent brackets inside the timed region (every --event-every-th iteration), on the library's stream",

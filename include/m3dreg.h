@@ -21,9 +21,11 @@
  *     thread-safe, different handles are independent. No global mutable state shapes a result or a
  *     schedule (ABI 5; the only process-wide word is a creation counter that places a handle's pairs
  *     on the XCDs). What a registration launches is a function of the batch — with one documented
- *     exception, per handle: it remembers at which pyramid levels its last finished batch met a crowded
- *     target and launches the crowded-level search kernel only there (a handle's first batch: at every
- *     coarse level). A wrong guess costs microseconds, never a bit.
+ *     exception, per handle: it remembers at which levels its last finished batch met a dense target
+ *     (more than 24 points per voxel, or a map: more than 6 and at least 4 x the source) in some / in
+ *     every pair and launches the dense-level search kernel only there (alone where it was every pair;
+ *     a handle's first batch: behind the ordinary one at every level). A wrong guess costs
+ *     microseconds, never a bit.
  *   - Poses map SOURCE-frame points into the TARGET frame: p_target = T * p_source.
  *   - All results are bit-reproducible: they do not depend on launch geometry, scheduling or
  *     atomics order (integer fixed-point normal-equation sums).
