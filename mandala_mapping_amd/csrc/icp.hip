@@ -2064,7 +2064,42 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     const int nW = min(s_cnt, M3D_LATE_CAP);   // (the cap cannot be exceeded: see launch_iteration)
     if (threadIdx.x < 16) s_T[threadIdx.x] = t_pre;
     long long* my_partial = partials + ((size_t)pair * bpp + blk) * M3D_PARTIAL_STRIDE;
-    {
+    // MANY uncertified queries in this workgroup (config 2's 0.2 m point-to-point level: neighbours on a scan ring are 2 cm apart, half of the certificates fail
+    // in every iteration — ~190 of a workgroup's 385 queries, six cooperative passes of 32): one query per lane, one pass. The streaming loop's sums are
+    // parked in LDS meanwhile (the walk needs their registers). Not on a dense level, where one lane's walk is hundreds of candidates long.
+#ifndef M3D_LATE_LANE_MIN
+#define M3D_LATE_LANE_MIN 96
+#endif
+    __shared__ long long s_park[32];
+    // (point-to-point only: with the 29 sums and the normals of point-to-plane the same code takes 193 VGPRs instead of 157 — two waves per SIMD instead of three
+    // for every launch of the headline's kernel)
+    if (METRIC == 0 && nW > M3D_LATE_LANE_MIN && !J.coop_always) {   // (uniform)
+        block_reduce_to_global<NACC>(acc, st->sums, nullptr, s_park, nullptr);
+        __syncthreads();   // (s_park is complete, the reduction's scratch is free again)
+        for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {   // (the walk alone: no sum is live in it)
+            const int e = s_list[w];
+            const int qi = e & 0x7FFFFFFF;
+            long long code = 0; float sec = 0.f;
+            const int mq = m3d_nn27_walk(g, tab, pts, cbox, bigcum, s_wu[0][w], s_wu[1][w], s_wu[2][w], dmax2, e < 0, s_wd[w], code, sec, 0);
+            out[qi] = (m3d_i32x2){ mq, m3d_cert_pack(sec, itq) };
+            if (mq == M3D_NN_NONE_CACHED) cache[qi] = code;
+            s_list[w] = mq;   // (this thread's own slot)
+        }
+        acc.clear();
+        for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
+            const int mq = s_list[w];
+            const float vx = s_wu[0][w], vy = s_wu[1][w], vz = s_wu[2][w];
+            if (mq >= 0) {
+                const float4 qm = m3d_ld(pts, (size_t)mq);
+                const float4 nm = (METRIC == 1) ? m3d_ld(nrm, (size_t)mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float ex = vx - qm.x, ey = vy - qm.y, ez = vz - qm.z;
+                const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                m3d_accumulate_match<METRIC, NACC>(acc, vx, vy, vz, qm, d2, nm, cx, cy, cz, S);
+            }
+        }
+        LATE_STAMP(3);
+        block_reduce_to_global<NACC>(acc, st->sums, my_partial, nullptr, s_park);
+    } else {
         const int sub = (int)threadIdx.x & 7;
         for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
             const int w = base + ((int)threadIdx.x >> 3);
