@@ -2073,6 +2073,8 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
     __shared__ long long s_park[32];
     // (point-to-point only: with the 29 sums and the normals of point-to-plane the same code takes 193 VGPRs instead of 157 — two waves per SIMD instead of three
     // for every launch of the headline's kernel)
+    // (and measured with it on the headline's batch: the two late iterations that have such workgroups took 92 / 82 instead of 75 / 57 us — its uncertified
+    // queries sit next to obstacles, in long rows)
     if (METRIC == 0 && nW > M3D_LATE_LANE_MIN && !J.coop_always) {   // (uniform)
         block_reduce_to_global<NACC>(acc, st->sums, nullptr, s_park, nullptr);
         __syncthreads();   // (s_park is complete, the reduction's scratch is free again)
