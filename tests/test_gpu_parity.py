@@ -435,6 +435,13 @@ def test_batch_mixing_crowded_and_ordinary_coarse_levels(reg, orc, n_pairs):
             To, sto, _ = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True))
             assert np.array_equal(Tb[k], To), k
             _same_stats(stb[k], sto)
+    # the dense pairs as a batch of their own, twice: the second time the handle knows that EVERY pair of its last batch had a dense coarse level and
+    # launches k_nn_coop alone there (no classifying launch) — several pairs in that schedule, the same bits
+    dense = [k for k in range(n_pairs) if k % 2 == 0]
+    for _ in range(2):
+        Td, std = R.align_batch([(clouds[k][0], clouds[k][1], None) for k in dense])
+        for j, k in enumerate(dense):
+            assert np.array_equal(Td[j], Tb[k]) and std[j].n_corr == stb[k].n_corr, k
 
 
 def test_config5_full_size_properties(reg):
