@@ -1447,7 +1447,12 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     }
     long long code; float sec;
     __shared__ M3dCoopLds s_coop[32];
-    const int m = m3d_coop_query<true>(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, 0, &s_coop[tid >> 3]);
+#ifdef M3D_STATS   // (scripts/walk_stats_c5.py: this launch's iteration is its statistics row)
+    const int sit_c = (int)st->iters;
+#else
+    const int sit_c = 0;
+#endif
+    const int m = m3d_coop_query<true>(g, tab, pts, cbox, bigcum, dmax2, cls != 0, cls == 1, ux, uy, uz, dseed, sub, code, sec, sit_c, &s_coop[tid >> 3]);
     if (cls != 0 && sub == 0) {
         out[i] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
         if (m == M3D_NN_NONE_CACHED) cache[i] = code;
