@@ -1459,6 +1459,83 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     }
 }
 
+// k_nn_coop_list: the same search for the iterations in which most queries of a dense level are CERTIFIED (config 5: 74 % at the end of the 0.4 m level,
+// 93-98 % at 0.2 / 0.1 m): k_nn_coop gives every query a group of eight lanes whether it searches or not, and a wave with one searching group of eight
+// runs the whole chain. Here a workgroup owns QPB queries, its first QPB lanes classify one each (k_nn_iter's way), the searchers are compacted into an
+// LDS list (one ballot per wave) and walked 32 at a time by all 256 lanes: QPB / 32 times fewer waves when few search, QPB / 32 passes one after the other
+// when all do (why the level's first iterations stay with k_nn_coop).
+template <int QPB>
+__global__ __launch_bounds__(256, 4) void k_nn_coop_list(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
+    static_assert(QPB == 64 || QPB == 128 || QPB == 256, "whole waves classify");
+    NN_SETUP();
+    if (A.coop_kernel != 2 && !J.coop_always) return;   // (block-uniform)
+    {   // the crowded 256-point blocks first
+        const uint32_t* ord = J.src_order;
+        constexpr int PER = 256 / QPB;
+        const int b256 = blk / PER;
+        if (ord && b256 < J.src_nblk) blk = (int)ord[b256] * PER + (blk % PER);
+    }
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_ring[M3D_RING_FLOATS];
+    __shared__ M3dCoopLds s_coop[32];
+    __shared__ int s_list[QPB];
+    __shared__ float s_wu[3][QPB], s_wd[QPB];
+    __shared__ int s_wn[4];
+    if (!first_of_level) { m3d_ring_to_lds(s_ring, A.ring + (size_t)pair * M3D_RING_FLOATS); __syncthreads(); }   // (block-uniform)
+    int cls = 0;
+    float ux = 0.f, uy = 0.f, uz = 0.f, dseed = 0.f;
+    const int i = blk * QPB + tid;
+    if (tid < QPB && i < n) {
+        const float4 p = m3d_ld3(src, (size_t)i);
+        m3d_i32x2 e = (m3d_i32x2){ -1, 0 };
+        if (!first_of_level || J.prev_pts) e = out[i];
+        ux = fmaf(R[0], p.x, fmaf(R[1], p.y, fmaf(R[2], p.z, tt[0])));
+        uy = fmaf(R[3], p.x, fmaf(R[4], p.y, fmaf(R[5], p.z, tt[1])));
+        uz = fmaf(R[6], p.x, fmaf(R[7], p.y, fmaf(R[8], p.z, tt[2])));
+        if (first_of_level) {
+            if (m3d_finite3(ux, uy, uz)) {
+                cls = 2;
+                if (J.prev_pts && e.x >= 0) {
+                    const float4 q1 = m3d_ld(m3d_as_global(J.prev_pts), (size_t)e.x);
+                    const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
+                    const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                    const float reach = A.seed_reach * g.leaf;
+                    if (dd1 < reach * reach) { cls = 1; dseed = dd1; }
+                }
+            } else out[i].x = -1;
+        } else {
+            bool certified; float4 q1;
+            cls = m3d_classify(g, pts, out, cache, s_ring, itq, p, i, e, ux, uy, uz, dmax2, A.certify, A.seed_reach, dseed, certified, q1, 0);
+        }
+    }
+    const unsigned long long bW = __ballot(cls != 0);
+    if (lane == 0) s_wn[wave] = (int)__popcll(bW);
+    __syncthreads();
+    int offW = 0, nW = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) offW += s_wn[w]; nW += s_wn[w]; }
+    if (cls != 0) {
+        const int w = offW + (int)__popcll(bW & ((1ull << lane) - 1ull));
+        s_list[w] = tid | (cls == 1 ? 256 : 0);
+        s_wu[0][w] = ux; s_wu[1][w] = uy; s_wu[2][w] = uz; s_wd[w] = dseed;
+    }
+    __syncthreads();
+    const int sub = tid & 7;
+    for (int base = 0; base < nW; base += 32) {   // uniform trip count: the shuffles inside need every lane
+        const int q = base + (tid >> 3);
+        const bool act = q < nW;
+        const int e = act ? s_list[q] : 0;
+        const int qi = blk * QPB + (e & 255);
+        const float vx = act ? s_wu[0][q] : 0.f, vy = act ? s_wu[1][q] : 0.f, vz = act ? s_wu[2][q] : 0.f;
+        long long code; float sec;
+        const int m = m3d_coop_query<true>(g, tab, pts, cbox, bigcum, dmax2, act, (e & 256) != 0, vx, vy, vz, act ? s_wd[q] : 0.f, sub, code, sec, 0, &s_coop[tid >> 3]);
+        if (act && sub == 0) {
+            out[qi] = (m3d_i32x2){ m, m3d_cert_pack(sec, itq) };
+            if (m == M3D_NN_NONE_CACHED) cache[qi] = code;
+        }
+    }
+}
+
 // k_nn_tiles: the searches k_nn_iter binned, answered from LDS. One workgroup per (pair, tile): it copies the tile's image into LDS —
 // the voxel directory and the tile's own + neighbouring buckets' points (one coalesced index stream, one 16-B gather per staged
 // point, all independent) — and answers every query record of the tile against it, one record per thread; a tile with several
@@ -2204,6 +2281,19 @@ int m3d_ticket_words(int n_pairs, int max_n_src) {
 // One Gauss-Newton iteration: k_nn_iter (classify; sparse blocks search cooperatively, dense blocks bin their queries by target
 // tile), k_nn_tiles (the binned queries, from LDS), k_accumulate_matches (residuals, 29-term reduction; with fuse_solve the last
 // block of every pair solves and updates the pose).
+#ifndef M3D_COOP_LIST
+#define M3D_COOP_LIST 64   // queries per workgroup of k_nn_coop_list (0: never launched; A/B builds)
+#endif
+static void m3d_launch_coop(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int bpp_s, int first_of_level, const M3dNnArgs& A, int list) {
+    if (M3D_COOP_LIST == 0 || first_of_level || !list) {
+        hipLaunchKernelGGL(k_nn_coop, dim3(8 * bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, 8 * bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_coop");
+    } else {
+        constexpr int QPB = M3D_COOP_LIST ? M3D_COOP_LIST : 64, PER = 256 / QPB;
+        hipLaunchKernelGGL(k_nn_coop_list<QPB>, dim3(PER * bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, PER * bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_coop_list");
+    }
+}
 static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level, const M3dNnWork& w,
                              hipEvent_t k0, hipEvent_t k1, long long* partials, unsigned int seq, unsigned long long* progress, int fuse_solve) {
     int bpp_s = (max_n_src + 255) / 256; if (bpp_s < 1) bpp_s = 1;
@@ -2239,9 +2329,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     const bool walk_in_acc = lean_iter;
     const bool coop_only = A.coop_kernel == 2;
     if (coop_only) {   // a dense level (every pair's, by the handle's last batch): no classifying launch that finds nothing to do, no tile launch that finds no item
-        const int bpp_c = 8 * bpp_s;
-        hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A);
-        M3D_DBG(s, "k_nn_coop");
+        m3d_launch_coop(s, d_jobs, n_pairs, bpp_s, first_of_level, A, w.coop_list);
     } else if (lean_iter) {   // (every target of the batch has tiles: build_jobs checked)
         hipLaunchKernelGGL(k_nn_iter<true>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter<lean>");
@@ -2249,9 +2337,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
         hipLaunchKernelGGL(k_nn_iter<false>, dim3(bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_iter");
         if (A.coop_kernel) {   // a coarser level of a pyramid: where it is crowded (decided on the device, per pair) this kernel does the work, not the one above
-            const int bpp_c = 8 * bpp_s;
-            hipLaunchKernelGGL(k_nn_coop, dim3(bpp_c * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, bpp_c, first_of_level, A);
-            M3D_DBG(s, "k_nn_coop");
+            m3d_launch_coop(s, d_jobs, n_pairs, bpp_s, first_of_level, A, w.coop_list);
         }
     }
     if (w.tiles && !late && !coop_only) {

@@ -668,7 +668,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
     return M3DREG_OK;
 }
 
-M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
+M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     M3dNnWork w{};
     w.match = reinterpret_cast<int2*>(h->d_match); w.stride = h->match_stride; w.ring = h->d_ring; w.partials = h->d_partials; w.tickets = h->d_tickets; w.states = h->d_states;
     w.cache = reinterpret_cast<long long*>(h->d_match + 2 * h->match_cap);
@@ -692,6 +692,10 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1) {
     // pair of the last batch was dense: k_nn_coop answers ordinary pairs as well, only slower)
     const bool coop_level = level >= 0;
     w.coop_kernel = !coop_level ? 0 : (h->coop_known && ((h->coop_all >> level) & 1u)) ? 2 : (!h->coop_known || ((h->coop_seen >> level) & 1u)) ? 1 : 0;
+    // a dense level's later iterations: most queries are certified (config 5: 74 % at the end of its first level, 93-98 % on the levels that start from a coarser
+    // level's result) — from the 4th iteration of a registration's first level and the 2nd of every other one the searchers are compacted (k_nn_coop_list).
+    // A function of the iteration number alone; the other choice costs time, never a bit (profiles/r04_dense_levels.txt).
+    w.coop_list = (level > 0 ? it >= 1 : it >= 4) ? 1 : 0;
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
@@ -1055,7 +1059,7 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                     if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
                 }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0), nn_work(h, l), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0), nn_work(h, l, it), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             roctx_pop();
             h->launched_iters++;
         }
