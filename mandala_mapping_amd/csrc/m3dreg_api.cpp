@@ -1059,7 +1059,10 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
                     if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
                 }
             }
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0), nn_work(h, l, it), h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
+            const M3dNnWork nw = nn_work(h, l, it);
+            int fol = it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0);
+            // (a dense level's mostly-certified iterations as ONE launch, k_icp_late with its row-by-row walk, were measured again in round 4: config 5 1.76 -> 2.80 ms)
+            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, fol, nw, h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
             roctx_pop();
             h->launched_iters++;
         }
