@@ -2288,6 +2288,9 @@ static void m3d_launch_coop(hipStream_t s, const M3dJob* d_jobs, int n_pairs, in
     if (M3D_COOP_LIST == 0 || first_of_level || !list) {
         hipLaunchKernelGGL(k_nn_coop, dim3(8 * bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, 8 * bpp_s, first_of_level, A);
         M3D_DBG(s, "k_nn_coop");
+    } else if (list == 2) {   // nearly every query certified (a level that started from a coarser level's result): 128 per workgroup
+        hipLaunchKernelGGL(k_nn_coop_list<128>, dim3(2 * bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, 2 * bpp_s, first_of_level, A);
+        M3D_DBG(s, "k_nn_coop_list<128>");
     } else {
         constexpr int QPB = M3D_COOP_LIST ? M3D_COOP_LIST : 64, PER = 256 / QPB;
         hipLaunchKernelGGL(k_nn_coop_list<QPB>, dim3(PER * bpp_s * n_pairs), dim3(256), 0, s, d_jobs, n_pairs, PER * bpp_s, first_of_level, A);

@@ -695,7 +695,7 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     // a dense level's later iterations: most queries are certified (config 5: 74 % at the end of its first level, 93-98 % on the levels that start from a coarser
     // level's result) — from the 4th iteration of a registration's first level and the 2nd of every other one the searchers are compacted (k_nn_coop_list).
     // A function of the iteration number alone; the other choice costs time, never a bit (profiles/r04_dense_levels.txt).
-    w.coop_list = (level > 0 ? it >= 1 : it >= 4) ? 1 : 0;
+    w.coop_list = level > 0 ? (it >= 1 ? 2 : 0) : (it >= 4 ? 1 : 0);
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
     w.rec_stride = h->rec_stride; w.tcnt = h->d_tcnt; w.cnt_stride = h->cnt_stride;
     w.wcount = reinterpret_cast<unsigned int*>(h->d_witems); w.witems = h->d_witems ? h->d_witems + 16 * M3D_TILE_LISTS : nullptr; w.wcap = int(h->witems_cap);
