@@ -137,7 +137,7 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     int rot;                     // XCD rotation of the block -> pair map: differs between handles, so concurrent batches do not stack their k-th pairs on one XCD
     int tiles;                   // 1 = dense blocks bin their searches by target tile and k_nn_tiles answers them from LDS (M3DREG_TILES)
     int coop_kernel;             // 1 = k_nn_coop is launched behind k_nn_iter<false> and answers the pairs whose target level is dense; 2 = it is the only search kernel (icp.hip: M3dNnArgs)
-    int coop_list;               // 1 = an iteration in which most queries of a dense level are expected to be certified: k_nn_coop_list (searchers compacted per 64 queries) instead of k_nn_coop
+    int coop_list;               // 1 / 2 = an iteration in which most / nearly all queries of a dense level are expected to be certified: k_nn_coop_list (searchers compacted per 64 / 128 queries) instead of k_nn_coop
     int lean;                    // 1 = the tile iterations run k_nn_iter<true> (classify + bin only; the reduction pass walks what it cannot bin); needs every target of the batch to have tiles (M3DREG_LEAN)
     int ntile_max;               // tiles per pair the arrays below are laid out for
     float4* rec;                 // [n_pairs][ntile_max * M3D_TILE_QCAP] query records

@@ -693,7 +693,8 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     const bool coop_level = level >= 0;
     w.coop_kernel = !coop_level ? 0 : (h->coop_known && ((h->coop_all >> level) & 1u)) ? 2 : (!h->coop_known || ((h->coop_seen >> level) & 1u)) ? 1 : 0;
     // a dense level's later iterations: most queries are certified (config 5: 74 % at the end of its first level, 93-98 % on the levels that start from a coarser
-    // level's result) — from the 4th iteration of a registration's first level and the 2nd of every other one the searchers are compacted (k_nn_coop_list).
+    // level's result) — from the 4th iteration of a registration's first level (1: per 64 queries) and the 2nd of every other one (2: per 128) the searchers
+    // are compacted (k_nn_coop_list).
     // A function of the iteration number alone; the other choice costs time, never a bit (profiles/r04_dense_levels.txt).
     w.coop_list = level > 0 ? (it >= 1 ? 2 : 0) : (it >= 4 ? 1 : 0);
     w.ntile_max = h->ntile_max; w.rec = h->d_rec; w.recd = reinterpret_cast<float*>(h->d_rec + h->rec_cap);
