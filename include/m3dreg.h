@@ -22,7 +22,8 @@
  *     schedule (ABI 5; the only process-wide word is a creation counter that places a handle's pairs
  *     on the XCDs). What a registration launches is a function of the batch — with one documented
  *     exception, per handle: it remembers at which levels its last finished batch met a dense target
- *     (more than 24 points per voxel, or a map: more than 6 and at least 4 x the source) in some / in
+ *     (more than 24 points per voxel; more than 8 on a level that starts from a coarser one; or a map:
+ *     more than 6 and at least 4 x the source) in some / in
  *     every pair and launches the dense-level search kernel only there (alone where it was every pair;
  *     a handle's first batch: behind the ordinary one at every level). A wrong guess costs
  *     microseconds, never a bit.

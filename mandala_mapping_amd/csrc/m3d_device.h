@@ -169,9 +169,15 @@ struct M3dJob {            // one pair at one level
 #endif
 #define M3D_COOP_DENSITY_MAP 6
 #define M3D_COOP_MAP_RATIO 4
-__host__ __device__ inline bool m3d_dense_level(uint32_t n_tgt, uint32_t occupied_voxels, uint32_t n_src) {
+// ... or more than M3D_COOP_DENSITY_LATER points per voxel on a level that starts from a coarser level's result: nearly every query is certified from its second
+// iteration on, and the compacted search (k_nn_coop_list) beats classifying 256 queries per workgroup and walking the few searchers of a crowded block one per
+// lane (config 2's 0.4 m level, 10 per voxel: 4.75 -> 4.56 ms per registration; as a registration's FIRST level the same density is better served by the tiles:
+// with the threshold at 4 config 2's 0.2 m level loses 15 %).
+#define M3D_COOP_DENSITY_LATER 8
+__host__ __device__ inline bool m3d_dense_level(uint32_t n_tgt, uint32_t occupied_voxels, uint32_t n_src, int level) {
     const unsigned long long n = n_tgt, v = occupied_voxels;
-    return n > (unsigned long long)M3D_COOP_DENSITY * v || (n > (unsigned long long)M3D_COOP_DENSITY_MAP * v && n >= (unsigned long long)M3D_COOP_MAP_RATIO * (unsigned long long)n_src);
+    return n > (unsigned long long)M3D_COOP_DENSITY * v || (level > 0 && n > (unsigned long long)M3D_COOP_DENSITY_LATER * v) ||
+           (n > (unsigned long long)M3D_COOP_DENSITY_MAP * v && n >= (unsigned long long)M3D_COOP_MAP_RATIO * (unsigned long long)n_src);
 }
 
 // ---- spec primitives shared by every kernel (operation order is normative) --------
