@@ -83,6 +83,7 @@ def parse():
                                                          "the launcher adds nothing to the measurement")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N without torchrun: seconds after which the launcher ends its rank processes")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
+    ap.add_argument("--all-legs", action="store_true", help="also the legs the default run leaves out to stay short (batch16 / batch32 / batch64 with two chains, from_host_converge)")
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="the block of --steps timed steps is repeated (each block bracketed by barrier + synchronize on both sides, exactly --steps steps) "
                          "until the blocks add up to this much wall time; the MEDIAN block is reported (0 = one block)")
@@ -113,7 +114,7 @@ def run_multi(args):
         T, st, dev = M.align_described(descs)
     dt = time.perf_counter() - t0
     errs = [synth.pose_error(T[i], gts[i]) for i in range(n)]
-    print(json.dumps({
+    emit({
         "metric": "scan-pair registrations/sec (100k-pt clouds, point-to-plane, 0.1 m voxel NN)", "value": n * args.steps / dt, "unit": "registrations/s",
         "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (int64 fixed-point sums, f64 solve)", "data": "synthetic",
@@ -122,7 +123,7 @@ def run_multi(args):
                    "pairs_per_gpu": args.pairs_per_gpu, "iterations": args.iters, "parallelism": f"pairs LPT-sharded over {len(devices)} device context(s) by the library, no collective"},
         "pairs_per_device_ordinal": {str(d): int((dev == d).sum()) for d in sorted(set(devices))},
         "max_rot_err_deg": max(e[0] for e in errs), "max_trans_err_m": max(e[1] for e in errs),
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": None, "cpu_baseline": None})
 
 
 def launch_ranks(args):
@@ -570,10 +571,122 @@ def main():
             out["data"] = "synthetic (host PointCloud2 buffers: PCIe-inclusive, not the headline configuration)"
         if world == 1 and not args.no_extra and not args.no_cpu_baseline and args.workload == "config4" and not (args.from_host or args.converge):
             out["legs"] = extra_legs(args)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_BUDGET = 6000   # bytes: the driver parses the LAST stdout line and keeps only a few KB of tail (round 4's 27 KB line came back parsed = null)
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is read by people and a parser, not fed back into arithmetic)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The ONE line of the contract, built from the full result: the contract's keys, a numbers-only `roofline`, a compact `cpu_baseline`,
+    `legs` as {name: {value, ms_per_step, frac_alone, ...}}. Every definition and every prose field lives in DESIGN.md section 6 (keyed by
+    `roofline_definition_version`) and in the full result (gpurun_out/bench_full.json + stderr). Always < LINE_BUDGET bytes
+    (tests/test_bench_launcher.py builds it from a canned full result and from one eight times as wordy)."""
+    pick = lambda d, keys: {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    for k, cap in (("metric", 120), ("unit", 24), ("scaling", 16), ("dtype", 48), ("data", 100)):
+        if isinstance(line.get(k), str):
+            line[k] = line[k][:cap]
+    cfg = full.get("config") or {}
+    line["config"] = pick(cfg, ("workload", "pairs_per_gpu", "points_per_cloud", "iterations", "parallelism", "overlap"))
+    for k in ("workload", "parallelism", "overlap"):
+        if isinstance(line["config"].get(k), str):
+            line["config"][k] = line["config"][k][:480 if k == "workload" else 120]
+    line.update(pick(full, ("ms_per_icp_iter_batch", "ms_per_icp_iter_per_pair", "ms_per_icp_iter_batch_alone", "ms_bucketing_batch", "ms_bucketing_batch_alone",
+                            "max_rot_err_deg", "max_trans_err_m", "iterations_executed_pair0", "roofline_definition_version",
+                            "map_points", "bucket_map_ms", "registration_ms")))
+    if isinstance(full.get("blocks"), dict):
+        line["blocks"] = pick(full["blocks"], ("n", "median_ms", "min_ms", "max_ms"))
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        r = pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_fetch_uncorrected", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                      "launches_timed", "concurrent_chains"))
+        r["bound"], r["unit"] = str(rf.get("bound", "hbm"))[:4], str(rf.get("unit", "GB/s"))[:8]
+        r["kernel"] = str(rf.get("kernel", ""))[:40]
+        if isinstance(rf.get("traffic_source"), str):
+            r["traffic_source"] = rf["traffic_source"].split(":")[0][:24]   # "measured in this run" / "committed"
+        if isinstance(rf.get("traffic_step"), dict):
+            r["traffic_step_bytes"] = rf["traffic_step"].get("step_bytes")
+            r["traffic_step_bytes_fetch_uncorrected"] = rf["traffic_step"].get("step_bytes_fetch_uncorrected")
+        if isinstance(rf.get("alone"), dict):
+            r["alone"] = pick(rf["alone"], ("avg_launch_ms", "achieved", "frac"))
+        if isinstance(rf.get("iteration"), dict):
+            it = pick(rf["iteration"], ("algorithmic_bytes", "avg_ms", "achieved", "frac"))
+            if isinstance(rf["iteration"].get("alone"), dict):
+                it["alone"] = pick(rf["iteration"]["alone"], ("avg_ms", "achieved", "frac"))
+            r["iteration"] = it
+        line["roofline"] = r
+    elif "roofline" in full:
+        line["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = pick(cb, ("value", "unit", "cores", "kind"))
+        c["unit"], c["kind"] = str(cb.get("unit", ""))[:24], str(cb.get("kind", ""))[:9]
+        c["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:200]
+        for impl in ("port", "kdtree"):
+            if isinstance(cb.get(impl), dict):
+                c[impl] = {t: cb[impl][t].get("registrations_per_s") for t in ("threads_1", "threads_all") if isinstance(cb[impl].get(t), dict)}
+        line["cpu_baseline"] = c
+    elif "cpu_baseline" in full:
+        line["cpu_baseline"] = None
+    if isinstance(full.get("legs"), dict):
+        legs = {}
+        for name, d in list(full["legs"].items())[:16]:
+            if not isinstance(d, dict) or "error" in d:
+                legs[name] = {"error": str((d or {}).get("error", "?"))[-80:]} if isinstance(d, dict) else None
+                continue
+            e = pick(d, ("value", "ms_per_step", "registration_ms", "bucket_map_ms"))
+            al = ((d.get("roofline") or {}).get("alone") or {}).get("frac")
+            if al is not None:
+                e["frac_alone"] = al
+            itf = ((d.get("roofline") or {}).get("iteration") or {}).get("frac")
+            if itf is not None:
+                e["frac_iteration"] = itf
+            if isinstance(d.get("levels"), list):
+                e["level_ms_per_icp_iter"] = [lv.get("ms_per_icp_iter") for lv in d["levels"][:4]]
+            legs[name] = e
+        line["legs"] = legs
+    if isinstance(full.get("per_rank"), list):
+        line["per_rank"] = [pick(p, ("rank", "pairs", "own_work_ms_median")) for p in full["per_rank"][:8] if isinstance(p, dict)]
+    line["full_result"] = "gpurun_out/bench_full.json (and stderr)"
+    line = _r(line)
+    # belt and braces: if a future field pushes the line over the budget, optional parts go first — the contract's keys, roofline and cpu_baseline stay
+    for drop in ("per_rank", "legs", "blocks"):
+        if len(json.dumps(line)) < LINE_BUDGET:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def emit(full):
+    """Full result -> gpurun_out/bench_full.json and stderr; the compact line -> stdout, the ONLY thing this run prints there."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            json.dump(full, f)
+    except OSError:
+        pass
+    print("[bench full result] " + json.dumps(full), file=sys.stderr, flush=True)
+    if os.environ.get("M3D_BENCH_FULL_LINE"):   # child runs of this script (extra_legs, scripts/): the parent wants every field
+        print(json.dumps(full), flush=True)
+        return
+    s = json.dumps(compact_line(full))
+    assert len(s) < LINE_BUDGET, len(s)
+    print(s, flush=True)
 
 
 def measure_traffic(args):
@@ -629,22 +742,25 @@ def extra_legs(args):
         "serial": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1"],
         "from_host": ["--steps", "40", "--warmup", "3", "--from-host"],
         "converge": ["--steps", "40", "--warmup", "3", "--converge"],
-        "from_host_converge": ["--steps", "40", "--warmup", "3", "--from-host", "--converge"],   # SURVEY 8d's literal "registrations/s": H2D of both clouds + bucketing + iterations to eps 1e-5 (at most --iters) + D2H
         # (the default bracket, every 7th iteration: with every iteration bracketed none of them runs fused, and these two legs are LATENCIES of the shipped schedule)
         "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config5": ["--workload", "config5", "--steps", "10", "--warmup", "2"],
         # the big-batch regime: B pairs per step in ONE launch chain — 64 = ALL of config 4 on one GPU (pairs 0 ... 63: also the ones next to
         # obstacles, which rank 0's 8-pair shard does not hold) — with one chain (the kernels' own throughput: nothing else on the GPU) and with two in flight
-        "batch16": ["--pairs-per-gpu", "16", "--inflight", "2", "--queue-depth", "2", "--steps", "10", "--warmup", "3"],
-        "batch32": ["--pairs-per-gpu", "32", "--inflight", "2", "--queue-depth", "2", "--steps", "8", "--warmup", "2"],
         "batch64_one_chain": ["--pairs-per-gpu", "64", "--inflight", "1", "--queue-depth", "1", "--steps", "6", "--warmup", "2"],
-        "batch64": ["--pairs-per-gpu", "64", "--inflight", "2", "--queue-depth", "2", "--steps", "6", "--warmup", "2"],
     }
+    if args.all_legs:   # not in the driver's command: its run must stay well under a minute
+        runs.update({
+            "batch16": ["--pairs-per-gpu", "16", "--inflight", "2", "--queue-depth", "2", "--steps", "10", "--warmup", "3"],
+            "batch32": ["--pairs-per-gpu", "32", "--inflight", "2", "--queue-depth", "2", "--steps", "8", "--warmup", "2"],
+            "batch64": ["--pairs-per-gpu", "64", "--inflight", "2", "--queue-depth", "2", "--steps", "6", "--warmup", "2"],
+            "from_host_converge": ["--steps", "40", "--warmup", "3", "--from-host", "--converge"],   # SURVEY 8d's literal "registrations/s": H2D of both clouds + bucketing + iterations to eps 1e-5 (at most --iters) + D2H
+        })
     legs = {}
     for name, extra in runs.items():
         try:
-            r = subprocess.run(base + extra + ["--min-seconds", "0.5"], capture_output=True, text=True, timeout=300)
+            r = subprocess.run(base + extra + ["--min-seconds", "0.5"], capture_output=True, text=True, timeout=300, env=dict(os.environ, M3D_BENCH_FULL_LINE="1"))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 legs[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -727,7 +843,7 @@ def run_config5(args):
         Tl = Tn
         del tl, sl, Rl
     fin = levels[-1]
-    print(json.dumps({
+    emit({
         "metric": "scan-to-map registrations/sec (100k-pt live scan vs ~2M-pt map, multi-resolution 0.4/0.2/0.1 m, point-to-plane)",
         "value": 1e3 / reg_ms, "unit": "registrations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": reg_ms,
         "higher_is_better": True, "scaling": "replicas only", "vs_baseline": None, "dtype": "f32 (int64 fixed-point sums, f64 solve)", "data": "synthetic",
@@ -738,7 +854,7 @@ def run_config5(args):
         "max_rot_err_deg": rot, "max_trans_err_m": tra, "iterations_executed_pair0": int(st.iterations),
         "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles, finest level", "achieved": fin["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": fin["frac"], "avg_launch_ms": fin["ms_correspondence_step"], "algorithmic_bytes_per_launch": fin["algorithmic_bytes_per_iteration"], "traffic": None},
-    }), flush=True)
+    })
 
 
 def host_cores():

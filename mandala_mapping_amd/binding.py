@@ -11,6 +11,7 @@ visible, loading/creating fails loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -54,6 +55,14 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.m3dreg_abi_version.restype = C.c_int
+    if L.m3dreg_abi_version() != abi.ABI_VERSION:
+        # checked for EVERY library, M3DREG_LIB included (a stale build is most likely to arrive that way: struct strides differ between versions, every
+        # pair after the first would be read at the wrong offset). An A/B against an older build must say so: M3DREG_ALLOW_ABI_MISMATCH=1 (scripts/ab2.sh).
+        msg = f"libm3dreg.so ABI version mismatch: library {L.m3dreg_abi_version()}, binding {abi.ABI_VERSION} ({L._name})"
+        if os.environ.get("M3DREG_ALLOW_ABI_MISMATCH") != "1":
+            raise RuntimeError(msg)
+        print("[m3dreg] " + msg + " - allowed by M3DREG_ALLOW_ABI_MISMATCH=1, at the caller's risk", file=sys.stderr)
     vp, sz = C.c_void_p, C.c_size_t
     f32p, f64p, i32p, u32p, i64p = (C.POINTER(t) for t in (C.c_float, C.c_double, C.c_int32, C.c_uint32, C.c_int64))
     L.m3dreg_default_params.argtypes = [C.POINTER(abi.Params)]
@@ -122,8 +131,6 @@ def lib():
     L.m3dreg_multi_last_error.restype = C.c_char_p
     L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
     L.m3dreg_debug_throw.argtypes = [C.c_int]
-    if L.m3dreg_abi_version() != abi.ABI_VERSION and not os.environ.get("M3DREG_LIB"):   # (M3DREG_LIB: an A/B against an older build, at the caller's risk)
-        raise RuntimeError("libm3dreg.so ABI version mismatch")
     _lib = L
     return L
 

@@ -1,5 +1,6 @@
 #!/bin/bash
 # interleaved A/B, headline and serial, on one box: scripts/ab2.sh rounds "ENV_A=.." "ENV_B=.." ...
+# an older build with another ABI version: add M3DREG_ALLOW_ABI_MISMATCH=1 to its ENV string (the binding refuses it otherwise)
 N=$1; shift
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for i in $(seq $N); do

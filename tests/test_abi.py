@@ -88,3 +88,21 @@ def test_no_exception_crosses_the_boundary():
     assert L.m3dreg_debug_throw(0) == abi.ERR_OUT_OF_MEMORY
     assert L.m3dreg_debug_throw(1) == abi.ERR_HIP
     assert L.m3dreg_debug_fail_alloc(0) == 0
+
+
+def test_a_stale_library_is_refused_also_through_M3DREG_LIB(tmp_path):
+    """M3DREG_LIB is how instrumented and older builds are selected, so the ABI version is checked there too; only
+    M3DREG_ALLOW_ABI_MISMATCH=1 lets a mismatch through (and says so on stderr)."""
+    import subprocess
+    import sys
+    src = tmp_path / "stale.c"
+    src.write_text("int m3dreg_abi_version(void) { return 3; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    code = "from mandala_mapping_amd import binding\ntry:\n    binding.lib()\nexcept RuntimeError as e:\n    print('REFUSED', e)\nexcept AttributeError as e:\n    print('PASSED THE CHECK')\n"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict({k: v for k, v in os.environ.items() if k != "M3DREG_ALLOW_ABI_MISMATCH"}, M3DREG_LIB=str(so), PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "REFUSED" in r.stdout and "library 3" in r.stdout, (r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, M3DREG_ALLOW_ABI_MISMATCH="1"), timeout=300)
+    assert "PASSED THE CHECK" in r.stdout and "M3DREG_ALLOW_ABI_MISMATCH" in r.stderr, (r.stdout, r.stderr)
