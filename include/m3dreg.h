@@ -17,7 +17,8 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no exceptions cross the boundary, every function
  *     returns an int status (0 = M3DREG_OK, <0 = m3dreg_error).
- *   - Threading: one handle = one device + one HIP stream + the state of one batch; a handle is not
+ *   - Threading: one handle = one device + one HIP stream + the state of one batch (with m3dreg_set_batch_chains the synchronous
+ *     m3dreg_align_batch also drives up to three internal child handles, forked from and joined to the handle's stream); a handle is not
  *     thread-safe, different handles are independent. No global mutable state shapes a result or a
  *     schedule (ABI 5; the only process-wide word is a creation counter that places a handle's pairs
  *     on the XCDs). What a registration launches is a function of the batch — with one documented
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 5   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+#define M3DREG_ABI_VERSION 6   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
                                      M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
                                   3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
                                      exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
@@ -51,7 +52,9 @@ extern "C" {
                                   4: + m3dreg_host_alloc / _free / _register / _unregister (pinned payloads); m3dreg_multi_align runs one host thread
                                      per device; m3dreg_default_params is a coarse-to-fine pyramid (see there)
                                   5: + m3dreg_pair_desc.target_group (shared targets are co-located and bucketed once), m3dagg_set_scan_trig,
-                                     m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight */
+                                     m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight
+                                  6: + m3dreg_set_batch_chains (opt-in: the SYNCHRONOUS m3dreg_align_batch may cut a batch of >= 4 pairs into internal
+                                     launch chains, same results); m3dreg_pair_desc.reserved must be 0 */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -204,10 +207,20 @@ int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_byte
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c);
 int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
                         const float init_T[16], float out_T[16], m3dreg_stats* stats);
-/* Registers n_pairs independent pairs on this handle's device: one launch per Gauss-Newton
- * iteration covers the whole batch (grid.y = pair). out_T: 16*n_pairs floats. */
+/* Registers n_pairs independent pairs on this handle's device and waits for them: one launch chain, one launch per stage and
+ * Gauss-Newton iteration for the whole batch. out_T: 16*n_pairs floats.
+ * (ABI 6, opt-in) m3dreg_set_batch_chains(h, k), 2 <= k <= 4: this synchronous call cuts a batch of >= 4 pairs into up to k
+ * contiguous parts (at least two pairs each) that run as independent launch chains, the first on the handle's stream, the others
+ * on streams of internal child handles, forked from and joined to the handle's stream with events: work enqueued on that stream
+ * before the call is complete before any part starts, work enqueued after it starts after every part. Bit-identical results for
+ * every cut. Default (k = 0 or 1, environment M3DREG_BATCH_CHAINS): no cut — measured on 8 x 100 k-point pairs the cut LOSES (4982
+ * registrations/s as one chain, 4642 as two, 3233 as four: the iteration kernels are latency-bound at a duration that does not
+ * shrink with the batch); it exists for callers with many small pairs. To keep the GPU busy across calls use the asynchronous
+ * pair below with two handles: the bucketing of the next batch then runs under the iterations of this one (bench.py's headline).
+ * m3dreg_align_batch_async never cuts; while event brackets are on (m3dreg_profile_enable) a batch runs as one chain. */
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T,
                        m3dreg_stats* stats);
+int m3dreg_set_batch_chains(m3dreg_handle* h, int chains);
 /* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. A handle holds the state of ONE batch: a second
  * m3dreg_align_batch_async before the wait is refused (M3DREG_ERR_INVALID_ARG) — to queue batches behind each other, give
  * several handles the same stream (m3dreg_create's `stream`), as bench.py does. */
@@ -232,7 +245,7 @@ typedef struct m3dreg_pair_desc {
     int32_t target_group;               /* (ABI 5) 0 = this pair's target is its own; > 0: every pair of the call with this id registers against the SAME
                                            reference cloud (identical target descriptors: loop-closure candidates against one submap): the
                                            group is kept on one device and its target is uploaded and bucketed ONCE there */
-    int32_t reserved;
+    int32_t reserved;                   /* must be 0 (ABI 6: checked). Zero-initialise the struct: m3dreg_pair_desc p = {0}; */
 } m3dreg_pair_desc;
 int m3dreg_multi_create(const m3dreg_params* params, const int* devices, int n_devices, m3dreg_multi** out);
 int m3dreg_multi_destroy(m3dreg_multi* m);

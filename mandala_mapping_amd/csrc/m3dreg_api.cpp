@@ -164,6 +164,17 @@ struct m3dreg_handle {
     uint64_t prof_launches[5] = { 0, 0, 0, 0, 0 };   // M3DREG_PROFILE_*: iteration, correspondence step, bucketing batch, reduce + solve, all iterations of a batch (launches = iterations enqueued)
     double prof_ms[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
     uint64_t chain_iters = 0;          // iterations enqueued between the open kind-5 event and its kind-6 partner
+    // the batch being enqueued (batch_begin / batch_step / batch_end): m3dreg_align_batch_async runs them back to back, the synchronous m3dreg_align_batch
+    // interleaves the steps of several internal chains
+    struct Run { size_t n_pairs = 0; int max_n_src = 0; int l = 0, it = 0; bool can_stop_early = false, prev_sampled = false; uint64_t iters_before = 0; unsigned int level_first_seq = 0; } run;
+    // internal chains of the SYNCHRONOUS m3dreg_align_batch (include/m3dreg.h): child handles with streams of their own, created on first use; a child never
+    // owns a cloud and is released with its parent
+    std::vector<m3dreg_handle*> lanes;
+    hipEvent_t fork_ev = nullptr;      // recorded on this handle's stream in front of a split batch: the lanes' streams wait for it
+    std::vector<hipEvent_t> join_ev;   // recorded behind a lane's part of the batch: this handle's stream waits for them
+    std::vector<size_t> split;         // pairs per chain of the split batch awaiting m3dreg_batch_wait (empty: not split)
+    int batch_chains = 0;              // m3dreg_set_batch_chains: 0 = library default, 1 = never split, k = at most k chains
+    bool is_lane = false;
 };
 
 namespace {
@@ -815,6 +826,10 @@ void roctx_pop() {
 void release_handle(m3dreg_handle* h) {
     hipSetDevice(h->device);
     sync_handle(h);
+    for (m3dreg_handle* lane : h->lanes) release_handle(lane);   // (a lane owns no cloud)
+    h->lanes.clear();
+    if (h->fork_ev) hipEventDestroy(h->fork_ev);
+    for (hipEvent_t e : h->join_ev) hipEventDestroy(e);
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
@@ -1016,8 +1031,8 @@ int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c) {
     });
 }
 
-int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
-    return m3d_guarded(h, "m3dreg_align_batch_async", [&]() -> int {
+// ---- one batch on one handle, in three parts: set-up, one Gauss-Newton iteration per call, tail -----------------------------------------
+static int batch_begin(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
     if (h->closed) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: the handle was destroyed");
     if (h->pending_pairs) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch_async: a batch is pending on this handle (a handle holds the state of ONE batch: call m3dreg_batch_wait, or use another handle on the same stream)");
@@ -1030,46 +1045,65 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     if ((rc = ensure_match(h, n_pairs, max_n_src, max_n_tgt))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
-    const bool can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
-    bool prev_sampled = false;
-    const uint64_t iters_before = h->launched_iters;
+    m3dreg_handle::Run& R = h->run;
+    R = m3dreg_handle::Run();
+    R.n_pairs = n_pairs; R.max_n_src = max_n_src;
+    R.can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
+    R.iters_before = h->launched_iters;
     if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(5); (void)hipEventRecord(e, h->stream); } }   // the whole chain of this batch's iterations as it ships
-    for (int l = 0; l < P.n_levels; l++) {
+    return M3DREG_OK;
+}
+
+// enqueues the batch's next iteration: 1 = one was enqueued, 0 = there is none left, < 0 = error
+static int batch_step(m3dreg_handle* h) {
+    m3dreg_handle::Run& R = h->run;
+    const m3dreg_params& P = h->params;
+    for (;;) {
+        if (R.l >= P.n_levels) return 0;
+        if (R.it >= P.iterations[R.l]) { R.l++; R.it = 0; continue; }
+        if (R.it == 0) R.level_first_seq = h->seq + 1;
+        if (R.can_stop_early && R.it > 0) {   // nothing left to do at this level? (a stale value only delays the exit)
+            const unsigned long long v = *h->h_progress;
+            if ((unsigned int)(v >> 32) >= R.level_first_seq && (unsigned int)(v >> 32) <= h->seq && (unsigned int)v == 0u) {
+                h->skipped_iters += uint64_t(P.iterations[R.l] - R.it);
+                R.l++; R.it = 0;
+                continue;
+            }
+        }
+        const int l = R.l, it = R.it;
         const M3dJob* dj = h->d_jobs + size_t(l) * h->cap_pairs;
-        const unsigned int level_first_seq = h->seq + 1;
         // (the fused late launches only on the finest level: a pyramid's coarser levels are the crowded ones, where the uncertified few of a late
         // iteration are long cooperative walks behind a fat workgroup's stream — config 5 with them fused from the 8th iteration: 4.12 instead of 3.82 ms)
         const int fuse_from_l = (l < P.n_levels - 1) ? 0 : h->fuse_from;
-        for (int it = 0; it < P.iterations[l]; it++) {
-            if (can_stop_early && it > 0) {   // nothing left to do at this level? (a stale value only delays the exit)
-                const unsigned long long v = *h->h_progress;
-                if ((unsigned int)(v >> 32) >= level_first_seq && (unsigned int)(v >> 32) <= h->seq && (unsigned int)v == 0u) {
-                    h->skipped_iters += uint64_t(P.iterations[l] - it);
-                    break;
-                }
+        h->seq++;
+        roctx_push("m3dreg:iteration");
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        if (h->profiling) {   // every prof_every-th iteration is bracketed: {k0, k1, end of the iteration}
+            if (R.prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
+            R.prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
+            if (R.prev_sampled) {
+                k0 = next_event(h); if (k0) h->ev_kind.push_back(0);
+                k1 = k0 ? next_event(h) : nullptr; if (k1) h->ev_kind.push_back(1);
+                if (!k1) { k0 = nullptr; R.prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
             }
-            h->seq++;
-            roctx_push("m3dreg:iteration");
-            hipEvent_t k0 = nullptr, k1 = nullptr;
-            if (h->profiling) {   // every prof_every-th iteration is bracketed: {k0, k1, end of the iteration}
-                if (prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
-                prev_sampled = (h->launched_iters % uint64_t(h->prof_every)) == 0;
-                if (prev_sampled) {
-                    k0 = next_event(h); if (k0) h->ev_kind.push_back(0);
-                    k1 = k0 ? next_event(h) : nullptr; if (k1) h->ev_kind.push_back(1);
-                    if (!k1) { k0 = nullptr; prev_sampled = false; }   // (an event could not be created: this iteration is not bracketed)
-                }
-            }
-            const M3dNnWork nw = nn_work(h, l, it);
-            int fol = it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0);
-            // (a dense level's mostly-certified iterations as ONE launch, k_icp_late with its row-by-row walk, were measured again in round 4: config 5 1.76 -> 2.80 ms)
-            HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(n_pairs), max_n_src, P.metric, fol, nw, h->seq, can_stop_early ? h->d_progress : nullptr, k0, k1));
-            roctx_pop();
-            h->launched_iters++;
         }
+        const M3dNnWork nw = nn_work(h, l, it);
+        int fol = it == 0 ? 1 : (it >= h->tile_iters ? ((fuse_from_l > 0 && it >= fuse_from_l) ? -2 : -1) : 0);
+        // (a dense level's mostly-certified iterations as ONE launch, k_icp_late with its row-by-row walk, were measured again in round 4: config 5 1.76 -> 2.80 ms)
+        HIPCHK(h, m3d_launch_icp_iteration(h->stream, dj, int(R.n_pairs), R.max_n_src, P.metric, fol, nw, h->seq, R.can_stop_early ? h->d_progress : nullptr, k0, k1));
+        roctx_pop();
+        h->launched_iters++;
+        R.it++;
+        return 1;
     }
-    if (h->profiling && prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
-    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(6 + int(h->launched_iters - iters_before)); (void)hipEventRecord(e, h->stream); } }
+}
+
+static int batch_end(m3dreg_handle* h, const m3dreg_pair* pairs) {
+    m3dreg_handle::Run& R = h->run;
+    const size_t n_pairs = R.n_pairs;
+    int rc;
+    if (h->profiling && R.prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
+    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(6 + int(h->launched_iters - R.iters_before)); (void)hipEventRecord(e, h->stream); } }
     for (size_t i = 0; i < n_pairs; i++) {   // clouds of other handles: their owners' streams wait for this batch before the blocks are re-used
         if ((rc = note_foreign_use(h, pairs[i].source))) return rc;
         if ((rc = note_foreign_use(h, pairs[i].target))) return rc;
@@ -1078,6 +1112,15 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
     // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
     return M3DREG_OK;
+}
+
+int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs) {
+    return m3d_guarded(h, "m3dreg_align_batch_async", [&]() -> int {
+    int rc = batch_begin(h, pairs, n_pairs);
+    if (rc) return rc;
+    while ((rc = batch_step(h)) > 0) {}
+    if (rc < 0) return rc;
+    return batch_end(h, pairs);
     });
 }
 
@@ -1085,6 +1128,16 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     return m3d_guarded(h, "m3dreg_batch_wait", [&]() -> int {
     if (!h || h->pending_pairs == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "batch_wait: nothing pending");
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->split.empty()) {   // a batch the synchronous call spread over internal chains: this stream has waited for the lanes' (join events)
+        size_t off = h->split[0];
+        for (size_t c = 1; c < h->split.size(); c++) {
+            m3dreg_handle* lane = h->lanes[c - 1];
+            const int rc = m3dreg_batch_wait(lane, out_T ? out_T + 16 * off : nullptr, stats ? stats + off : nullptr);
+            if (rc) { h->err = lane->err; h->split.clear(); h->pending_pairs = 0; return rc; }
+            off += h->split[c];
+        }
+        h->split.clear();
+    }
     if (h->ev_used) drain_events(h);
     for (size_t i = 0; i < h->pending_pairs; i++) {
         const M3dPairState& S = h->h_states[i];
@@ -1103,10 +1156,85 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     });
 }
 
+// Internal launch chains of the SYNCHRONOUS call (ABI 6, opt-in: m3dreg_set_batch_chains / M3DREG_BATCH_CHAINS): a batch of >= 4 pairs is cut into up to 4
+// contiguous parts that run as independent launch chains, the first on the handle's stream, the others on streams of internal child handles (fork / join
+// with events on the handle's stream: everything enqueued on it before the call is done before any part starts, everything enqueued after the call starts
+// after all parts). Results do not depend on the cut: every pair's sums are integers, its schedule inside a chain is the schedule of a smaller batch, which
+// gives the same bits (tests/test_gpu_parity.py: test_internal_chains_...). MEASURED (profiles/r05_batch_chains.txt, 8 pairs x 100 k per call, serial
+// calls): 1 chain 4982 registrations/s, 2 chains 4642, 3 chains 4430, 4 chains 3233; 64 pairs: 7179 / 7110 / - / 6449. The iteration kernels of one chain
+// are latency-bound at a duration that hardly shrinks with the batch (k_nn_tiles' persistent grid, the reduction's 512 workgroups, the serial solve tail), so
+// two half-size chains each take ~85 % of the full chain's time and share the chip: the split loses. What round 4 measured as "two 4-pair chains beat one
+// 8-pair chain" (5553 vs 4755) was two STEPS in flight — the bucketing of step i + 1 under the iterations of step i — which a caller gets from the
+// asynchronous API (two handles), not from a cut inside one call. Hence the default: one chain.
+static int chains_for(const m3dreg_handle* h, size_t n_pairs) {
+    if (h->is_lane || h->profiling || n_pairs < 4) return 1;   // (event brackets describe ONE chain)
+    int want = h->batch_chains;
+    if (want == 0) { static const int env = [] { const char* v = getenv("M3DREG_BATCH_CHAINS"); return v ? atoi(v) : 0; }(); want = env > 0 ? env : 1; }
+    if (want > 4) want = 4;
+    const int by_size = int(n_pairs / 2);   // at least two pairs per chain
+    return want < by_size ? want : by_size;
+}
+
+int m3dreg_set_batch_chains(m3dreg_handle* h, int chains) {
+    if (!h || chains < 0) return M3DREG_ERR_INVALID_ARG;
+    h->batch_chains = chains;
+    return M3DREG_OK;
+}
+
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T, m3dreg_stats* stats) {
     return m3d_guarded(h, "m3dreg_align_batch", [&]() -> int {
-    int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
-    if (rc) return rc;
+    if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
+    const int K = chains_for(h, n_pairs);
+    if (K <= 1) {
+        int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
+        if (rc) return rc;
+        return m3dreg_batch_wait(h, out_T, stats);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    while (int(h->lanes.size()) < K - 1) {   // child handles: same parameters and device, a stream of their own
+        m3dreg_handle* lane = nullptr;
+        int rc = m3dreg_create(&h->params, h->device, nullptr, &lane);
+        if (rc) return fail(h, rc, "align_batch: could not create an internal chain");
+        lane->is_lane = true; lane->certify = h->certify; lane->tiles = h->tiles; lane->lean = h->lean; lane->fuse_from = h->fuse_from; lane->tile_iters = h->tile_iters;
+        alloc_point();
+        h->lanes.push_back(lane);
+        hipEvent_t e = nullptr;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->join_ev.push_back(e);
+    }
+    if (!h->fork_ev) HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    std::vector<size_t> part(size_t(K), n_pairs / size_t(K));   // contiguous parts, the first n % K one pair longer: a function of n_pairs and K alone
+    for (size_t c = 0; c < n_pairs % size_t(K); c++) part[c]++;
+    std::vector<m3dreg_handle*> ch(size_t(K), h);
+    for (int c = 1; c < K; c++) ch[size_t(c)] = h->lanes[size_t(c - 1)];
+    // any failure below: drain every stream, leave nothing pending
+    auto abort_all = [&](int rc, const std::string& msg) { for (m3dreg_handle* x : ch) { hipStreamSynchronize(x->stream); x->pending_pairs = 0; if (x->ev_used) drain_events(x); } h->split.clear(); h->err = msg; return rc; };
+    HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
+    for (int c = 1; c < K; c++) HIPCHK(h, hipStreamWaitEvent(ch[size_t(c)]->stream, h->fork_ev, 0));
+    std::vector<size_t> first(size_t(K), 0);
+    for (int c = 1; c < K; c++) first[size_t(c)] = first[size_t(c - 1)] + part[size_t(c - 1)];
+    for (int c = 0; c < K; c++) {
+        const int rc = batch_begin(ch[size_t(c)], pairs + first[size_t(c)], part[size_t(c)]);
+        if (rc) return abort_all(rc, ch[size_t(c)]->err);
+    }
+    for (bool any = true; any;) {   // the chains' iterations enqueued round-robin: no chain's launches queue up behind another chain's host-side work
+        any = false;
+        for (int c = 0; c < K; c++) {
+            const int rc = batch_step(ch[size_t(c)]);
+            if (rc < 0) return abort_all(rc, ch[size_t(c)]->err);
+            any = any || rc > 0;
+        }
+    }
+    for (int c = 0; c < K; c++) {
+        const int rc = batch_end(ch[size_t(c)], pairs + first[size_t(c)]);
+        if (rc) return abort_all(rc, ch[size_t(c)]->err);
+    }
+    for (int c = 1; c < K; c++) {
+        hipError_t e = hipEventRecord(h->join_ev[size_t(c - 1)], ch[size_t(c)]->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->join_ev[size_t(c - 1)], 0);
+        if (e != hipSuccess) return abort_all(M3DREG_ERR_HIP, "align_batch: join of an internal chain");
+    }
+    h->split = part;
     return m3dreg_batch_wait(h, out_T, stats);
     });
 }
@@ -2179,6 +2307,7 @@ int m3dreg_multi_align(m3dreg_multi* m, const m3dreg_pair_desc* pairs, size_t n_
         for (size_t i = 0; i < n_pairs; i++) {
             const int32_t gid = pairs[i].target_group;
             if (gid < 0) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: negative target_group");
+            if (pairs[i].reserved != 0) return mfail(m, M3DREG_ERR_INVALID_ARG, "multi_align: m3dreg_pair_desc.reserved must be 0 (zero-initialise the struct: code written for ABI 4 leaves target_group and reserved undefined)");
             size_t u = size_t(-1);
             if (gid > 0) { const auto f = unit_of_group.find(gid); if (f != unit_of_group.end()) u = f->second; }
             if (u == size_t(-1)) {

@@ -145,6 +145,40 @@ def test_batch_equals_single_and_oracle(reg, orc):
         assert np.array_equal(T1, Tb[k])
 
 
+def test_internal_chains_of_the_synchronous_call_give_the_same_bits(reg, orc):
+    """ABI 6 (opt-in, m3dreg_set_batch_chains): m3dreg_align_batch cuts a batch of >= 4 pairs into internal launch chains (at most 4). Every cut — none, 2, 3, 4 chains,
+    even and uneven parts, fixed iteration counts and convergence-terminated (every chain polls its own progress word) — gives the oracle's bits, the
+    asynchronous call's bits, and leaves the handle usable for single registrations and further batches; work queued on the handle's stream right before
+    the call (the bucketing of its clouds) is complete before any chain starts."""
+    for eps in (0.0, 1e-5):
+        p = _params(leaf=0.25, iterations=12, metric=abi.POINT_TO_PLANE, normal_leaf=0.5, eps_rot=eps, eps_trans=eps)
+        R = reg.Registrar(p)
+        raw, ref = [], []
+        for k in range(9):
+            tgt = synth.planes_cloud(3000 + 400 * k, 150 + k)
+            Tg = synth.random_T(np.random.default_rng(100 + k), 2.0, 0.1)
+            src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(2500 + 300 * k, 180 + k)).astype(np.float32)
+            raw.append((src, tgt))
+            ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+        for n in (9, 8, 5, 4, 3):
+            for chains in (0, 1, 2, 3, 4):
+                R.set_batch_chains(chains)
+                cl = R.clouds([a for s_, t_ in raw[:n] for a in (s_, t_)], wait=False)      # bucketing still in flight when the call is made
+                pairs = [(cl[2 * i], cl[2 * i + 1], None) for i in range(n)]
+                Tb, stb = R.align_batch(pairs)
+                for k in range(n):
+                    assert np.array_equal(Tb[k], ref[k][0]), (eps, n, chains, k)
+                    _same_stats(stb[k], ref[k][1])
+                if chains == 3 and n == 9:
+                    R.align_batch_async(R._pairs(pairs), n)
+                    Ta, sta = R.batch_wait(n)
+                    assert np.array_equal(Ta, Tb) and [s_.iterations for s_ in sta] == [s_.iterations for s_ in stb]
+                    T1, _ = R.align(pairs[7][0], pairs[7][1])
+                    assert np.array_equal(T1, Tb[7])
+                for c in cl:
+                    c.free()
+
+
 def test_status_codes(reg, orc):
     p = _params(leaf=0.5, iterations=5, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
     R = reg.Registrar(p)
