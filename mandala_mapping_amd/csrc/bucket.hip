@@ -185,12 +185,24 @@ __device__ __forceinline__ void sort_buffers(const M3dBuild& B, int pass, const 
 }
 __device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return B.skey_out; }
 __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { return B.perm_out; }
-// the ping-pong key buffer that does NOT hold the sorted keys is free after the last pass: the normal grid keeps the list
-// of its voxel heads (first sorted position of every occupied voxel) there
-__device__ __forceinline__ uint32_t* voxel_head_list(const M3dBuild& B) { return (B.sort_passes & 1) ? B.ka : B.kb; }
-// both VALUE ping-pong buffers are free after the last pass: a level of a point-to-plane cloud keeps its inverse permutation (sorted position by
-// input index) in the first, for its cloud's normal grid to address the level's normal array with
-__device__ __forceinline__ uint32_t* level_inverse(const M3dBuild& B) { return B.va; }
+// ---- a9 without a second sort (round 5) -----------------------------------------------------------------------------------------------
+// The normal-estimation grid (leaf = normal_leaf over the same AABB) used to be bucketed like a level: keyed, radix-sorted, tabled, gathered — a third
+// of a point-to-plane target's bucketing — only to add up ten integers per voxel. Its voxels are SHORT RUNS of the finest level's sorted order (that
+// order follows a Morton curve of 2x2x2-voxel buckets; a coarser voxel is a handful of consecutive buckets, give or take the points the two grids'
+// float arithmetic rounds differently), and the moments are exact integers, so they can be added in any order: the runs' heads insert the voxel into an
+// open-addressing table (k_finalize_level, fused), the runs add their moments to the slot (k_nrm_moments: one set of 64-bit atomics per run and wave),
+// k_nrm_solve sums the 27 neighbours of every occupied voxel and solves, k_nrm_handout looks every point's voxel up, in every level's order. Same
+// integers, same doubles, same bits as the sorted version and as the oracle's per-point loop (oracle/m3d_oracle.c: grid_normals).
+__device__ __forceinline__ uint32_t nrm_voxel_key(const M3dGrid& g, float x, float y, float z) {
+    const int ix = (int)m3d_cell_f(x, g.mn[0], g.inv_leaf), iy = (int)m3d_cell_f(y, g.mn[1], g.inv_leaf), iz = (int)m3d_cell_f(z, g.mn[2], g.inv_leaf);
+    return (uint32_t)ix | ((uint32_t)iy << (g.cb[0] + 1)) | ((uint32_t)iz << (g.cb[0] + g.cb[1] + 2));   // (sum of the widths = cb0 + cb1 + cb2 + 3 <= 31: never M3D_INVALID_KEY)
+}
+// slot of a voxel that IS in the table
+__device__ __forceinline__ uint32_t nrm_slot_of(const uint32_t* __restrict__ nkeys, uint32_t mask, int shift, uint32_t key) {
+    uint32_t h = (key * 0x9E3779B1u) >> shift;
+    while (nkeys[h] != key) h = (h + 1u) & mask;
+    return h;
+}
 
 // (fused = the batch's clouds are small enough — at most RS_FUSED_TILES tiles — for every scatter workgroup to scan the counters it
 // needs itself: no k_rs_scan launch, counters stored [tile][digit] so that those reads coalesce)
@@ -503,6 +515,14 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
 __global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
     const M3dBuild& B = builds[rb.row];
+    if (B.nkeys) {   // a normal grid: its voxel table (keys only: a slot's moments are zeroed by the thread that takes it)
+        uint4* t4 = reinterpret_cast<uint4*>(B.nkeys);   // [ncap] keys, then [ncap] "further runs of this voxel" counters
+        const uint32_t n4 = B.ncap >> 2;   // (a power of two >= 16)
+        for (uint32_t i = (uint32_t)rb.blk * blockDim.x + threadIdx.x; i < 2u * n4; i += (uint32_t)bpr * blockDim.x) {
+            const uint32_t f = i < n4 ? M3D_INVALID_KEY : 0u;
+            t4[i] = make_uint4(f, f, f, f);
+        }
+    }
     if (!B.htab) return;   // a source-only cloud has no table
     const uint32_t T2 = 2u * (B.dyn[1] + 1u);
     uint4* t = reinterpret_cast<uint4*>(B.htab);
@@ -542,35 +562,52 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const uint32_t oi = inb ? sval[j] : 0u;
     const bool valid = k != M3D_INVALID_KEY;
     const uint32_t kp = (inb && j) ? skey[j - 1] : M3D_INVALID_KEY;
-    if (B.mom) {   // normal grid: k_normals runs once per occupied voxel, over the dense list of voxel heads: this block
-        // appends its heads at the prefix k_table_params left in hist[2 blk] (ranks: wave64 ballots + LDS; no atomics)
-        __shared__ uint32_t s_wc[4];
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inb) {
+        p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
+        p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
+        B.pts[j] = p;
+        if (B.src3) { B.src3[3 * (size_t)j] = p.x; B.src3[3 * (size_t)j + 1] = p.y; B.src3[3 * (size_t)j + 2] = p.z; }
+    }
+    if (B.nrm_feed) {   // (block-uniform) the finest level of a cloud with normals: the heads of the normal-grid voxels' runs take the voxels' slots
+        const M3dBuild& G = builds[B.nrm_build];
+        const uint32_t nmask = G.ncap - 1u;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const bool vhead = valid && (j == 0 || kp != k);
-        const unsigned long long bh = __ballot(vhead);
-        if (lane == 0) s_wc[wave] = (uint32_t)__popcll(bh);
-        __syncthreads();
-        uint32_t off = B.hist[2 * rb.blk];
-#pragma unroll
-        for (int w = 0; w < 4; w++) if (w < wave) off += s_wc[w];
-        if (vhead) {
-            voxel_head_list(B)[off + (uint32_t)__popcll(bh & ((1ull << lane) - 1ull))] = (uint32_t)j;
-            // the voxel's moment slot, zeroed here: k_cell_moments adds the pieces of a run cut by a wave boundary with atomics, k_normals
-            // reads head slots only — no 80-B-per-point memset of the whole array (64 MB per step for eight 100 k-point targets)
-#pragma unroll
-            for (int i = 0; i < 10; i++) B.mom[10 * (size_t)j + i] = 0;
+        uint32_t nk = M3D_INVALID_KEY;
+        if (valid) nk = nrm_voxel_key(G.grid, p.x, p.y, p.z);
+        uint32_t nkp = (uint32_t)__shfl_up((int)nk, 1);
+        if (lane == 0) {   // (the wave's first position: its predecessor's point once more — finite, like every point before a finite one)
+            nkp = M3D_INVALID_KEY;
+            if (valid && j > 0) { const float4 pp = B.xyz[sval[j - 1]]; nkp = nrm_voxel_key(G.grid, pp.x, pp.y, pp.z); }
         }
+        bool won = false;
+        uint32_t h = 0u;
+        if (valid && (j == 0 || nkp != nk)) {
+            h = (nk * 0x9E3779B1u) >> G.nshift;
+            for (;;) {   // the first head of a voxel to arrive owns its slot; a later run of the same voxel finds it
+                const uint32_t old = atomicCAS(&G.nkeys[h], M3D_INVALID_KEY, nk);
+                if (old == M3D_INVALID_KEY) { won = true; break; }
+                if (old == nk) { atomicAdd(&G.nkeys[G.ncap + h], 1u); break; }   // a further run of a voxel that has its slot: k_nrm_moments then ADDS this voxel's runs instead of storing its one
+                h = (h + 1u) & nmask;
+            }
+            if (won) {
+#pragma unroll
+                for (int i = 0; i < 10; i++) G.mom[10 * (size_t)h + i] = 0;   // (k_nrm_moments, the next launch but two, adds to it)
+            }
+        }
+        // the slots this block took, as a list (ranks: wave64 ballots + LDS; no atomics): k_nrm_solve's work items
+        __shared__ uint32_t s_wc[4];
+        const unsigned long long bw = __ballot(won);
+        if (lane == 0) s_wc[wave] = (uint32_t)__popcll(bw);
+        __syncthreads();
+        uint32_t off = 0u, tot = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { if (w < wave) off += s_wc[w]; tot += s_wc[w]; }
+        if (won) G.nlist[(size_t)rb.blk * 256u + off + (uint32_t)__popcll(bw & ((1ull << lane) - 1ull))] = h;
+        if (threadIdx.x == 0) G.nvcnt[rb.blk] = tot;
     }
     if (!inb) return;
     const bool bhead = valid && (j == 0 || (kp >> 3) != (k >> 3));
-    float4 p = B.xyz[oi];    // one 16-B gather per point (three 4-B gathers from SoA arrays touched three cache lines)
-    p.w = __uint_as_float(oi);   // bits of the input index (< 2^28): the tie-break key of the NN search, and the way back to input order
-    B.pts[j] = p;
-    if (B.src3) { B.src3[3 * (size_t)j] = p.x; B.src3[3 * (size_t)j + 1] = p.y; B.src3[3 * (size_t)j + 2] = p.z; }
-    if (B.nrm_sorted) {   // a level that will carry normals: k_normals (the cloud's normal grid) writes them straight into this level's order
-        if (valid) level_inverse(B)[oi] = (uint32_t)j;
-        else B.nrm_sorted[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (non-finite points, sorted last, have none)
-    }
     if (bhead && B.htab) {
         const uint32_t bk = bucket_key_of_point(B.grid, p);
         uint32_t h = m3d_hash_slot(bk, hshift);
@@ -1032,37 +1069,88 @@ __device__ __forceinline__ int m3d_quant_frac(float v, float mn, float inv_leaf)
     return (int)rintf(fr * 65536.0f);
 }
 
-__device__ __forceinline__ M3dLevelDev build_level(const M3dBuild& B) {
-    M3dLevelDev L;
-    L.pts = B.pts; L.nrm = nullptr; L.htab = B.htab; L.bigcum = B.bigcum; L.g = B.grid;
-    L.g.hmask = B.dyn[1]; L.g.hshift = (int)B.dyn[2];   // the host copy is not known yet at this point
-    return L;
-}
-
-__global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build — a row per build started two workgroups in three for nothing)
-    if (!B.mom) return;
-    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
-    if (rb.blk * (int)blockDim.x >= B.grid.n_valid) return;
-    const M3dLevelDev L = build_level(B);
-    const M3dGrid& g = L.g;
-    const int lane = threadIdx.x & 63;
-    const bool ok = j < g.n_valid;
-    uint32_t key = M3D_INVALID_KEY;
-    long long v[10];
+// Pass 1: the moments {n, S[3], P[6]} of every run of equal normal-grid voxels in the finest level's sorted order, into the voxel's slot. Device-scope
+// atomics are slow on this chip (ten 64-bit adds into one line per run: 57 us for 8 clouds when every run used them), so a run that is the voxel's ONLY one
+// (no head lost the race for the slot in k_finalize_level: the counter behind the keys) and lies inside one wave's 256 positions STORES its sums; only
+// runs cut by a wave's edge and the runs of voxels that have several are added with atomics (any grouping of a voxel's points gives the same integers).
+// A thread walks NRM_PPT consecutive positions: pieces that begin and end inside it are whole runs; its first piece, when a second follows, is handed to
+// the thread before it (whose last piece it continues, or which then knows it is a run of its own); the threads' last pieces are merged by a segmented wave64
+// scan — a quarter of the cross-lane traffic of a position per lane.
+#define NRM_PPT 4
+__device__ __forceinline__ void nrm_flush(const M3dBuild& G, uint32_t key, const long long (&v)[10], bool whole) {
+    const uint32_t h = nrm_slot_of(G.nkeys, G.ncap - 1u, G.nshift, key);
+    long long* m = &G.mom[10 * (size_t)h];
+    if (whole && G.nkeys[G.ncap + h] == 0u) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) v[i] = 0;
-    if (ok) {
-        key = B.skey_out[j];
-        const float4 p = L.pts[j];
-        const long long qx = m3d_quant_frac(p.x, g.mn[0], g.inv_leaf), qy = m3d_quant_frac(p.y, g.mn[1], g.inv_leaf),
-                        qz = m3d_quant_frac(p.z, g.mn[2], g.inv_leaf);
-        v[0] = 1; v[1] = qx; v[2] = qy; v[3] = qz;
-        v[4] = qx * qx; v[5] = qx * qy; v[6] = qx * qz; v[7] = qy * qy; v[8] = qy * qz; v[9] = qz * qz;
+        for (int i = 0; i < 10; i++) m[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&m[i]), (unsigned long long)v[i]);
     }
-    const uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
-    const bool head = (lane == 0) || (kprev != key);
+}
+__global__ __launch_bounds__(256) void k_nrm_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& G = builds[rb.row * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build)
+    if (!G.nkeys) return;
+    const M3dBuild& L = builds[rb.row * grids_per_cloud + grids_per_cloud - 1];   // the cloud's finest level
+    const int nv = L.grid.n_valid;
+    if (rb.blk * 256 * NRM_PPT >= nv || L.n == 0) return;   // (block-uniform)
+    const int j0 = (rb.blk * 256 + (int)threadIdx.x) * NRM_PPT;
+    const M3dGrid& g = G.grid;
+    const int lane = threadIdx.x & 63;
+    // the voxels of the positions next to the wave's 256: does its first run begin here, does its last run end here?
+    uint32_t k_left = M3D_INVALID_KEY, k_right = M3D_INVALID_KEY;
+    if (lane == 0 && j0 > 0 && j0 - 1 < nv) { const float4 q = L.pts[j0 - 1]; k_left = nrm_voxel_key(g, q.x, q.y, q.z); }
+    if (lane == 63 && j0 + NRM_PPT < nv) { const float4 q = L.pts[j0 + NRM_PPT]; k_right = nrm_voxel_key(g, q.x, q.y, q.z); }
+    uint32_t key = M3D_INVALID_KEY;   // voxel of the piece being summed (the thread's last, in the end); M3D_INVALID_KEY: none yet / past the end
+    uint32_t kf = M3D_INVALID_KEY;    // voxel of the thread's FIRST piece when a second one followed
+    bool multi = false;
+    long long v[10], vF[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { v[i] = 0; vF[i] = 0; }
+    float4 p[NRM_PPT];
+#pragma unroll
+    for (int u = 0; u < NRM_PPT; u++) p[u] = (j0 + u < nv) ? L.pts[j0 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NRM_PPT; u++) {
+        if (j0 + u >= nv) break;
+        const uint32_t ku = nrm_voxel_key(g, p[u].x, p[u].y, p[u].z);
+        if (ku != key) {
+            if (key != M3D_INVALID_KEY) {
+                if (!multi) {   // the thread's first piece ends here: kept for the hand-over below
+                    multi = true; kf = key;
+#pragma unroll
+                    for (int i = 0; i < 10; i++) vF[i] = v[i];
+                } else nrm_flush(G, key, v, true);   // a piece between two boundaries inside the thread: a whole run
+            }
+            key = ku;
+#pragma unroll
+            for (int i = 0; i < 10; i++) v[i] = 0;
+        }
+        const long long qx = m3d_quant_frac(p[u].x, g.mn[0], g.inv_leaf), qy = m3d_quant_frac(p[u].y, g.mn[1], g.inv_leaf),
+                        qz = m3d_quant_frac(p[u].z, g.mn[2], g.inv_leaf);
+        v[0] += 1; v[1] += qx; v[2] += qy; v[3] += qz;
+        v[4] += qx * qx; v[5] += qx * qy; v[6] += qx * qz; v[7] += qy * qy; v[8] += qy * qz; v[9] += qz * qz;
+    }
+    const bool ok = key != M3D_INVALID_KEY;
+    if (!multi) kf = key;   // (one piece: first == last)
+    // hand-over: lane t + 1's first piece (multi) continues lane t's last piece when the voxels agree — lane t takes its sums; otherwise lane t + 1 flushes it
+    // itself, as a whole run (it begins where lane t's piece of another voxel ends) unless it is the wave's first lane and the run began before the wave
+    const uint32_t kl_prev = (uint32_t)__shfl_up((int)key, 1);        // last voxel of the lane before (lane 0: unused)
+    const uint32_t kf_next = (uint32_t)__shfl_down((int)kf, 1);       // first voxel of the lane after (lane 63: unused)
+    const bool multi_next = __shfl_down((int)multi, 1) != 0;
+    if (__ballot(multi) != 0ull) {   // (wave-uniform; nearly always some lane has a boundary inside)
+        const bool take_next = lane < 63 && multi_next && ok && kf_next == key;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const long long t = __shfl_down(vF[i], 1); if (take_next) v[i] += t; }
+        if (multi) {
+            const bool given = lane > 0 && kl_prev == kf;
+            if (!given) nrm_flush(G, kf, vF, lane > 0 || k_left != kf);
+        }
+    }
+    // the threads' last pieces: a run continues from lane t - 1 into lane t when lane t has ONE piece of the same voxel
+    const bool head = (lane == 0) || multi || (kl_prev != key);
+    const bool left_whole = lane == 0 ? (multi || k_left != key) : true;   // at a head lane: does the run begin inside the wave?
     const unsigned long long heads = __ballot(head);
     const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const int seg_start = 63 - __clzll((long long)(heads & le));
@@ -1070,226 +1158,215 @@ __global__ __launch_bounds__(256) void k_cell_moments(const M3dBuild* __restrict
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const bool take = (lane - o) >= seg_start;
-        if (__ballot(take) == 0ull) break;   // wave-uniform: every run of this wave is already complete (runs average ~6 points)
+        if (__ballot(take) == 0ull) break;   // wave-uniform: every run of this wave is already complete
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const long long t = __shfl_up(v[i], o);
             if (take) v[i] += t;
         }
     }
-    // does the wave's first run continue one that began in the previous wave / its last run continue into the next wave?
-    const int j0 = j - lane;   // sorted position of lane 0
-    uint32_t kb = M3D_INVALID_KEY, ka = M3D_INVALID_KEY;
-    if (lane == 0 && ok && j0 > 0) kb = B.skey_out[j0 - 1];
-    if (lane == 63 && ok && j + 1 < g.n_valid) ka = B.skey_out[j + 1];
-    const bool first_continues = __shfl((int)(lane == 0 && ok && kb == key), 0) != 0;
-    const bool last_continues = __shfl((int)(lane == 63 && ok && ka == key), 63) != 0;
-    if (ok && tail) {
-        // the moments of a voxel live at its first sorted position
-        const bool began_here = !(seg_start == 0 && first_continues);
-        const bool whole = began_here && !(lane == 63 && last_continues);
-        int hp = j0 + seg_start;
-        if (!began_here) {
-            const float4 pj = L.pts[j];
-            hp = (int)m3d_find_voxel(L, (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
-                                     (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf)).x;
-        }
-        if (whole) {   // the run lies inside this wave (nearly all do): plain stores into the zeroed array, no probe, no atomics
+    const bool lw = __shfl((int)left_whole, seg_start) != 0;
+    // (a tail lane's run ends inside the wave when the next lane starts another voxel — or took over nothing of it: the next lane's FIRST voxel decides)
+    const bool right_whole = lane == 63 ? (k_right != key) : (kf_next != key || multi_next);
+    if (ok && tail) nrm_flush(G, key, v, lw && right_whole);
+}
+
+// Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same normal): add the (shifted)
+// moments of the 27 voxels around it and take the smallest eigenvector of the covariance. Work is dealt BY VOXEL: every workgroup scans the per-block
+// counts k_finalize_level left (a few hundred words) into LDS, the voxels are then numbered across the blocks' lists and taken 32 at a time, grid-stride
+// (a workgroup per group of blocks, the first shape, ran 93 us for 8 clouds: a far, sparse stretch of a scan has a voxel per point, a near one two per
+// thousand points). Eight lanes per voxel for the sums (27 table probes shared out), then one lane per voxel solves.
+#define NRM_PREF_CAP 8192   // blocks whose counts one prefix covers (2 M points); larger clouds are taken in stretches of that many blocks
+__global__ __launch_bounds__(256) void k_nrm_solve(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int rows, int bpr) {
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& G = builds[rb.row * grids_per_cloud];
+    if (!G.nkeys) return;
+    const M3dBuild& L = builds[rb.row * grids_per_cloud + grids_per_cloud - 1];
+    const int nblk = (L.n + 255) / 256;   // blocks of k_finalize_level that wrote their counts
+    if (nblk == 0) return;
+    // two levels: the prefix of the counts of every SIXTEEN blocks in LDS (2 KB: the kernel's occupancy is the double-precision solve's registers, not this),
+    // the sixteen counts themselves re-read (64 bytes, cached) by the lanes that look a voxel up
+    __shared__ uint32_t s_pref[NRM_PREF_CAP / 16 + 1];
+    __shared__ uint32_t s_w[4];
+    __shared__ long long s_sum[32][10];
+    __shared__ uint32_t s_vs[32];
+    const int tid = (int)threadIdx.x;
+    const uint32_t* nlist = G.nlist;
+    const uint32_t* nvcnt = G.nvcnt;
+    for (int sb0 = 0; sb0 < nblk; sb0 += NRM_PREF_CAP) {   // (one stretch for clouds of up to 2 M points)
+    const int sbn = min(nblk - sb0, NRM_PREF_CAP), sgn = (sbn + 15) / 16;
+    __syncthreads();   // (the previous stretch's prefix is no longer read)
+    uint32_t run = 0u;
+    for (int base = 0; base < sgn; base += 256) {   // exclusive prefix over the groups of sixteen blocks
+        const int gq = base + tid;
+        uint32_t c = 0u;
+        if (gq < sgn) {
+            const uint4* c4 = reinterpret_cast<const uint4*>(nvcnt + sb0 + 16 * gq);   // (256-byte aligned array, sb0 a multiple of 16; the array is padded to whole groups)
+            const uint4 a = c4[0], b = c4[1], d = c4[2], e = c4[3];
+            const uint32_t cc[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w };
 #pragma unroll
-            for (int i = 0; i < 10; i++) B.mom[10 * (size_t)hp + i] = v[i];
-        } else {       // a run cut by a wave boundary: its pieces are added with 64-bit integer atomics
-#pragma unroll
-            for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&B.mom[10 * (size_t)hp + i]), (unsigned long long)v[i]);
+            for (int q = 0; q < 16; q++) c += (16 * gq + q < sbn) ? cc[q] : 0u;   // (the words behind the last block's count are padding: never written)
         }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256(c, s_w, tot);
+        if (gq < sgn) s_pref[gq] = run + ex;
+        run += tot;
+    }
+    if (tid == 0) s_pref[sgn] = run;
+    __syncthreads();
+    const uint32_t nV = s_pref[sgn];
+    const M3dGrid& g = G.grid;
+    const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
+    const uint32_t nmask = G.ncap - 1u;
+    const int nshift = G.nshift;
+    const uint32_t* nkeys = G.nkeys;
+    const long long* mom = G.mom;
+    const int li = tid >> 3, part = tid & 7;
+    for (uint32_t vb = (uint32_t)rb.blk * 32u; vb < nV; vb += (uint32_t)bpr * 32u) {   // (block-uniform: barriers and shuffles inside)
+        const uint32_t v = vb + (uint32_t)li;
+        const bool act = v < nV;
+        uint32_t slot = 0u;
+        if (act) {   // voxel v of the stretch: the group of sixteen blocks that holds it (bisection of the prefix in LDS), the block inside the group, its place in that block's list
+            int lo = 0, hi = sgn;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= v) lo = mid; else hi = mid; }
+            const uint4* c4 = reinterpret_cast<const uint4*>(nvcnt + sb0 + 16 * lo);
+            const uint4 a = c4[0], b = c4[1], d = c4[2], e = c4[3];
+            const uint32_t cc[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w };
+            uint32_t r = v - s_pref[lo], bsel = 0u, before = 0u, acc = 0u;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { if (acc <= r) { bsel = (uint32_t)q; before = acc; } acc += (16 * lo + q < sbn) ? cc[q] : 0u; }   // the last block whose prefix is <= r (empty blocks in between are skipped: their prefix equals their successor's)
+            slot = nlist[(size_t)(sb0 + 16 * lo + (int)bsel) * 256u + (r - before)];
+        }
+        const uint32_t key = act ? nkeys[slot] : 0u;
+        const int icx = (int)(key & ((1u << sh1) - 1u)), icy = (int)((key >> sh1) & ((1u << (g.cb[1] + 1)) - 1u)), icz = (int)(key >> sh2);
+        long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+        // this lane's neighbours: part, part + 8, part + 16, part + 24 of the 27; their probes first (independent), then the moments of the ones that exist
+        uint32_t hh[4], nkq[4], kq[4]; bool fnd[4]; int ddx[4], ddy[4], ddz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int nb = part + 8 * u;
+            ddx[u] = nb % 3 - 1; ddy[u] = (nb / 3) % 3 - 1; ddz[u] = nb / 9 - 1;
+            const int x = icx + ddx[u], y = icy + ddy[u], z = icz + ddz[u];
+            fnd[u] = act && nb < 27 && x >= 0 && y >= 0 && z >= 0 && x < g.dims[0] && y < g.dims[1] && z < g.dims[2];
+            nkq[u] = (uint32_t)x | ((uint32_t)y << sh1) | ((uint32_t)z << sh2);
+            hh[u] = (nkq[u] * 0x9E3779B1u) >> nshift;
+            kq[u] = fnd[u] ? nkeys[hh[u]] : M3D_INVALID_KEY;   // the four first probes are in flight together
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {   // (linear probing past the rare collision)
+            while (kq[u] != nkq[u] && kq[u] != M3D_INVALID_KEY) { hh[u] = (hh[u] + 1u) & nmask; kq[u] = nkeys[hh[u]]; }
+            fnd[u] = fnd[u] && kq[u] == nkq[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!fnd[u]) continue;
+            const long long* m = &mom[10 * (size_t)hh[u]];
+            const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
+            const long long Dx = (long long)ddx[u] * M3D_NQ, Dy = (long long)ddy[u] * M3D_NQ, Dz = (long long)ddz[u] * M3D_NQ;
+            k += n;
+            s0 += Sx + n * Dx; s1 += Sy + n * Dy; s2 += Sz + n * Dz;
+            q0 += m[4] + 2 * Dx * Sx + n * Dx * Dx;
+            q1 += m[5] + Dx * Sy + Dy * Sx + n * Dx * Dy;
+            q2 += m[6] + Dx * Sz + Dz * Sx + n * Dx * Dz;
+            q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
+            q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
+            q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
+        }
+        {   // lane 8g collects the sums of its group (every lane of the wave shuffles)
+            long long* acc[10] = { &k, &s0, &s1, &s2, &q0, &q1, &q2, &q3, &q4, &q5 };
+#pragma unroll
+            for (int a = 0; a < 10; a++) {
+#pragma unroll
+                for (int o = 4; o >= 1; o >>= 1) *acc[a] += __shfl_down(*acc[a], o);
+            }
+        }
+        if (part == 0) {
+            s_sum[li][0] = k; s_sum[li][1] = s0; s_sum[li][2] = s1; s_sum[li][3] = s2; s_sum[li][4] = q0;
+            s_sum[li][5] = q1; s_sum[li][6] = q2; s_sum[li][7] = q3; s_sum[li][8] = q4; s_sum[li][9] = q5;
+            s_vs[li] = slot;
+        }
+        __syncthreads();
+        if (tid < 32 && vb + (uint32_t)tid < nV) {
+            const long long k = s_sum[tid][0], s0 = s_sum[tid][1], s1 = s_sum[tid][2], s2 = s_sum[tid][3], q0 = s_sum[tid][4],
+                            q1 = s_sum[tid][5], q2 = s_sum[tid][6], q3 = s_sum[tid][7], q4 = s_sum[tid][8], q5 = s_sum[tid][9];
+            float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+            do {
+                if (k < (long long)min_pts || k < 3) break;
+                const double inv = 1.0 / (double)k;
+                const double m0 = (double)s0 * inv, m1 = (double)s1 * inv, m2 = (double)s2 * inv;
+                double c[6] = { (double)q0 * inv - m0 * m0, (double)q1 * inv - m0 * m1, (double)q2 * inv - m0 * m2,
+                                (double)q3 * inv - m1 * m1, (double)q4 * inv - m1 * m2, (double)q5 * inv - m2 * m2 };
+                const double cm = sym3_maxabs(c);
+                if (!(cm > 0.0)) break;
+                const double sc = pow2_recip(cm);
+#pragma unroll
+                for (int i = 0; i < 6; i++) c[i] = c[i] * sc;
+                const double a[6] = { c[3] * c[5] - c[4] * c[4], c[2] * c[4] - c[1] * c[5], c[1] * c[4] - c[2] * c[3],
+                                      c[0] * c[5] - c[2] * c[2], c[1] * c[2] - c[0] * c[4], c[0] * c[3] - c[1] * c[1] };
+                const double am = sym3_maxabs(a);
+                if (!(am > 1e-12)) break;
+                double p[6], t2[6];
+                {
+                    const double sa = pow2_recip(am);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) p[i] = a[i] * sa;
+                }
+                for (int it = 0; it < 5; it++) {
+                    sym3_square(p, t2);
+                    const double tm = sym3_maxabs(t2);
+                    const double st = pow2_recip(tm);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) p[i] = t2[i] * st;
+                }
+                double v0, v1, v2;
+                if (p[0] >= p[3] && p[0] >= p[5]) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+                else if (p[3] >= p[5]) { v0 = p[1]; v1 = p[3]; v2 = p[4]; }
+                else { v0 = p[2]; v1 = p[4]; v2 = p[5]; }
+                const double nn = v0 * v0 + v1 * v1 + v2 * v2;
+                if (!(nn > 0.0)) break;
+                const double rn = det_rsqrt(nn);
+                v0 = v0 * rn; v1 = v1 * rn; v2 = v2 * rn;
+                const double cv0 = c[0] * v0 + c[1] * v1 + c[2] * v2, cv1 = c[1] * v0 + c[3] * v1 + c[4] * v2, cv2 = c[2] * v0 + c[4] * v1 + c[5] * v2;
+                double l3 = v0 * cv0 + v1 * cv1 + v2 * cv2;
+                const double av0 = a[0] * v0 + a[1] * v1 + a[2] * v2, av1 = a[1] * v0 + a[3] * v1 + a[4] * v2, av2 = a[2] * v0 + a[4] * v1 + a[5] * v2;
+                const double pr = v0 * av0 + v1 * av1 + v2 * av2;
+                const double sm = (c[0] + c[3] + c[5]) - l3;
+                if (l3 < 0.0) l3 = 0.0;
+                const double mth = l3 / (double)plane_ratio;
+                if (!((mth <= 0.5 * sm) && ((mth * mth - sm * mth) + pr >= 0.0))) break;
+                const double spread_q = (double)min_spread * 65536.0;
+                const double mw = (spread_q * spread_q) * sc;   // the threshold in the units c was scaled to
+                if (!((mw <= 0.5 * sm) && ((mw * mw - sm * mw) + pr >= 0.0))) break;
+                int im = 0;
+                double vm = fabs(v0);
+                if (fabs(v1) > vm) { im = 1; vm = fabs(v1); }
+                if (fabs(v2) > vm) { im = 2; }
+                const double lead = im == 0 ? v0 : (im == 1 ? v1 : v2);
+                if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
+                out = make_float4((float)v0, (float)v1, (float)v2, 0.f);
+            } while (0);
+            G.nnrm[s_vs[tid]] = out;
+        }
+        __syncthreads();   // (the sums are overwritten by the next trip)
+    }
     }
 }
 
-// Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same
-// normal — the per-point version did 10x the hash probes for identical results): add the (shifted) moments of the 27
-// voxels around it and take the smallest eigenvector of the covariance. The result is stored in the slot of the voxel's
-// first point, and the same launch hands it to the voxel's other points, in every level's sorted order.
-// voxels per workgroup and trip: 32 (one round of 8 lanes per voxel; the solving wave half full) — with 64 a 100 k-point cloud's ~2500 voxels kept 40
-// workgroups busy per cloud, each passing through its three phases (sums, solve, hand-out) alone on its CU
-#ifndef NRM_TRIP
-#define NRM_TRIP 32
-#endif
-__global__ __launch_bounds__(256) void k_normals(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int rows, int bpr) {
+// Pass 3: every point takes the normal of its normal-grid voxel — in every level's sorted order, one coalesced pass per level (one table probe per
+// point; neighbours share their voxel's slot). Non-finite points (sorted last) get {0,0,0,0}.
+__global__ __launch_bounds__(256) void k_nrm_handout(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const int ng_build = rb.row * grids_per_cloud;   // (one row per CLOUD, as in k_cell_moments)
-    const M3dBuild& B = builds[ng_build];
-    if (!B.mom) return;
-    // eight lanes per occupied voxel, one BUCKET of the 27-voxel neighbourhood each: the 3x3x3 voxels around a voxel lie in exactly 2x2x2
-    // buckets, so one probe of the level's table per lane (both halves of the entry in one round trip) replaces the 27 dependent
-    // probe chains of a per-voxel walk (they, not the arithmetic, were this kernel's 49 us); the lane then adds the moments of the
-    // bucket's voxels that belong to the neighbourhood (1, 2, 4 or 8 of them). The sums are exact integers: any split gives the same
-    // bits. Merged with three shuffles per word into LDS; a workgroup gathers the sums of 64 voxels that way (two rounds of 32), then ONE
-    // wave solves them, a voxel per lane (the eigen-solve with one lane in eight active was the other half of the kernel's time).
-    const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int grp = tl >> 3, part = tl & 7;
-    const uint32_t n_vox = B.dyn[5];
-    __shared__ long long s_sum[NRM_TRIP][10];
-    __shared__ uint32_t s_head[NRM_TRIP + 1];   // first sorted position of the trip's voxels, and of the voxel after them
-    __shared__ float4 s_nrm[NRM_TRIP];
-    for (uint32_t vb = (uint32_t)rb.blk * (uint32_t)NRM_TRIP; vb < n_vox; vb += (uint32_t)bpr * (uint32_t)NRM_TRIP) {   // (block-uniform: barriers and shuffles inside)
-    for (int rnd = 0; rnd < NRM_TRIP / 32; rnd++) {
-    const int li = rnd * 32 + wv * 8 + grp;   // voxel of this trip this group sums up
-    const uint32_t v = vb + (uint32_t)li;
-    const bool act = v < n_vox;
-    const int j = act ? (int)voxel_head_list(B)[v] : 0;   // first sorted position of the voxel (a finite point)
-    const M3dLevelDev L = build_level(B);
-    const M3dGrid& g = L.g;
-    const long long* mom = B.mom;
-    const float4 pj = L.pts[j];
-    const int icx = (int)m3d_cell_f(pj.x, g.mn[0], g.inv_leaf), icy = (int)m3d_cell_f(pj.y, g.mn[1], g.inv_leaf),
-              icz = (int)m3d_cell_f(pj.z, g.mn[2], g.inv_leaf);
-    long long k = 0, s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    {
-        // bucket (part & 1, part >> 1 & 1, part >> 2) of the neighbourhood: ((ic - 1) >> 1) + {0, 1} per axis (arithmetic shift: -1 at the border)
-        const int bx = ((icx - 1) >> 1) + (part & 1), by = ((icy - 1) >> 1) + ((part >> 1) & 1), bz = ((icz - 1) >> 1) + (part >> 2);
-        const int nb0 = (g.dims[0] + 1) >> 1, nb1 = (g.dims[1] + 1) >> 1, nb2 = (g.dims[2] + 1) >> 1;
-        if (act && bx >= 0 && by >= 0 && bz >= 0 && bx < nb0 && by < nb1 && bz < nb2) {
-            const uint32_t key = m3d_bucket_key(g, bx, by, bz);
-            const uint4* tab = reinterpret_cast<const uint4*>(L.htab);
-            uint32_t h = m3d_hash_slot(key, g.hshift);
-            uint4 lo = tab[2 * (size_t)h], hi = tab[2 * (size_t)h + 1];
-            while (lo.x != key && lo.x != M3D_INVALID_KEY) { h = (h + 1u) & g.hmask; lo = tab[2 * (size_t)h]; hi = tab[2 * (size_t)h + 1]; }
-            if (lo.x == key) {
-#pragma unroll 2
-                for (int sub = 0; sub < 8; sub++) {
-                    const int dx = 2 * bx + (sub & 1) - icx, dy = 2 * by + ((sub >> 1) & 1) - icy, dz = 2 * bz + (sub >> 2) - icz;
-                    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;   // (voxels beyond dims are simply unoccupied)
-                    const uint2 vr = m3d_sub_range(lo, hi, L.bigcum, sub);
-                    if (vr.y <= vr.x) continue;
-                    const long long* m = &mom[10 * (size_t)vr.x];
-                    const long long n = m[0], Sx = m[1], Sy = m[2], Sz = m[3];
-                    const long long Dx = (long long)dx * M3D_NQ, Dy = (long long)dy * M3D_NQ, Dz = (long long)dz * M3D_NQ;
-                    k += n;
-                    s0 += Sx + n * Dx; s1 += Sy + n * Dy; s2 += Sz + n * Dz;
-                    q0 += m[4] + 2 * Dx * Sx + n * Dx * Dx;
-                    q1 += m[5] + Dx * Sy + Dy * Sx + n * Dx * Dy;
-                    q2 += m[6] + Dx * Sz + Dz * Sx + n * Dx * Dz;
-                    q3 += m[7] + 2 * Dy * Sy + n * Dy * Dy;
-                    q4 += m[8] + Dy * Sz + Dz * Sy + n * Dy * Dz;
-                    q5 += m[9] + 2 * Dz * Sz + n * Dz * Dz;
-                }
-            }
-        }
+    const M3dBuild& B = builds[rb.row];
+    if (!B.nrm_sorted || B.nrm_build < 0) return;
+    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
+    if (j >= B.n) return;
+    const M3dBuild& G = builds[B.nrm_build];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < B.grid.n_valid) {
+        const float4 p = B.pts[j];
+        o = G.nnrm[nrm_slot_of(G.nkeys, G.ncap - 1u, G.nshift, nrm_voxel_key(G.grid, p.x, p.y, p.z))];
     }
-    {   // lane 8g collects the sums of its group (every lane of the wave shuffles)
-        long long* acc[10] = { &k, &s0, &s1, &s2, &q0, &q1, &q2, &q3, &q4, &q5 };
-#pragma unroll
-        for (int a = 0; a < 10; a++) {
-#pragma unroll
-            for (int o = 4; o >= 1; o >>= 1) *acc[a] += __shfl_down(*acc[a], o);
-        }
-    }
-    if (part == 0) {
-        s_sum[li][0] = k; s_sum[li][1] = s0; s_sum[li][2] = s1; s_sum[li][3] = s2; s_sum[li][4] = q0;
-        s_sum[li][5] = q1; s_sum[li][6] = q2; s_sum[li][7] = q3; s_sum[li][8] = q4; s_sum[li][9] = q5;
-        if (act) s_head[li] = (uint32_t)j;   // (slot n_trip belongs to thread 0 below)
-    }
-    }
-    const uint32_t n_trip = min((uint32_t)NRM_TRIP, n_vox - vb);
-    if (threadIdx.x == 0) s_head[n_trip] = vb + (uint32_t)NRM_TRIP < n_vox ? voxel_head_list(B)[vb + (uint32_t)NRM_TRIP] : (uint32_t)B.grid.n_valid;
-    __syncthreads();
-    if (threadIdx.x < NRM_TRIP && vb + threadIdx.x < n_vox) {
-    const long long k = s_sum[threadIdx.x][0], s0 = s_sum[threadIdx.x][1], s1 = s_sum[threadIdx.x][2], s2 = s_sum[threadIdx.x][3], q0 = s_sum[threadIdx.x][4],
-                    q1 = s_sum[threadIdx.x][5], q2 = s_sum[threadIdx.x][6], q3 = s_sum[threadIdx.x][7], q4 = s_sum[threadIdx.x][8], q5 = s_sum[threadIdx.x][9];
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    do {
-        if (k < (long long)min_pts || k < 3) break;
-        const double inv = 1.0 / (double)k;
-        const double m0 = (double)s0 * inv, m1 = (double)s1 * inv, m2 = (double)s2 * inv;
-        double c[6] = { (double)q0 * inv - m0 * m0, (double)q1 * inv - m0 * m1, (double)q2 * inv - m0 * m2,
-                        (double)q3 * inv - m1 * m1, (double)q4 * inv - m1 * m2, (double)q5 * inv - m2 * m2 };
-        const double cm = sym3_maxabs(c);
-        if (!(cm > 0.0)) break;
-        const double sc = pow2_recip(cm);
-#pragma unroll
-        for (int i = 0; i < 6; i++) c[i] = c[i] * sc;
-        const double a[6] = { c[3] * c[5] - c[4] * c[4], c[2] * c[4] - c[1] * c[5], c[1] * c[4] - c[2] * c[3],
-                              c[0] * c[5] - c[2] * c[2], c[1] * c[2] - c[0] * c[4], c[0] * c[3] - c[1] * c[1] };
-        const double am = sym3_maxabs(a);
-        if (!(am > 1e-12)) break;
-        double p[6], t2[6];
-        {
-            const double sa = pow2_recip(am);
-#pragma unroll
-            for (int i = 0; i < 6; i++) p[i] = a[i] * sa;
-        }
-        for (int it = 0; it < 5; it++) {
-            sym3_square(p, t2);
-            const double tm = sym3_maxabs(t2);
-            const double st = pow2_recip(tm);
-#pragma unroll
-            for (int i = 0; i < 6; i++) p[i] = t2[i] * st;
-        }
-        double v0, v1, v2;
-        if (p[0] >= p[3] && p[0] >= p[5]) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-        else if (p[3] >= p[5]) { v0 = p[1]; v1 = p[3]; v2 = p[4]; }
-        else { v0 = p[2]; v1 = p[4]; v2 = p[5]; }
-        const double nn = v0 * v0 + v1 * v1 + v2 * v2;
-        if (!(nn > 0.0)) break;
-        const double rn = det_rsqrt(nn);
-        v0 = v0 * rn; v1 = v1 * rn; v2 = v2 * rn;
-        const double cv0 = c[0] * v0 + c[1] * v1 + c[2] * v2, cv1 = c[1] * v0 + c[3] * v1 + c[4] * v2, cv2 = c[2] * v0 + c[4] * v1 + c[5] * v2;
-        double l3 = v0 * cv0 + v1 * cv1 + v2 * cv2;
-        const double av0 = a[0] * v0 + a[1] * v1 + a[2] * v2, av1 = a[1] * v0 + a[3] * v1 + a[4] * v2, av2 = a[2] * v0 + a[4] * v1 + a[5] * v2;
-        const double pr = v0 * av0 + v1 * av1 + v2 * av2;
-        const double sm = (c[0] + c[3] + c[5]) - l3;
-        if (l3 < 0.0) l3 = 0.0;
-        const double mth = l3 / (double)plane_ratio;
-        if (!((mth <= 0.5 * sm) && ((mth * mth - sm * mth) + pr >= 0.0))) break;
-        const double spread_q = (double)min_spread * 65536.0;
-        const double mw = (spread_q * spread_q) * sc;   // the threshold in the units c was scaled to
-        if (!((mw <= 0.5 * sm) && ((mw * mw - sm * mw) + pr >= 0.0))) break;
-        int im = 0;
-        double vm = fabs(v0);
-        if (fabs(v1) > vm) { im = 1; vm = fabs(v1); }
-        if (fabs(v2) > vm) { im = 2; }
-        const double lead = im == 0 ? v0 : (im == 1 ? v1 : v2);
-        if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
-        out = make_float4((float)v0, (float)v1, (float)v2, 0.f);
-    } while (0);
-    s_nrm[threadIdx.x] = out;
-    }
-    __syncthreads();
-    // every point takes the normal of its voxel: the trip's voxels are consecutive in the head list, so their points are ONE contiguous
-    // stretch of the sorted order; a thread per position, its voxel found by bisection of the (ascending) heads in LDS; written straight
-    // into the sorted order of every level of the cloud (the builds behind this one), through the level's inverse permutation. (This was
-    // two more launches: one probing the hash table once per point to find the head, one gathering the normals into each level's order.)
-    {
-        const uint32_t p0 = s_head[0], p1 = s_head[n_trip];
-        const uint32_t* sval = sorted_vals(B);
-        for (uint32_t t0 = p0 + threadIdx.x; t0 < p1; t0 += 1024u) {   // four positions per thread and trip: their (dependent) loads are in flight together
-            uint32_t oi[4], vox[4]; bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t t = t0 + 256u * (uint32_t)u; ok[u] = t < p1; oi[u] = ok[u] ? sval[t] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t t = t0 + 256u * (uint32_t)u;
-                uint32_t lo = 0, hi = n_trip;   // the last voxel with head <= t
-#pragma unroll
-                for (int st = 0; st < 7; st++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (hi - lo > 1u) { if (s_head[mid] <= t) lo = mid; else hi = mid; }
-                }
-                vox[u] = lo;
-            }
-            for (int l = 1; l < grids_per_cloud; l++) {
-                const M3dBuild& LB = builds[ng_build + l];
-                if (!LB.nrm_sorted) continue;
-                const uint32_t* inv = level_inverse(LB);
-                uint32_t pos[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) pos[u] = ok[u] ? inv[oi[u]] : 0u;
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (ok[u]) LB.nrm_sorted[pos[u]] = s_nrm[vox[u]];
-            }
-        }
-    }
-    __syncthreads();   // (the sums are overwritten by the next trip)
-    }
+    B.nrm_sorted[j] = o;
 }
 
 // ---- export helpers (introspection API) -----------------------------------------------------------
@@ -1364,11 +1441,14 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
         M3D_DBG(s, "k_tile_build");
     }
     if (any_normals) {
-        hipLaunchKernelGGL(k_cell_moments, dim3(blocks * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, n_clouds, blocks);
-        M3D_DBG(s, "k_cell_moments");
-        const int nb_n = std::min((max_n + NRM_TRIP - 1) / NRM_TRIP, 256);
-        hipLaunchKernelGGL(k_normals, dim3(nb_n * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread, n_clouds, nb_n);   // 64 voxels per block and trip; the voxel count is only known on the device: grid-stride
-        M3D_DBG(s, "k_normals");
+        const int nb_m = (blocks + NRM_PPT - 1) / NRM_PPT;
+        hipLaunchKernelGGL(k_nrm_moments, dim3(nb_m * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, n_clouds, nb_m);
+        M3D_DBG(s, "k_nrm_moments");
+        const int nb_s = std::min(blocks, 256);   // voxels are taken 32 at a time, grid-stride (their number is only known on the device)
+        hipLaunchKernelGGL(k_nrm_solve, dim3(nb_s * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread, n_clouds, nb_s);
+        M3D_DBG(s, "k_nrm_solve");
+        hipLaunchKernelGGL(k_nrm_handout, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+        M3D_DBG(s, "k_nrm_handout");
     }
     return hipGetLastError();
 }

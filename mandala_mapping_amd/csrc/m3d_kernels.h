@@ -55,8 +55,19 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     uint32_t* blkw;              // [ceil(n / 256)] workspace: occupied voxels per 256 sorted positions (k_count_cells)
     uint32_t* order;             // [ceil(n / 256)] out (levels only, else null): the 256-point blocks of the sorted cloud, most crowded first (k_table_params)
     uint32_t* dyn;               // out: the grid's M3dLevelMeta (144 B; its first 8 words are the dyn counters {occupied voxels, hmask, hshift, ...})
-    long long* mom;              // [10 n] zeroed workspace, normal grids only (else null)
-    float4* nrm_sorted;          // [n] out: the normals in this level's sorted order, written by the cloud's normal-grid build (level builds of point-to-plane clouds, else null)
+    // a9 (round 5): the normal-estimation grid is never sorted. Its build (a cloud's first) carries the grid's GEOMETRY (k_grid_params) and an open-addressing
+    // table of its occupied voxels, filled from the cloud's finest level in that level's sorted order (a normal-grid voxel is a short run there): host sets n = 0,
+    // so every stage of the sort / table pipeline skips the build.
+    uint32_t* nkeys;             // [ncap] normal grids only (else null): voxel key ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2), or M3D_INVALID_KEY (k_clear_table)
+    long long* mom;              // [ncap][10] exact moments {n, S[3], P[6]} of the slot's voxel (zeroed by the thread that inserted the key)
+    float4* nnrm;                // [ncap] the voxel's normal ({0,0,0,0}: none)
+    uint32_t* nlist;             // [256 * ceil(n / 256)] the slots every 256-position block of the finest level inserted (k_finalize_level), nvcnt[blk] of them
+    uint32_t* nvcnt;             // [ceil(n / 256)]
+    uint32_t ncap;               // slots: a power of two >= 2 n
+    int32_t nshift;              // 32 - log2(ncap)
+    int32_t nrm_build;           // level builds of a cloud with normals: index of the cloud's normal-grid build (else -1)
+    int32_t nrm_feed;            // 1 on the level (a cloud's finest) whose sorted order fills the normal grid's table
+    float4* nrm_sorted;          // [n] out: the normals in this level's sorted order (k_nrm_handout; level builds of point-to-plane clouds, else null)
     M3dTileHdr* thdr;            // [m3d_tiles_of(n)] out: tile headers (levels of clouds that can be targets, else null)
     uint8_t* timg;               // [tiles + pool][M3D_TILE_IMG_BYTES] out: tile images (k_tile_build), tiles = m3d_tiles_of(n), pool = m3d_tile_pool(tiles)
     M3dTileImgMeta* timeta;      // [tiles + pool] out

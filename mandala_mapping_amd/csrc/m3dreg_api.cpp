@@ -373,7 +373,9 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     // ---- workspace layout (device) + pinned host staging -------------------------------------------------
     std::vector<uint8_t*> staged(k, nullptr);
     std::vector<uint32_t*> aabb(k, nullptr);
-    struct BuildWs { uint32_t *ka, *va, *kb, *vb, *hist, *dyn, *blkw; DevLevel ng; long long* mom; };
+    struct BuildWs { uint32_t *ka = nullptr, *va = nullptr, *kb = nullptr, *vb = nullptr, *hist = nullptr, *dyn = nullptr, *blkw = nullptr;
+                     // a normal grid (a point-to-plane cloud's first build): its voxel table (round 5: never sorted, see bucket.hip)
+                     uint32_t *nkeys = nullptr, *nlist = nullptr, *nvcnt = nullptr; long long* mom = nullptr; float4* nnrm = nullptr; uint32_t ncap = 0; };
     std::vector<BuildWs> bw(n_builds);
     M3dDecode* d_dec = nullptr; M3dBuild* d_builds = nullptr; uint8_t* zero_lo = nullptr; uint8_t* zero_hi = nullptr;
     auto layout = [&](void* base) -> size_t {
@@ -388,25 +390,25 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
         uint32_t* dyn_all = w.take<uint32_t>(mw * n_builds);       // one M3dLevelMeta per build (the normal grids' live here, the levels' in their clouds)
         for (size_t b = 0; b < n_builds; b++) bw[b].dyn = base ? dyn_all + mw * b : nullptr;
         w.take<uint8_t>(0); zero_hi = base ? static_cast<uint8_t*>(base) + ((w.off + 255) & ~size_t(255)) : nullptr;
-        for (size_t i = 0; i < k; i++) {
-            BuildWs& B = bw[i * size_t(grids_per_cloud)];
-            B.mom = (want_normals && !in[i].src_only) ? w.take<long long>(10 * in[i].n) : nullptr;   // 80 B per point slot, only the voxel heads' slots are used
-        }
         // --- the rest ---
         for (size_t i = 0; i < k; i++) {
             const size_t n = in[i].n;
             staged[i] = (!in[i].is_device) ? w.take<uint8_t>(in[i].generic ? in[i].data_bytes : (in[i].aligned ? n * in[i].step : 12 * n)) : nullptr;
             for (int gidx = 0; gidx < grids_per_cloud; gidx++) {
                 BuildWs& B = bw[i * size_t(grids_per_cloud) + size_t(gidx)];
+                if (want_normals && gidx == 0) {   // the normal grid: no sort workspace — a table of its occupied voxels (keys 4 B + moments 80 B + normal 16 B per slot; only taken
+                    // slots are ever touched beyond the keys) and the list of the slots every 256-position block of the finest level takes
+                    if (!in[i].src_only) {
+                        B.ncap = table_cap(n);
+                        B.nkeys = w.take<uint32_t>(2 * size_t(B.ncap));   // keys, then the "further runs of this voxel" counters
+                        B.mom = w.take<long long>(10 * size_t(B.ncap)); B.nnrm = w.take<float4>(B.ncap);
+                        B.nlist = w.take<uint32_t>(256 * ((n + 255) / 256)); B.nvcnt = w.take<uint32_t>((((n + 255) / 256) + 15) & ~size_t(15));   // (read sixteen at a time)
+                    }
+                    continue;
+                }
                 B.ka = w.take<uint32_t>(n); B.va = w.take<uint32_t>(n); B.kb = w.take<uint32_t>(n); B.vb = w.take<uint32_t>(n);
                 B.hist = w.take<uint32_t>(256 * size_t(m3d_sort_tiles(int(n)) + 1));
                 B.blkw = w.take<uint32_t>((n + 255) / 256);
-                if (want_normals && gidx == 0) {   // the normal grid lives in the workspace only
-                    DevLevel& G = B.ng;
-                    G.hcap = table_cap(n); G.bigcap = uint32_t(n / 65536 + 1);
-                    G.pts = w.take<float4>(n); G.htab = w.take<M3dBucket>(G.hcap); G.bigcum = w.take<uint32_t>(size_t(G.bigcap) * 8);
-                    G.keys = w.take<uint32_t>(n); G.skey = w.take<uint32_t>(n); G.perm = w.take<uint32_t>(n);
-                }
             }
         }
         return (w.off + 255) & ~size_t(255);
@@ -466,28 +468,38 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
             const size_t bi = i * size_t(grids_per_cloud) + size_t(gidx);
             BuildWs& W = bw[bi];
             const bool is_ng = want_normals && gidx == 0;
-            DevLevel& L = is_ng ? W.ng : c->lv[gidx - (want_normals ? 1 : 0)];
             M3dBuild& B = h_builds[bi];
             memset(&B, 0, sizeof(B));
-            B.n = c->n; B.sort_passes = 0; B.ntiles = m3d_sort_tiles(c->n);
-            {   // a coarser level of a pyramid is sorted from its cloud's finest level's order (M3dBuild::fine)
-                const int lvl = gidx - (want_normals ? 1 : 0);
-                B.fine = (!is_ng && P.n_levels > 1 && lvl < P.n_levels - 1) ? int(i * size_t(grids_per_cloud)) + (want_normals ? 1 : 0) + (P.n_levels - 1) : -1;
-            }
+            B.fine = -1; B.nrm_build = -1;
             B.xyz = c->xyz; B.aabb = aabb[i];
-            B.grid.leaf = is_ng ? P.normal_leaf : P.leaf[gidx - (want_normals ? 1 : 0)];
+            if (is_ng) {   // geometry + error state from k_grid_params (it is the cloud's first build: its aabb pointer is the one that kernel reads), nothing sorted
+                B.n = 0; B.ntiles = 0;
+                B.grid.leaf = P.normal_leaf;
+                B.dyn = W.dyn;
+                if (!no_normals) {
+                    B.nkeys = W.nkeys; B.mom = W.mom; B.nnrm = W.nnrm; B.nlist = W.nlist; B.nvcnt = W.nvcnt; B.ncap = W.ncap;
+                    int lg = 0; while ((1u << lg) < W.ncap) lg++;
+                    B.nshift = 32 - lg;
+                }
+                continue;
+            }
+            const int lvl = gidx - (want_normals ? 1 : 0);
+            DevLevel& L = c->lv[lvl];
+            B.n = c->n; B.sort_passes = 0; B.ntiles = m3d_sort_tiles(c->n);
+            // a coarser level of a pyramid is sorted from its cloud's finest level's order (M3dBuild::fine)
+            B.fine = (P.n_levels > 1 && lvl < P.n_levels - 1) ? int(i * size_t(grids_per_cloud)) + (want_normals ? 1 : 0) + (P.n_levels - 1) : -1;
+            B.grid.leaf = P.leaf[lvl];
             B.keys = L.keys; B.ka = W.ka; B.va = W.va; B.kb = W.kb; B.vb = W.vb; B.hist = W.hist;
-            B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.src3 = is_ng ? nullptr : L.src3; B.htab = L.htab; B.hcap = L.hcap;
-            B.cbox = is_ng ? nullptr : L.cbox;
-            B.blkw = W.blkw; B.order = is_ng ? nullptr : L.order;
-            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = is_ng ? W.dyn : L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
-            B.mom = is_ng ? bw[i * size_t(grids_per_cloud)].mom : nullptr;
-            B.nrm_sorted = (is_ng || no_normals) ? nullptr : L.nrm;
-            if (is_ng && no_normals) { B.n = 0; B.ntiles = 0; B.mom = nullptr; }   // the normal grid of a source-only cloud is not built
-            if (!is_ng && no_normals && gidx - (want_normals ? 1 : 0) < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // nor the coarser levels of its pyramid: a registration streams a source in its FINEST level's order on every level (build_jobs)
-            if (!is_ng && no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
+            B.skey_out = L.skey; B.perm_out = L.perm; B.pts = L.pts; B.src3 = L.src3; B.htab = L.htab; B.hcap = L.hcap;
+            B.cbox = L.cbox;
+            B.blkw = W.blkw; B.order = L.order;
+            B.bigcum = L.bigcum; B.bigcap = L.bigcap; B.dyn = L.dyn;   // a level's meta lives in its cloud (read by the jobs later)
+            B.nrm_sorted = no_normals ? nullptr : L.nrm;
+            if (want_normals && !no_normals) { B.nrm_build = int(i * size_t(grids_per_cloud)); B.nrm_feed = (lvl == P.n_levels - 1) ? 1 : 0; }
+            if (no_normals && lvl < P.n_levels - 1) { B.n = 0; B.ntiles = 0; B.fine = -1; }   // the coarser levels of a source-only cloud's pyramid are not built: a registration streams a source in its FINEST level's order on every level (build_jobs)
+            if (no_normals) { B.htab = nullptr; B.cbox = nullptr; }         // nor its bucket table and chunk boxes: nobody will search it
             any_fine = any_fine || B.fine >= 0;
-            if (!is_ng && !no_normals && h->tiles && L.thdr) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = std::max(any_tiles, gidx == grids_per_cloud - 1 ? 1 : 2); c->has_tiles = true; }
+            if (!no_normals && h->tiles && L.thdr) { B.thdr = L.thdr; B.timg = L.timg; B.timeta = L.timeta; B.occ = L.occ; any_tiles = std::max(any_tiles, gidx == grids_per_cloud - 1 ? 1 : 2); c->has_tiles = true; }
         }
     }
     // decode and build descriptors sit side by side, laid out alike on both sides of the bus: ONE copy (every copy is a blit kernel
