@@ -623,7 +623,7 @@ def _r(x, sig=6):
 def compact_line(full):
     """The ONE line of the contract, built from the full result: the contract's keys, a numbers-only `roofline`, a compact `cpu_baseline`,
     `legs` as {name: {value, ms_per_step, frac_alone, ...}}. Every definition and every prose field lives in DESIGN.md section 6 (keyed by
-    `roofline_definition_version`) and in the full result (gpurun_out/bench_full.json + stderr). Always < LINE_BUDGET bytes
+    `roofline_definition_version`) and in the full result (gpurun_out/bench_result_full.json + stderr). Always < LINE_BUDGET bytes
     (tests/test_bench_launcher.py builds it from a canned full result and from one eight times as wordy)."""
     pick = lambda d, keys: {k: d[k] for k in keys if isinstance(d, dict) and k in d}
     line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
@@ -691,7 +691,7 @@ def compact_line(full):
         line["legs"] = legs
     if isinstance(full.get("per_rank"), list):
         line["per_rank"] = [pick(p, ("rank", "pairs", "own_work_ms_median")) for p in full["per_rank"][:8] if isinstance(p, dict)]
-    line["full_result"] = "gpurun_out/bench_full.json (and stderr)"
+    line["full_result"] = "gpurun_out/bench_result_full.json (and stderr)"
     line = _r(line)
     # belt and braces: if a future field pushes the line over the budget, optional parts go first — the contract's keys, roofline and cpu_baseline stay
     for drop in ("per_rank", "legs", "blocks"):
@@ -702,10 +702,10 @@ def compact_line(full):
 
 
 def emit(full):
-    """Full result -> gpurun_out/bench_full.json and stderr; the compact line -> stdout, the ONLY thing this run prints there."""
+    """Full result -> gpurun_out/bench_result_full.json and stderr; the compact line -> stdout, the ONLY thing this run prints there."""
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "bench_result_full.json"), "w") as f:
             json.dump(full, f)
     except OSError:
         pass

@@ -25,6 +25,24 @@ __device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr) {
     (void)rows;
     return r;
 }
+// SLICED rows (round 5), for the kernels whose workgroups gather or scatter with spatial locality: a row is launched with 8 * ceil(bpr / 8) workgroups and
+// XCD x (the dispatcher deals workgroups round-robin by linear id; a padded row starts at a multiple of 8) takes the x-th CONTIGUOUS eighth of the row's
+// blocks. A cloud is still spread over all eight XCDs, but each XCD's L2 sees one compact stretch of the sorted order — one region of space, whose points
+// also sit close together in the input (scan) order — instead of every eighth block of the whole cloud. blk >= bpr: a padding workgroup, nothing to do.
+__device__ __forceinline__ M3dRB m3d_row_block_sliced(int bpr, int sliced) {
+    const int id = (int)blockIdx.x;
+    const int per = (bpr + 7) >> 3, w = per << 3;
+    M3dRB r;
+    r.row = id / w;
+    const int k = id - r.row * w;
+    r.blk = sliced ? (k & 7) * per + (k >> 3) : k;
+    return r;
+}
+static inline int m3d_sliced_grid(int bpr) { return ((bpr + 7) >> 3) << 3; }
+// (M3DREG_SLICED: A/B switch, bit 0 = k_finalize_level, 1 = k_rs_scatter, 2 = k_tile_build; default all on. Measured, profiles/r05_sliced.txt: the kernels' durations
+// alone do not move — they are latency-bound — but k_finalize_level fetches 50 MB per 16-cloud step instead of 109, k_rs_scatter writes 42 instead of 54, k_tile_build
+// fetches 40 instead of 58, and the headline, where four chains compete for the fabric, gains 0.8 %)
+static inline int m3d_sliced_on() { static const int on = [] { const char* v = getenv("M3DREG_SLICED"); return v ? atoi(v) : 7; }(); return on; }
 
 #define RS_THREADS 256
 #define RS_ROUNDS 8
@@ -158,8 +176,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__
         const int iz = (int)m3d_cell_f(pz, B.grid.mn[2], B.grid.inv_leaf);
         key = m3d_voxel_key(B.grid.cb, ix, iy, iz);
     }
-    B.keys[i] = key;
-    if (B.fine < 0) { B.ka[i] = key; B.va[i] = (uint32_t)i; }   // (a coarser level of a pyramid is keyed again in the finest level's order: k_rekey)
+    B.keys[i] = key;   // (pass 0 of the sort reads this array and takes the position as the value: no second copy of the keys, no identity array — 8 bytes per point less
+                       //  written here and 4 less read there; a coarser level of a pyramid is keyed again in the finest level's order: k_rekey fills ka / va)
 }
 
 // a coarser level of a pyramid starts its sort from the finest level's ORDER (M3dBuild::fine): the LSD passes are stable, so inside a
@@ -181,6 +199,7 @@ __device__ __forceinline__ void sort_buffers(const M3dBuild& B, int pass, const 
                                              uint32_t*& vout) {
     if (pass & 1) { kin = B.kb; vin = B.vb; kout = B.ka; vout = B.va; }
     else { kin = B.ka; vin = B.va; kout = B.kb; vout = B.vb; }
+    if (pass == 0 && B.fine < 0) { kin = B.keys; vin = nullptr; }   // the keys in input order; value = position
     if (pass == B.sort_passes - 1) { kout = B.skey_out; vout = B.perm_out; }   // the last pass scatters straight into the cloud's own arrays
 }
 __device__ __forceinline__ const uint32_t* sorted_keys(const M3dBuild& B) { return B.skey_out; }
@@ -279,11 +298,11 @@ __global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restric
     }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr, int sliced) {
+    const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
     const int tile = rb.blk;
     const M3dBuild& B = builds[rb.row];
-    if (pass >= B.sort_passes || tile >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
+    if (tile >= bpr || pass >= B.sort_passes || tile >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
     const int n = B.n, shift = 8 * pass, ntiles = B.ntiles;
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
         const int i = base + r * RS_THREADS + t;
         const bool ok = i < n;
         key[r] = ok ? kin[i] : 0u;
-        val[r] = ok ? vin[i] : 0u;
+        val[r] = ok ? (vin ? vin[i] : (uint32_t)i) : 0u;
         const uint32_t d = (key[r] >> shift) & 255u;
         // lanes of this wave holding the same digit: 8 ballots (wave64 "match_any")
         unsigned long long m = __ballot(ok);
@@ -547,12 +566,12 @@ __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const 
     return m3d_bucket_key(g, ix >> 1, iy >> 1, iz >> 1);
 }
 
-__global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
+__global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds, int rows, int bpr, int sliced) {
+    const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
     const M3dBuild& B = builds[rb.row];
     const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     const int n = B.n;
-    if (rb.blk * (int)blockDim.x >= n) return;   // block-uniform
+    if (rb.blk >= bpr || rb.blk * (int)blockDim.x >= n) return;   // block-uniform
     const bool inb = j < n;
     const uint32_t* skey = sorted_keys(B);
     const uint32_t* sval = sorted_vals(B);
@@ -744,8 +763,9 @@ extern "C" hipError_t m3d_debug_read_tb(unsigned long long* out, unsigned int* n
 #else
 #define TB_STAMP(k) ((void)0)
 #endif
-__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
+__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int rows, int bpr, int sliced) {
+    const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
+    if (rb.blk >= bpr) return;
     const M3dBuild& B = builds[rb.row * row_stride + row_first];   // (a row per cloud: its last build — tiles on finest levels only)
     if (!B.thdr || !B.htab) return;
     const int nv = B.grid.n_valid;
@@ -1419,7 +1439,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
                 hipLaunchKernelGGL(k_rs_scan_apply, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
                 M3D_DBG(s, "k_rs_scan");
             }
-            hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(m3d_sliced_grid(ntiles) * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles, (m3d_sliced_on() >> 1) & 1);
             M3D_DBG(s, "k_rs_scatter");
         }
     }
@@ -1430,14 +1450,14 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_table_params");
     hipLaunchKernelGGL(k_clear_table, dim3(cb * n_builds), dim3(256), 0, s, d_builds, n_builds, cb);
     M3D_DBG(s, "k_clear_table");
-    hipLaunchKernelGGL(k_finalize_level, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+    hipLaunchKernelGGL(k_finalize_level, dim3(m3d_sliced_grid(blocks) * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks, m3d_sliced_on() & 1);
     M3D_DBG(s, "k_finalize_level");
     hipLaunchKernelGGL(k_bucket_counts, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
     M3D_DBG(s, "k_bucket_counts");
     hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
     M3D_DBG(s, "k_chunk_boxes");
     if (any_tiles) {
-        hipLaunchKernelGGL(k_tile_build, dim3(m3d_tiles_of(max_n) * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1, n_clouds, m3d_tiles_of(max_n));
+        hipLaunchKernelGGL(k_tile_build, dim3(m3d_sliced_grid(m3d_tiles_of(max_n)) * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1, n_clouds, m3d_tiles_of(max_n), (m3d_sliced_on() >> 2) & 1);
         M3D_DBG(s, "k_tile_build");
     }
     if (any_normals) {

@@ -63,7 +63,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     float4* nnrm;                // [ncap] the voxel's normal ({0,0,0,0}: none)
     uint32_t* nlist;             // [256 * ceil(n / 256)] the slots every 256-position block of the finest level inserted (k_finalize_level), nvcnt[blk] of them
     uint32_t* nvcnt;             // [ceil(n / 256)]
-    uint32_t ncap;               // slots: a power of two >= 2 n
+    uint32_t ncap;               // slots: a power of two > 1.25 n
     int32_t nshift;              // 32 - log2(ncap)
     int32_t nrm_build;           // level builds of a cloud with normals: index of the cloud's normal-grid build (else -1)
     int32_t nrm_feed;            // 1 on the level (a cloud's finest) whose sorted order fills the normal grid's table

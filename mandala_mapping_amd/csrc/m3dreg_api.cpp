@@ -399,7 +399,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
                 if (want_normals && gidx == 0) {   // the normal grid: no sort workspace — a table of its occupied voxels (keys 4 B + moments 80 B + normal 16 B per slot; only taken
                     // slots are ever touched beyond the keys) and the list of the slots every 256-position block of the finest level takes
                     if (!in[i].src_only) {
-                        B.ncap = table_cap(n);
+                        { uint32_t c = 16; while (size_t(c) < n + n / 4 + 16) c <<= 1; B.ncap = c; }   // a power of two > 1.25 n: at most n voxels, so there is always an empty slot to end a probe chain (an ordinary cloud fills a few per cent)
                         B.nkeys = w.take<uint32_t>(2 * size_t(B.ncap));   // keys, then the "further runs of this voxel" counters
                         B.mom = w.take<long long>(10 * size_t(B.ncap)); B.nnrm = w.take<float4>(B.ncap);
                         B.nlist = w.take<uint32_t>(256 * ((n + 255) / 256)); B.nvcnt = w.take<uint32_t>((((n + 255) / 256) + 15) & ~size_t(15));   // (read sixteen at a time)

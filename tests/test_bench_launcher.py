@@ -112,5 +112,5 @@ def test_emit_prints_exactly_one_stdout_line(tmp_path):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and len(lines[0]) < 6000 and json.loads(lines[0])["value"] > 0
-    assert json.load(open(tmp_path / "gpurun_out" / "bench_full.json"))["legs"]["config5"]["levels"]      # the full result is on disk (and on stderr)
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_result_full.json"))["legs"]["config5"]["levels"]      # the full result is on disk (and on stderr)
     assert "[bench full result] {" in r.stderr
