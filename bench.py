@@ -814,8 +814,9 @@ def extra_legs(args):
 
 
 def run_config5(args):
-    """BASELINE config 5: a 100k-point live scan against the ~2 M-point aggregated map (20 sweeps along a 10 m trajectory, de-duplicated
-    at 2 cm), multi-resolution 0.4 / 0.2 / 0.1 m, 10 iterations each, point-to-plane. A single giant pair does not shard ("replicas only",
+    """BASELINE config 5: a 100k-point live scan against the 2 066 481-point aggregated map (synth.config5: 22 sweeps along a 10 m trajectory,
+    de-duplicated at 1 cm; rounds 1-3 built 20 sweeps at 2 cm = 1.51 M points: scripts/c5_old_map.py runs that map, like for like with their
+    numbers), multi-resolution 0.4 / 0.2 / 0.1 m, 10 iterations each, point-to-plane. A single giant pair does not shard ("replicas only",
     SURVEY 8e). Reported: the whole registration (sort of the scan + 30 iterations; the map is bucketed once, outside), ms per iteration and
     the roofline of the correspondence step PER LEVEL (one run per level alone, started from the previous levels' result), on
     12 N + 12 M + 8 C_occ bytes — the one workload whose iteration working set (tens of MB) is larger than an XCD's L2."""

@@ -26,8 +26,10 @@
  *     (more than 24 points per voxel; more than 8 on a level that starts from a coarser one; or a map:
  *     more than 6 and at least 4 x the source) in some / in
  *     every pair and launches the dense-level search kernel only there (alone where it was every pair;
- *     a handle's first batch: behind the ordinary one at every level). A wrong guess costs
- *     microseconds, never a bit.
+ *     a handle's first batch: behind the ordinary one at every level). A batch whose SHAPE differs from the
+ *     last one's (every target >= 4 x its source / none / mixed: host-known sizes) is scheduled like a first batch.
+ *     A wrong guess costs time — at worst one empty 5 us launch per iteration, or an ordinary pair answered by
+ *     the dense-level kernel at roughly twice its usual search time — never a bit.
  *   - Poses map SOURCE-frame points into the TARGET frame: p_target = T * p_source.
  *   - All results are bit-reproducible: they do not depend on launch geometry, scheduling or
  *     atomics order (integer fixed-point normal-equation sums).

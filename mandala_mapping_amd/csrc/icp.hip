@@ -804,8 +804,8 @@ struct M3dNnArgs {
     int tiles;                         // 1 = on
     int ntile_max;                     // tiles per pair the workspace is laid out for (>= tiles of every target of the batch)
     int tile_chunk;                    // records per work item of a tile without crowded voxels: 512, or 256 when the batch is small (launch_iteration)
-    float4* rec;                       // per pair [ntile_max][M3D_TILE_QCAP] + [match_stride]: query records {u.xyz, bits(query | seeded << 31)} of the
-                                       //   tiles, then the records that take the global walk (home bucket empty, tile flagged, slab full)
+    float4* rec;                       // per pair [ntile_max][M3D_TILE_QCAP]: query records {u.xyz, bits(query | seeded << 31)} of the tiles (a query that cannot be
+                                       //   filed — tile flagged, slab full — is walked in global memory by k_nn_iter<false> itself or left M3D_NN_PENDING by k_nn_iter<true>)
     float* recd;                       // same layout: squared distance to the seed (the previous match)
     unsigned long long rec_stride;     // records per pair
     unsigned int* tcnt;                // per pair [ntile_max]: records per tile (zero between iterations)

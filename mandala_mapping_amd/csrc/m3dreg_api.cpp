@@ -122,6 +122,9 @@ struct m3dreg_handle {
     bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
     uint32_t coop_seen = 0;
     uint32_t coop_all = 0;         // ... and the levels at which EVERY pair of that batch had one
+    int coop_shape = -1;           // ... and that batch's SHAPE (host-known sizes): 0 = every target smaller than 4 x its source, 1 = every target a map (>= 4 x), 2 = mixed. A batch of
+                                   // another shape (scan-to-map after scan pairs or the other way round) is scheduled like a handle's first batch: what the last one met says nothing about it
+    int batch_shape = -1;          // shape of the batch being enqueued (build_jobs)
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
@@ -742,6 +745,13 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
     const m3dreg_params& P = h->params;
     max_n_src = 0; max_n_tgt = 0;
     h->batch_all_tiles = h->tiles != 0;
+    {   // the batch's shape; a change of shape forgets the dense-level memory (the latency of an ordinary batch behind a scan-to-map batch)
+        bool any_map = false, any_plain = false;
+        for (size_t i = 0; i < n_pairs; i++)
+            if (pairs[i].source && pairs[i].target) { if ((long long)pairs[i].target->n >= 4ll * (long long)pairs[i].source->n) any_map = true; else any_plain = true; }
+        h->batch_shape = any_map ? (any_plain ? 2 : 1) : 0;
+        if (h->coop_known && h->batch_shape != h->coop_shape) h->coop_known = false;
+    }
     for (size_t i = 0; i < n_pairs; i++) {
         const m3dreg_cloud* s = pairs[i].source;
         const m3dreg_cloud* t = pairs[i].target;
@@ -1159,7 +1169,7 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     {
         uint32_t seen = 0, all = 0xFFFFFFFFu;
         for (size_t i = 0; i < h->pending_pairs; i++) { seen |= h->h_states[i].coop_levels; all &= h->h_states[i].coop_levels; }
-        h->coop_seen = seen; h->coop_all = h->pending_pairs ? all : 0u; h->coop_known = true;
+        h->coop_seen = seen; h->coop_all = h->pending_pairs ? all : 0u; h->coop_known = true; h->coop_shape = h->batch_shape;
     }
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);

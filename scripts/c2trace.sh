@@ -1,5 +1,5 @@
 #!/bin/bash
-# config 5: kernel durations per launch, in order, for ONE registration (the last of the run)
+# config 2: kernel durations per launch, in order, for ONE registration (the last of the run)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/c2t
