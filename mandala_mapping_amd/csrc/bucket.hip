@@ -18,8 +18,7 @@
 // 41 -> 77, k_tile_build 47 -> 74, k_rs_scatter 19.8 -> 23.9; bucketing 0.32 -> 0.49 ms per step, profiles/r04_xcd_rows.txt): eight XCDs walking
 // eight far-apart address streams lose more in DRAM locality than the L2s gain.
 struct M3dRB { int row, blk; };
-__device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr) {
-    const int id = (int)blockIdx.x;
+__device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr, int id = (int)blockIdx.x) {
     M3dRB r;
     r.row = id / bpr; r.blk = id - r.row * bpr;
     (void)rows;
@@ -29,8 +28,7 @@ __device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr) {
 // XCD x (the dispatcher deals workgroups round-robin by linear id; a padded row starts at a multiple of 8) takes the x-th CONTIGUOUS eighth of the row's
 // blocks. A cloud is still spread over all eight XCDs, but each XCD's L2 sees one compact stretch of the sorted order — one region of space, whose points
 // also sit close together in the input (scan) order — instead of every eighth block of the whole cloud. blk >= bpr: a padding workgroup, nothing to do.
-__device__ __forceinline__ M3dRB m3d_row_block_sliced(int bpr, int sliced) {
-    const int id = (int)blockIdx.x;
+__device__ __forceinline__ M3dRB m3d_row_block_sliced(int bpr, int sliced, int id = (int)blockIdx.x) {
     const int per = (bpr + 7) >> 3, w = per << 3;
     M3dRB r;
     r.row = id / w;
@@ -39,10 +37,11 @@ __device__ __forceinline__ M3dRB m3d_row_block_sliced(int bpr, int sliced) {
     return r;
 }
 static inline int m3d_sliced_grid(int bpr) { return ((bpr + 7) >> 3) << 3; }
-// (M3DREG_SLICED: A/B switch, bit 0 = k_finalize_level, 1 = k_rs_scatter, 2 = k_tile_build; default all on. Measured, profiles/r05_sliced.txt: the kernels' durations
-// alone do not move — they are latency-bound — but k_finalize_level fetches 50 MB per 16-cloud step instead of 109, k_rs_scatter writes 42 instead of 54, k_tile_build
-// fetches 40 instead of 58, and the headline, where four chains compete for the fabric, gains 0.8 %)
-static inline int m3d_sliced_on() { static const int on = [] { const char* v = getenv("M3DREG_SLICED"); return v ? atoi(v) : 7; }(); return on; }
+// (M3DREG_SLICED: bit 0 = k_finalize_level, 1 = k_rs_scatter, 2 = the tile workgroups of k_tiles_normals; default OFF. Measured, profiles/r05_sliced.txt: sliced,
+// k_finalize_level fetches 50 MB per 16-cloud step instead of 109, k_rs_scatter writes 42 instead of 54, the tile build fetches 40 instead of 58 — and nothing gets
+// faster: alone the kernels are latency-bound, with 64 pairs in one chain k_finalize_level takes 48 instead of 38 us per 8 pairs and the tile build 4 us more (eight XCDs
+// walking eight far-apart stretches lose more in DRAM page locality than their L2s gain, as round 4 found for whole rows), the headline is within +-0.4 %.)
+static inline int m3d_sliced_on() { static const int on = [] { const char* v = getenv("M3DREG_SLICED"); return v ? atoi(v) : 0; }(); return on; }
 
 #define RS_THREADS 256
 #define RS_ROUNDS 8
@@ -209,7 +208,7 @@ __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { retu
 // of a point-to-plane target's bucketing — only to add up ten integers per voxel. Its voxels are SHORT RUNS of the finest level's sorted order (that
 // order follows a Morton curve of 2x2x2-voxel buckets; a coarser voxel is a handful of consecutive buckets, give or take the points the two grids'
 // float arithmetic rounds differently), and the moments are exact integers, so they can be added in any order: the runs' heads insert the voxel into an
-// open-addressing table (k_finalize_level, fused), the runs add their moments to the slot (k_nrm_moments: one set of 64-bit atomics per run and wave),
+// open-addressing table (k_finalize_level, fused), the runs store or add their moments to the slot (k_post_finalize),
 // k_nrm_solve sums the 27 neighbours of every occupied voxel and solves, k_nrm_handout looks every point's voxel up, in every level's order. Same
 // integers, same doubles, same bits as the sorted version and as the oracle's per-point loop (oracle/m3d_oracle.c: grid_normals).
 __device__ __forceinline__ uint32_t nrm_voxel_key(const M3dGrid& g, float x, float y, float z) {
@@ -606,12 +605,12 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
             for (;;) {   // the first head of a voxel to arrive owns its slot; a later run of the same voxel finds it
                 const uint32_t old = atomicCAS(&G.nkeys[h], M3D_INVALID_KEY, nk);
                 if (old == M3D_INVALID_KEY) { won = true; break; }
-                if (old == nk) { atomicAdd(&G.nkeys[G.ncap + h], 1u); break; }   // a further run of a voxel that has its slot: k_nrm_moments then ADDS this voxel's runs instead of storing its one
+                if (old == nk) { atomicAdd(&G.nkeys[G.ncap + h], 1u); break; }   // a further run of a voxel that has its slot: k_post_finalize then ADDS this voxel's runs instead of storing its one
                 h = (h + 1u) & nmask;
             }
             if (won) {
 #pragma unroll
-                for (int i = 0; i < 10; i++) G.mom[10 * (size_t)h + i] = 0;   // (k_nrm_moments, the next launch but two, adds to it)
+                for (int i = 0; i < 10; i++) G.mom[10 * (size_t)h + i] = 0;   // (k_post_finalize, the next launch, stores or adds)
             }
         }
         // the slots this block took, as a list (ranks: wave64 ballots + LDS; no atomics): k_nrm_solve's work items
@@ -632,101 +631,21 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
         uint32_t h = m3d_hash_slot(bk, hshift);
         for (;;) {   // bucket keys are unique here, so a successful CAS owns the slot
             uint32_t old = atomicCAS(&B.htab[h].key, M3D_INVALID_KEY, bk);
-            if (old == M3D_INVALID_KEY) { B.htab[h].start = (uint32_t)j; break; }
+            if (old == M3D_INVALID_KEY) {
+                B.htab[h].start = (uint32_t)j;
+                // more than 65535 points in this bucket? (the sorted keys say so: position j + 65535 still belongs to it) Then its cumulative populations are 32-bit rows
+                // of bigcum, row = j >> 16: two such buckets start at least 65536 positions apart, so the rows are distinct without a counter
+                const bool big = (uint32_t)j + 65535u < (uint32_t)n && (skey[(uint32_t)j + 65535u] >> 3) == (k >> 3);
+                B.htab[h].big = big ? 1u + ((uint32_t)j >> 16) : 0u;
+                break;
+            }
             h = (h + 1) & hmask;
         }
         if (B.occ && B.grid.cb[0] + B.grid.cb[1] + B.grid.cb[2] <= M3D_OCC_BITS) atomicOr(&B.occ[bk >> 5], 1u << (bk & 31u));
     }
 }
 
-// second pass, one probe per occupied voxel: the last point of every VOXEL writes the cumulative population of its voxel
-// and of the empty voxels that follow it inside the bucket (leading empty voxels keep the cleared value 0); when it is also
-// the last point of its BUCKET it writes the bucket's population and, should that exceed 16 bits, claims a bigcum row.
-// The 16-bit cum values of such a bucket are meaningless (and unused): k_bucket_big rewrites them as 32-bit rows.
-__global__ __launch_bounds__(256) void k_bucket_counts(const M3dBuild* __restrict__ builds, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
-    const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
-    const int n = B.n;
-    if (j >= n || !B.htab) return;   // (a source-only cloud has no table)
-    const uint32_t* skey = B.skey_out;
-    const uint32_t k = skey[j];
-    if (k == M3D_INVALID_KEY) return;
-    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
-    if (kn == k) return;                                              // not the last point of its voxel
-    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
-    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
-    const uint32_t hmask = B.dyn[1];
-    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
-    while (B.htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
-    for (int t = s0; t < s1; t++) B.htab[h].cum[t] = (uint16_t)v;
-    if (!same_bucket) {                                               // last point of the bucket
-        B.htab[h].count = v;
-        B.htab[h].big = (v > 65535u) ? (1u + atomicAdd(&B.dyn[4], 1u)) : 0u;
-    }
-}
-
-// third pass, almost always empty (a bucket of 2x2x2 voxels with more than 65535 points): 32-bit cumulative rows
-__device__ __forceinline__ void bucket_big_point(const M3dBuild& B, int j) {
-    const int n = B.n;
-    if (j >= n) return;
-    const uint32_t* skey = B.skey_out;
-    const uint32_t k = skey[j];
-    if (k == M3D_INVALID_KEY) return;
-    const uint32_t kn = (j + 1 < n) ? skey[j + 1] : M3D_INVALID_KEY;
-    if (kn == k) return;
-    const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (k >> 3));
-    const int s0 = (int)(k & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
-    const uint32_t hmask = B.dyn[1];
-    const uint32_t bk = bucket_key_of_point(B.grid, B.pts[j]);
-    uint32_t h = m3d_hash_slot(bk, (int)B.dyn[2]);
-    while (B.htab[h].key != bk) h = (h + 1) & hmask;
-    const uint32_t big = B.htab[h].big;
-    if (big == 0u || big - 1u >= B.bigcap) return;
-    const uint32_t v = (uint32_t)j - B.htab[h].start + 1u;
-    for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)(big - 1u) + t] = v;
-}
-
-// exact AABB of every M3D_CHUNK consecutive sorted (finite) points: the search tests a crowded voxel's chunks by their boxes
-// before it gathers them (min / max of floats: exact, order-independent)
-__global__ __launch_bounds__(256) void k_chunk_boxes(const M3dBuild* __restrict__ builds, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
-    // (the same launch rewrites the rows of buckets with more than 65535 points as 32-bit counts: normally there are none, and an
-    // extra, empty launch cost its 5 us on every step's critical path)
-    if (B.htab && B.dyn[4] != 0u) bucket_big_point(B, rb.blk * (int)blockDim.x + (int)threadIdx.x);
-    if (!B.cbox) return;
-    // four lanes per chunk, four points each (a lane's 16-B loads and its neighbours' fall into the same cache lines), xor-shuffle merge
-    const int t = rb.blk * (int)blockDim.x + (int)threadIdx.x;
-    const int c = t >> 2, sub = t & 3;
-    const int nv = B.grid.n_valid;
-    const bool chunk_ok = c * M3D_CHUNK < nv;              // uniform over the 4 lanes of a chunk
-    const float inf = __uint_as_float(0x7F800000u);
-    float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
-    if (chunk_ok) {
-#pragma unroll
-        for (int k = 0; k < M3D_CHUNK / 4; k++) {
-            const int j = c * M3D_CHUNK + 4 * k + sub;
-            if (j < nv) {
-                const float4 p = B.pts[j];
-                mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
-                mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 1; o < 4; o <<= 1) {   // every lane of the wave takes part (lanes of finished chunks carry +-inf)
-        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
-    }
-    if (chunk_ok && sub == 0) {
-        B.cbox[2 * c] = make_float4(mnx, mny, mnz, 0.f);
-        B.cbox[2 * c + 1] = make_float4(mxx, mxy, mxz, 0.f);
-    }
-}
-
+// (the per-voxel populations of the bucket table, the chunk boxes and the normal grid's moments: k_post_finalize, behind the normals' helpers below)
 
 // ---- target tiles: what a workgroup of the LDS-staged search (icp.hip: k_nn_tiles) holds in LDS -------------------------------------
 // One workgroup per tile (m3d_device.h): the tile's own buckets are the bucket heads among its M3D_TILE_PTS sorted positions; every
@@ -763,8 +682,8 @@ extern "C" hipError_t m3d_debug_read_tb(unsigned long long* out, unsigned int* n
 #else
 #define TB_STAMP(k) ((void)0)
 #endif
-__global__ __launch_bounds__(256) void k_tile_build(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int rows, int bpr, int sliced) {
-    const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
+__device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int bpr, int sliced, int bid) {
+    const M3dRB rb = m3d_row_block_sliced(bpr, sliced, bid);
     if (rb.blk >= bpr) return;
     const M3dBuild& B = builds[rb.row * row_stride + row_first];   // (a row per cloud: its last build — tiles on finest levels only)
     if (!B.thdr || !B.htab) return;
@@ -1108,14 +1027,9 @@ __device__ __forceinline__ void nrm_flush(const M3dBuild& G, uint32_t key, const
         for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(&m[i]), (unsigned long long)v[i]);
     }
 }
-__global__ __launch_bounds__(256) void k_nrm_moments(const M3dBuild* __restrict__ builds, int grids_per_cloud, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& G = builds[rb.row * grids_per_cloud];   // (one row per CLOUD: the normal grid is a cloud's first build)
-    if (!G.nkeys) return;
-    const M3dBuild& L = builds[rb.row * grids_per_cloud + grids_per_cloud - 1];   // the cloud's finest level
-    const int nv = L.grid.n_valid;
-    if (rb.blk * 256 * NRM_PPT >= nv || L.n == 0) return;   // (block-uniform)
-    const int j0 = (rb.blk * 256 + (int)threadIdx.x) * NRM_PPT;
+// the moments part of k_post_finalize: this thread's NRM_PPT consecutive positions j0 ... of the finest level L (points p, finite ones first: nv of them) into the
+// table of the cloud's normal grid G. Every lane of the wave calls it.
+__device__ __forceinline__ void nrm_moments_part(const M3dBuild& G, const M3dBuild& L, const int j0, const float4 (&p)[NRM_PPT], const int nv) {
     const M3dGrid& g = G.grid;
     const int lane = threadIdx.x & 63;
     // the voxels of the positions next to the wave's 256: does its first run begin here, does its last run end here?
@@ -1128,9 +1042,6 @@ __global__ __launch_bounds__(256) void k_nrm_moments(const M3dBuild* __restrict_
     long long v[10], vF[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) { v[i] = 0; vF[i] = 0; }
-    float4 p[NRM_PPT];
-#pragma unroll
-    for (int u = 0; u < NRM_PPT; u++) p[u] = (j0 + u < nv) ? L.pts[j0 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < NRM_PPT; u++) {
         if (j0 + u >= nv) break;
@@ -1191,14 +1102,85 @@ __global__ __launch_bounds__(256) void k_nrm_moments(const M3dBuild* __restrict_
     if (ok && tail) nrm_flush(G, key, v, lw && right_whole);
 }
 
+// ---- behind k_finalize_level: ONE pass over every level's sorted points (round 5; three launches before, each re-reading the points) ------------------
+// A thread takes NRM_PPT = 4 consecutive sorted positions (its 64 bytes of points and five keys are loaded once) and
+//   * bucket table: the last point of every VOXEL writes the cumulative population of its voxel and of the empty voxels that follow it inside the bucket
+//     (leading empty voxels keep the cleared value 0); the last point of a BUCKET writes the bucket's population. A bucket of more than 65535 points keeps
+//     32-bit cumulative rows (k_finalize_level's bucket head saw it in the sorted keys and left 1 + row in the entry: no second pass);
+//   * chunk boxes: the exact AABB of every M3D_CHUNK = 16 consecutive finite points = four threads (min / max of floats: exact, order-independent);
+//   * normals: the moments of the normal-grid voxels' runs (nrm_moments_part), on the level that feeds the cloud's normal grid.
+__global__ __launch_bounds__(256) void k_post_finalize(const M3dBuild* __restrict__ builds, int rows, int bpr) {
+    static_assert(NRM_PPT == 4 && M3D_CHUNK == 16, "a chunk = four threads' positions");
+    const M3dRB rb = m3d_row_block(rows, bpr);
+    const M3dBuild& B = builds[rb.row];
+    const int n = B.n;
+    if (rb.blk * 256 * NRM_PPT >= n) return;   // (block-uniform; n = 0: a build the pipeline skips)
+    const int nv = B.grid.n_valid;
+    const int j0 = (rb.blk * 256 + (int)threadIdx.x) * NRM_PPT;
+    const uint32_t* skey = B.skey_out;
+    float4 p[NRM_PPT];
+    uint32_t k[NRM_PPT + 1];
+#pragma unroll
+    for (int u = 0; u < NRM_PPT; u++) p[u] = (j0 + u < n) ? B.pts[j0 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u <= NRM_PPT; u++) k[u] = (j0 + u < n) ? skey[j0 + u] : M3D_INVALID_KEY;
+    if (B.htab) {   // (block-uniform) the bucket table's populations
+        const uint32_t hmask = B.dyn[1];
+        const int hshift = (int)B.dyn[2];
+        const uint4* tab = reinterpret_cast<const uint4*>(B.htab);
+        // the (up to four) voxel ends among this thread's positions: their table probes first, all in flight together, then the stores
+        bool last[NRM_PPT]; uint32_t bk[NRM_PPT], hs[NRM_PPT]; uint4 lo[NRM_PPT];
+#pragma unroll
+        for (int u = 0; u < NRM_PPT; u++) {
+            last[u] = k[u] != M3D_INVALID_KEY && k[u + 1] != k[u];
+            bk[u] = 0u; hs[u] = 0u; lo[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (last[u]) { bk[u] = bucket_key_of_point(B.grid, p[u]); hs[u] = m3d_hash_slot(bk[u], hshift); lo[u] = tab[2 * (size_t)hs[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NRM_PPT; u++) {
+            if (!last[u]) continue;
+            while (lo[u].x != bk[u]) { hs[u] = (hs[u] + 1u) & hmask; lo[u] = tab[2 * (size_t)hs[u]]; }   // (the bucket exists; a collision is rare)
+            const uint32_t ku = k[u], kn = k[u + 1], h = hs[u];
+            const bool same_bucket = (kn != M3D_INVALID_KEY) && ((kn >> 3) == (ku >> 3));
+            const int s0 = (int)(ku & 7u), s1 = same_bucket ? (int)(kn & 7u) : 8;
+            const uint32_t v = (uint32_t)(j0 + u) - lo[u].y + 1u;       // lo = {key, first sorted position, -, big: 0 or 1 + row (k_finalize_level)}
+            if (lo[u].w == 0u) { for (int t = s0; t < s1; t++) B.htab[h].cum[t] = (uint16_t)v; }
+            else { const uint32_t row = lo[u].w - 1u; if (row < B.bigcap) for (int t = s0; t < s1; t++) B.bigcum[8 * (size_t)row + t] = v; }
+            if (!same_bucket) B.htab[h].count = v;                       // last point of the bucket
+        }
+    }
+    if (B.cbox) {   // (block-uniform) chunk boxes: this thread's quarter of chunk j0 / 16, merged over its four lanes (every lane of the wave shuffles)
+        const float inf = __uint_as_float(0x7F800000u);
+        float mnx = inf, mny = inf, mnz = inf, mxx = -inf, mxy = -inf, mxz = -inf;
+#pragma unroll
+        for (int u = 0; u < NRM_PPT; u++) {
+            if (j0 + u < nv) {
+                mnx = fminf(mnx, p[u].x); mny = fminf(mny, p[u].y); mnz = fminf(mnz, p[u].z);
+                mxx = fmaxf(mxx, p[u].x); mxy = fmaxf(mxy, p[u].y); mxz = fmaxf(mxz, p[u].z);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+        }
+        const int c = j0 / M3D_CHUNK;
+        if ((threadIdx.x & 3u) == 0u && c * M3D_CHUNK < nv) {
+            B.cbox[2 * c] = make_float4(mnx, mny, mnz, 0.f);
+            B.cbox[2 * c + 1] = make_float4(mxx, mxy, mxz, 0.f);
+        }
+    }
+    if (B.nrm_feed) nrm_moments_part(builds[B.nrm_build], B, j0, p, nv);   // (block-uniform)
+}
+
 // Pass 2: once per occupied VOXEL (every point of a voxel sees the same 27 voxels, hence the same sums and the same normal): add the (shifted)
 // moments of the 27 voxels around it and take the smallest eigenvector of the covariance. Work is dealt BY VOXEL: every workgroup scans the per-block
 // counts k_finalize_level left (a few hundred words) into LDS, the voxels are then numbered across the blocks' lists and taken 32 at a time, grid-stride
 // (a workgroup per group of blocks, the first shape, ran 93 us for 8 clouds: a far, sparse stretch of a scan has a voxel per point, a near one two per
 // thousand points). Eight lanes per voxel for the sums (27 table probes shared out), then one lane per voxel solves.
 #define NRM_PREF_CAP 8192   // blocks whose counts one prefix covers (2 M points); larger clouds are taken in stretches of that many blocks
-__global__ __launch_bounds__(256) void k_nrm_solve(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int rows, int bpr) {
-    const M3dRB rb = m3d_row_block(rows, bpr);
+__device__ __forceinline__ void nrm_solve_role(const M3dBuild* __restrict__ builds, int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int bpr, int bid) {
+    const M3dRB rb = m3d_row_block(0, bpr, bid);
     const M3dBuild& G = builds[rb.row * grids_per_cloud];
     if (!G.nkeys) return;
     const M3dBuild& L = builds[rb.row * grids_per_cloud + grids_per_cloud - 1];
@@ -1372,6 +1354,16 @@ __global__ __launch_bounds__(256) void k_nrm_solve(const M3dBuild* __restrict__ 
     }
 }
 
+// The tile images (k_tile_build's work) and the normals' solve (k_nrm_solve's) both follow k_post_finalize and touch nothing of each other's: ONE launch, the first
+// n_tile_blocks workgroups build tiles, the rest solve voxels. Alone on the GPU either is a latency chain that leaves most of the chip idle (44 and 39 us for 16
+// clouds): side by side they take what the longer one takes. (Two streams do the same on paper; measured, profiles/r05_side_stream.txt, the fork / join cost
+// what the overlap saved and the headline lost 11 %.)
+__global__ __launch_bounds__(256) void k_tiles_normals(const M3dBuild* __restrict__ builds, int row_stride, int row_first, int tile_bpr, int sliced, int n_tile_blocks,
+                                                       int grids_per_cloud, float plane_ratio, int min_pts, float min_spread, int solve_bpr) {
+    if ((int)blockIdx.x < n_tile_blocks) tile_build_role(builds, row_stride, row_first, tile_bpr, sliced, (int)blockIdx.x);
+    else nrm_solve_role(builds, grids_per_cloud, plane_ratio, min_pts, min_spread, solve_bpr, (int)blockIdx.x - n_tile_blocks);
+}
+
 // Pass 3: every point takes the normal of its normal-grid voxel — in every level's sorted order, one coalesced pass per level (one table probe per
 // point; neighbours share their voxel's slot). Non-finite points (sorted last) get {0,0,0,0}.
 __global__ __launch_bounds__(256) void k_nrm_handout(const M3dBuild* __restrict__ builds, int rows, int bpr) {
@@ -1452,21 +1444,19 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
     M3D_DBG(s, "k_clear_table");
     hipLaunchKernelGGL(k_finalize_level, dim3(m3d_sliced_grid(blocks) * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks, m3d_sliced_on() & 1);
     M3D_DBG(s, "k_finalize_level");
-    hipLaunchKernelGGL(k_bucket_counts, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
-    M3D_DBG(s, "k_bucket_counts");
-    hipLaunchKernelGGL(k_chunk_boxes, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);   // one thread per sorted position (big-bucket rows), of which 4 per chunk build the boxes
-    M3D_DBG(s, "k_chunk_boxes");
-    if (any_tiles) {
-        hipLaunchKernelGGL(k_tile_build, dim3(m3d_sliced_grid(m3d_tiles_of(max_n)) * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1, n_clouds, m3d_tiles_of(max_n), (m3d_sliced_on() >> 2) & 1);
-        M3D_DBG(s, "k_tile_build");
+    const int nb_p = (blocks + NRM_PPT - 1) / NRM_PPT;
+    hipLaunchKernelGGL(k_post_finalize, dim3(nb_p * n_builds), dim3(256), 0, s, d_builds, n_builds, nb_p);   // table populations, chunk boxes, normal-grid moments: one pass over the sorted points
+    M3D_DBG(s, "k_post_finalize");
+    {
+        const int tile_bpr = m3d_tiles_of(max_n), n_tile_blocks = any_tiles ? m3d_sliced_grid(tile_bpr) * n_clouds : 0;
+        const int nb_s = std::min(blocks, 256), n_solve_blocks = any_normals ? nb_s * n_clouds : 0;   // voxels are taken 32 at a time, grid-stride (their number is only known on the device)
+        if (n_tile_blocks + n_solve_blocks > 0) {
+            hipLaunchKernelGGL(k_tiles_normals, dim3(n_tile_blocks + n_solve_blocks), dim3(256), 0, s, d_builds, grids_per_cloud, grids_per_cloud - 1, tile_bpr, (m3d_sliced_on() >> 2) & 1,
+                               n_tile_blocks, grids_per_cloud, plane_ratio, min_pts, min_spread, nb_s);
+            M3D_DBG(s, "k_tiles_normals");
+        }
     }
     if (any_normals) {
-        const int nb_m = (blocks + NRM_PPT - 1) / NRM_PPT;
-        hipLaunchKernelGGL(k_nrm_moments, dim3(nb_m * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, n_clouds, nb_m);
-        M3D_DBG(s, "k_nrm_moments");
-        const int nb_s = std::min(blocks, 256);   // voxels are taken 32 at a time, grid-stride (their number is only known on the device)
-        hipLaunchKernelGGL(k_nrm_solve, dim3(nb_s * n_clouds), dim3(256), 0, s, d_builds, grids_per_cloud, plane_ratio, min_pts, min_spread, n_clouds, nb_s);
-        M3D_DBG(s, "k_nrm_solve");
         hipLaunchKernelGGL(k_nrm_handout, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
         M3D_DBG(s, "k_nrm_handout");
     }

@@ -13,8 +13,8 @@ bash scripts/kiter.sh ${t}c M3DREG_FUSE_FROM=0 >> gpurun_out/kiter_$t.txt 2>&1 &
 bash scripts/step_traffic.sh > gpurun_out/step_traffic_$t.txt 2>&1 && echo "step_traffic done"
 bash scripts/kstat5.sh $t > gpurun_out/config5_kernel_stats_$t.txt 2>&1 && echo "kstat5 done"
 python3 scripts/map_bench.py > gpurun_out/f4_map_bench_$t.json 2>gpurun_out/map_bench.err && echo "map_bench done"
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full.json 2>gpurun_out/bench_full.err && echo "bench done"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_line.json 2>gpurun_out/bench_line.err && echo "bench done"
 # the traces themselves stay on the box: gpurun merges at most 64 MiB back
 find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete; find gpurun_out -name "*agent_info.csv" -delete
 du -sh gpurun_out | tail -1
-tail -1 gpurun_out/bench_full.json | cut -c1-400
+tail -1 gpurun_out/bench_line.json | cut -c1-400
