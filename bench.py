@@ -769,7 +769,6 @@ def extra_legs(args):
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-extra", "--iters", str(args.iters), "--azimuth", str(args.azimuth)]
     runs = {
         "serial": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1"],
-        "serial_one_chain": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1", "--async-calls"],
         "from_host": ["--steps", "40", "--warmup", "3", "--from-host"],
         "converge": ["--steps", "40", "--warmup", "3", "--converge"],
         # (the default bracket, every 7th iteration: with every iteration bracketed none of them runs fused, and these two legs are LATENCIES of the shipped schedule)
@@ -785,6 +784,7 @@ def extra_legs(args):
             "batch16": ["--pairs-per-gpu", "16", "--inflight", "2", "--queue-depth", "2", "--steps", "10", "--warmup", "3"],
             "batch32": ["--pairs-per-gpu", "32", "--inflight", "2", "--queue-depth", "2", "--steps", "8", "--warmup", "2"],
             "batch64": ["--pairs-per-gpu", "64", "--inflight", "2", "--queue-depth", "2", "--steps", "6", "--warmup", "2"],
+            "serial_async_bracketed": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1", "--async-calls"],   # rounds 1-4's `serial`: async call + wait, event brackets in the timed region
             "from_host_converge": ["--steps", "40", "--warmup", "3", "--from-host", "--converge"],   # SURVEY 8d's literal "registrations/s": H2D of both clouds + bucketing + iterations to eps 1e-5 (at most --iters) + D2H
         })
     legs = {}

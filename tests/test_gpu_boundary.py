@@ -228,7 +228,8 @@ def test_hip_path_under_a_two_rank_process_group(reg, orc):
         assert np.array_equal(T0[i], To)
 
 
-def test_bench_launcher_runs_two_ranks_end_to_end():
+@pytest.mark.parametrize("extra,pts", [((), 100000), (("--azimuth", "1000", "--pairs-per-gpu", "3"), 32000)])
+def test_bench_launcher_runs_two_ranks_end_to_end(extra, pts):
     """the REAL `bench.py --gpus 2` — its launcher (a fresh process that never touches the GPU) starts two rank processes, which
     rendezvous (gloo; both on this box's one GPU: --share-gpu), take their LPT shards of config 4, run the timed steps, gather the poses and
     per-rank times, and rank 0 prints the one line. What the driver's first SCALE run does, minus RCCL and the second device."""
@@ -238,13 +239,15 @@ def test_bench_launcher_runs_two_ranks_end_to_end():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "M3D_BENCH_RANK_PROCESS", "M3D_BENCH_FULL_LINE")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
-                        "--no-extra", "--no-cpu-baseline", "--min-seconds", "0", "--launch-timeout", "110"], capture_output=True, text=True, timeout=120, env=env)
+                        "--no-extra", "--no-cpu-baseline", "--min-seconds", "0", "--launch-timeout", "110"] + list(extra), capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-500:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 2 and d["scaling"] == "weak"
     pr = d["per_rank"]
-    assert len(pr) == 2 and sorted(p["rank"] for p in pr) == [0, 1] and all(len(p["pairs"]) == 8 and p["own_work_ms_median"] > 0 for p in pr)
-    assert not set(pr[0]["pairs"]) & set(pr[1]["pairs"]) and sorted(pr[0]["pairs"] + pr[1]["pairs"]) == list(range(16))
+    B = d["config"]["pairs_per_gpu"]   # (second case: 1000 azimuth steps — no tabulated costs for that, so every rank buckets all pairs once and reads the LPT costs from the DEVICE: m3dreg_cloud_density)
+    assert len(pr) == 2 and sorted(p["rank"] for p in pr) == [0, 1] and all(len(p["pairs"]) == B and p["own_work_ms_median"] > 0 for p in pr)
+    assert not set(pr[0]["pairs"]) & set(pr[1]["pairs"]) and sorted(pr[0]["pairs"] + pr[1]["pairs"]) == list(range(2 * B))
+    assert abs(d["config"]["points_per_cloud"] - pts) < 0.1 * pts
     assert d["max_rot_err_deg"] < 0.2 and d["max_trans_err_m"] < 0.02

@@ -48,6 +48,30 @@ def test_large_cloud_takes_the_separate_scan_of_the_radix_sort(reg, orc):
     _check_bucketing(R.cloud(small), orc.Cloud(p, small), 1)   # (alone: the fused path)
 
 
+@pytest.mark.parametrize("leaf,normal_leaf", [(0.25, 0.07), (0.1, 1.3), (0.2, 0.2), ((0.6, 0.15), 0.33)])
+def test_normals_for_any_ratio_of_normal_leaf_to_leaf(reg, orc, leaf, normal_leaf):
+    """Round 5: the normal-estimation grid is no longer sorted — its voxels are a hash table filled from the finest level's sorted order (bucket.hip:
+    k_finalize_level / k_post_finalize / k_tiles_normals / k_nrm_handout). A normal voxel is then one short run of that order only when normal_leaf is a
+    multiple of the leaf; here it is smaller than a voxel (every voxel of the level holds several normal voxels, interleaved: many runs per voxel, the
+    atomic path), much larger, equal, and incommensurable under a pyramid (every level's order gets the normals) — with non-finite points, a crowded
+    patch and a sparse far field in the cloud. Keys, order and normals bit for bit against the oracle."""
+    rng = np.random.default_rng(5)
+    base = synth.planes_cloud(30000, 91, sigma=0.01, size=12.0)
+    crowd = (rng.normal(0, 0.03, (6000, 3)) + np.float32([1.0, 1.0, 0.0])).astype(np.float32)          # thousands of points in a few voxels
+    far = rng.uniform(-30, 30, (3000, 3)).astype(np.float32)                                            # a voxel per point
+    cloud = np.concatenate([base, crowd, far]).astype(np.float32)
+    cloud = cloud[rng.permutation(len(cloud))]
+    cloud[::977] = np.nan
+    levels = len(leaf) if isinstance(leaf, tuple) else 1
+    p = _params(leaf=leaf, iterations=(1,) * levels if levels > 1 else 1, max_corr_dist=(0.5,) * levels if levels > 1 else 0.5, metric=abi.POINT_TO_PLANE, normal_leaf=normal_leaf)
+    R = reg.Registrar(p)
+    c1, c2 = R.clouds([cloud, base])        # (a batch of two: the second cloud's tables lie behind the first's in the workspace)
+    _check_bucketing(c1, orc.Cloud(p, cloud), levels)
+    _check_bucketing(c2, orc.Cloud(p, base), levels)
+    e = c1.export(levels - 1)
+    assert np.any(e["normals"][: c1.grid_info(levels - 1).n_valid] != 0)
+
+
 @pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
 def test_config1_every_stage_bit_exact(reg, orc, metric):
     src, tgt, Tgt = synth.config1()
