@@ -11,5 +11,7 @@ cp "$(big stats_serial)" profiles/${tag}_serial_kernel_stats.csv
 cp gpurun_out/pmc_summary.json profiles/pmc_summary.json
 cp gpurun_out/pmc_summary.json profiles/${tag}_pmc_summary.json
 [ -f gpurun_out/kiter_${tag//_/}.txt ] && grep -v amdgpu.ids gpurun_out/kiter_${tag//_/}.txt > profiles/${tag}_nn_stage_per_iteration.txt
-[ -f gpurun_out/bench_line.json ] && tail -1 gpurun_out/bench_line.json > profiles/${tag}_bench.json; [ -f gpurun_out/bench_result_full.json ] && cp gpurun_out/bench_result_full.json profiles/${tag}_bench_full.json
+[ -f gpurun_out/bench_line.json ] && tail -1 gpurun_out/bench_line.json > profiles/${tag}_bench.json
+# the full result of THAT run: its stderr carries it (gpurun_out/bench_result_full.json is rewritten by every later bench run)
+[ -f gpurun_out/bench_line.err ] && grep "^\[bench full result\] " gpurun_out/bench_line.err | tail -1 | sed 's/^\[bench full result\] //' > profiles/${tag}_bench_full.json
 ls -la profiles | grep ${tag}
