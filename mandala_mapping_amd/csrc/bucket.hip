@@ -209,7 +209,7 @@ __device__ __forceinline__ const uint32_t* sorted_vals(const M3dBuild& B) { retu
 // order follows a Morton curve of 2x2x2-voxel buckets; a coarser voxel is a handful of consecutive buckets, give or take the points the two grids'
 // float arithmetic rounds differently), and the moments are exact integers, so they can be added in any order: the runs' heads insert the voxel into an
 // open-addressing table (k_finalize_level, fused), the runs store or add their moments to the slot (k_post_finalize),
-// k_nrm_solve sums the 27 neighbours of every occupied voxel and solves, k_nrm_handout looks every point's voxel up, in every level's order. Same
+// the solve workgroups of k_tiles_normals sum the 27 neighbours of every occupied voxel and solve, k_nrm_handout looks every point's voxel up, in every level's order. Same
 // integers, same doubles, same bits as the sorted version and as the oracle's per-point loop (oracle/m3d_oracle.c: grid_normals).
 __device__ __forceinline__ uint32_t nrm_voxel_key(const M3dGrid& g, float x, float y, float z) {
     const int ix = (int)m3d_cell_f(x, g.mn[0], g.inv_leaf), iy = (int)m3d_cell_f(y, g.mn[1], g.inv_leaf), iz = (int)m3d_cell_f(z, g.mn[2], g.inv_leaf);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
     if (t == 0) {
         uint32_t hmask; int hshift;
         m3d_table_size(carryB, B.hcap, hmask, hshift);
-        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u; B.dyn[6] = 0u;   // every word this pipeline reads is written here: no memset needed (dyn[6]: pool images handed out by k_tile_build)
+        B.dyn[0] = carryV; B.dyn[3] = carryB; B.dyn[5] = carryV; B.dyn[4] = 0u; B.dyn[6] = 0u;   // every word this pipeline reads is written here: no memset needed (dyn[6]: pool images handed out by the tile workgroups of k_tiles_normals)
         B.dyn[1] = hmask; B.dyn[2] = (uint32_t)hshift;
     }
     if (B.order) {   // (the loop above ended with a barrier: wv is complete)
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
                 for (int i = 0; i < 10; i++) G.mom[10 * (size_t)h + i] = 0;   // (k_post_finalize, the next launch, stores or adds)
             }
         }
-        // the slots this block took, as a list (ranks: wave64 ballots + LDS; no atomics): k_nrm_solve's work items
+        // the slots this block took, as a list (ranks: wave64 ballots + LDS; no atomics): the work items of the normals' solve
         __shared__ uint32_t s_wc[4];
         const unsigned long long bw = __ballot(won);
         if (lane == 0) s_wc[wave] = (uint32_t)__popcll(bw);
@@ -668,7 +668,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     return off + incl - v;
 }
 
-#define M3D_TILE_CS 4096   // k_tile_build: slots of the candidate-position set (bucket positions around the own buckets, occupied or not)
+#define M3D_TILE_CS 4096   // tile_build_role: slots of the candidate-position set (bucket positions around the own buckets, occupied or not)
 #ifdef M3D_TB_STAMPS   // diagnosis build: wall-clock stamps (100 MHz) at the phase boundaries of the first 4096 working workgroups
 __device__ unsigned long long g_tb_stamp[4096][10];
 __device__ unsigned int g_tb_n = 0;
@@ -1354,7 +1354,7 @@ __device__ __forceinline__ void nrm_solve_role(const M3dBuild* __restrict__ buil
     }
 }
 
-// The tile images (k_tile_build's work) and the normals' solve (k_nrm_solve's) both follow k_post_finalize and touch nothing of each other's: ONE launch, the first
+// The tile images (tile_build_role) and the normals' solve (nrm_solve_role) both follow k_post_finalize and touch nothing of each other's: ONE launch, the first
 // n_tile_blocks workgroups build tiles, the rest solve voxels. Alone on the GPU either is a latency chain that leaves most of the chip idle (44 and 39 us for 16
 // clouds): side by side they take what the longer one takes. (Two streams do the same on paper; measured, profiles/r05_side_stream.txt, the fork / join cost
 // what the overlap saved and the headline lost 11 %.)

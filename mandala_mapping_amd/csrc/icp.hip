@@ -677,7 +677,7 @@ __device__ __forceinline__ void m3d_tile_query(const M3dGrid& g, float ux, float
     if (seeded) Q.bound = fminf(Q.bound, dseed * 1.0001f);   // the previous match lies within these 27 voxels: it bounds the search before the first probe
 }
 // one staged image: returns the SORTED position (in the level's pts array) of a NEW best candidate, or -1 when the best so far stands — a staged bucket is
-// one contiguous run in LDS and in the sorted order, delta[bucket] = sorted position - LDS position of its points (k_tile_build).
+// one contiguous run in LDS and in the sorted order, delta[bucket] = sorted position - LDS position of its points (bucket.hip: tile_build_role).
 // step > 1: `step` consecutive lanes (a power of two, at most 8) answer ONE query together — a query in a crowded stretch compares
 // against a thousand and more candidates while the scans are still centimetres apart (no box is provably farther than a
 // neighbour that far away): every lane scans its share of each voxel, the group agrees on the bound after the home voxel and on

@@ -66,7 +66,7 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 // ---- target tiles: the LDS-staged search (k_nn_tiles) ------------------------------------------------------------------
 // A TILE owns the buckets whose first sorted position lies in [t * M3D_TILE_PTS, (t + 1) * M3D_TILE_PTS): consecutive buckets of the
 // Morton order, i.e. one compact patch of the scanned surface. Its IMAGE, built once per target by the bucketing pipeline
-// (k_tile_build), is what a workgroup must hold in LDS to answer every query that has an occupied bucket of the tile among the
+// (bucket.hip: the tile workgroups of k_tiles_normals), is what a workgroup must hold in LDS to answer every query that has an occupied bucket of the tile among the
 // 2x2x2 buckets of its 27-voxel neighbourhood: the tile's own buckets plus every occupied bucket within one bucket of them.
 //   vlist[n_voxels]        the staged VOXELS, a compact list {voxel key, value}: value = first LDS position (11 bits) | population - 1 (11 bits) << 11 |
 //                          staged-bucket number << 22; voxel key = ix | iy << (cb0 + 1) | iz << (cb0 + cb1 + 2): a neighbour's key is the query voxel's

@@ -69,7 +69,7 @@ struct M3dBuild {                // one voxel grid of a bucketing batch (a3, a4,
     int32_t nrm_feed;            // 1 on the level (a cloud's finest) whose sorted order fills the normal grid's table
     float4* nrm_sorted;          // [n] out: the normals in this level's sorted order (k_nrm_handout; level builds of point-to-plane clouds, else null)
     M3dTileHdr* thdr;            // [m3d_tiles_of(n)] out: tile headers (levels of clouds that can be targets, else null)
-    uint8_t* timg;               // [tiles + pool][M3D_TILE_IMG_BYTES] out: tile images (k_tile_build), tiles = m3d_tiles_of(n), pool = m3d_tile_pool(tiles)
+    uint8_t* timg;               // [tiles + pool][M3D_TILE_IMG_BYTES] out: tile images (k_tiles_normals), tiles = m3d_tiles_of(n), pool = m3d_tile_pool(tiles)
     M3dTileImgMeta* timeta;      // [tiles + pool] out
     uint32_t* occ;               // [2^M3D_OCC_BITS / 32] out: occupancy bitmap of the bucket positions (levels of clouds that can be targets, else null); dyn[7] = 1 when valid
 };

@@ -80,7 +80,7 @@ struct m3dreg_cloud {
     float leaf[M3DREG_MAX_LEVELS]{};
     bool has_normals = false;
     bool source_only = false;      // m3dreg_cloud_desc.source_only: sorted, but no hash table / chunk boxes / normals — never a target
-    bool has_tiles = false;        // the levels' tile images were built (k_tile_build): the LDS-staged search can use this cloud as a target
+    bool has_tiles = false;        // the levels' tile images were built (k_tiles_normals): the LDS-staged search can use this cloud as a target
     float4* xyz = nullptr;         // coordinates in input order
     float mn[3]{}, mx[3]{};
     DevLevel lv[M3DREG_MAX_LEVELS];
@@ -323,7 +323,7 @@ size_t carve_cloud(m3dreg_cloud* c, void* base, const m3dreg_params& P) {
         L.order = k.take<uint32_t>((n + 255) / 256);
         // tiles only where they are used: a target's FINEST level. A pyramid's coarser levels hold too many points per bucket for an image (their tiles
         // ended up flagged, their searches in the global walk anyway) — not carving them saves 1.5 images of 56 KB per 512 points and a 1 MiB bitmap per
-        // level (a 2 M-point map: 330 MB per level) and two thirds of k_tile_build's work on a pyramid.
+        // level (a 2 M-point map: 330 MB per level) and two thirds of the tile build's work on a pyramid.
         if (!c->source_only && l == P.n_levels - 1) {
             const size_t nt = size_t(m3d_tiles_of(int(n))), ni = nt + size_t(m3d_tile_pool(int(nt)));
             L.thdr = k.take<M3dTileHdr>(nt);

@@ -654,7 +654,7 @@ def _crowded_cloud(seed, n_bg=5000):
 
 @pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
 def test_crowded_voxels_chunk_boxes_stay_exact(reg, orc, metric):
-    """Rows with more than M3D_LONG_ROW candidates are walked chunk by chunk, each chunk's exact box first (k_chunk_boxes): whatever
+    """Rows with more than M3D_LONG_ROW candidates are walked chunk by chunk, each chunk's exact box first (k_post_finalize): whatever
     the boxes let the search skip, every per-iteration pose still equals the oracle's exhaustive search bit for bit — raster-ordered
     points (nearly every chunk skipped), random-ordered points (hardly any), non-finite points in the cloud, seeded and certified
     later iterations."""
