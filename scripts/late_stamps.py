@@ -11,12 +11,13 @@ params = abi.Params.make(leaf=0.1, iterations=iters, max_corr_dist=0.5, metric=a
 reg = binding.Registrar(params, device=0)
 L = binding.lib()
 clouds, so = [], []
-for i in range(8):
+PAIRS = [int(x) for x in os.environ.get("M3D_PAIRS", "0,1,2,3,4,5,6,7").split(",")]
+for i in PAIRS:
     src, tgt, _ = synth.config4_pair(i, 3125)
     clouds += [src, tgt]; so += [True, False]
 for rep in range(2):
     cs = reg.clouds(clouds, source_only=so)
-    reg.align_batch([(cs[2 * i], cs[2 * i + 1], None) for i in range(8)])
+    reg.align_batch([(cs[2 * i], cs[2 * i + 1], None) for i in range(len(PAIRS))])
 buf = (C.c_ulonglong * (4096 * 8))()
 L.m3d_debug_read_late(buf)
 a = np.array(buf[:], dtype=np.uint64).reshape(4096, 8).astype(np.int64)
