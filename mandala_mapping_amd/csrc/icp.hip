@@ -1844,6 +1844,9 @@ __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ j
 }
 
 __host__ __device__ inline int m3d_ticket_group(int bpp);
+#ifndef M3D_TAIL_LOADS
+#define M3D_TAIL_LOADS 32
+#endif
 // The end of an iteration for one pair, reached by every thread of every block of the pair's reduction: the LAST block
 // to arrive adds up the pair's block partials, solves the 6x6 system and updates the pose (a8).
 __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, const M3dJob& J, M3dPairState* st, int n_pairs, int pair, int blk, int bpp,
@@ -1885,15 +1888,16 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
         const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
         long long v = 0;
         if (slot < M3D_NSUMS)
-            for (int b0 = seg; b0 < bpp; b0 += 64) {   // eight loads in flight per thread (a `v += load` loop waits for every one)
-                long long t[8];
+            for (int b0 = seg; b0 < bpp; b0 += 8 * M3D_TAIL_LOADS) {   // M3D_TAIL_LOADS loads in flight per thread (a `v += load` loop waits for every one). Round 5: 32, was 8 —
+                // a LONE pair is reduced by 256 workgroups (m3d_acc_blocks), its last workgroup made five dependent round trips here: 3 us of every launch of configs 2, 3 and 5
+                long long t[M3D_TAIL_LOADS];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < M3D_TAIL_LOADS; k++) {
                     const int b = b0 + 8 * k;
                     t[k] = (b < bpp) ? __hip_atomic_load(&partials[((size_t)pair * bpp + b) * M3D_PARTIAL_STRIDE + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ll;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) v += t[k];
+                for (int k = 0; k < M3D_TAIL_LOADS; k++) v += t[k];
             }
         s_part[seg][slot] = v;
         __syncthreads();
