@@ -18,6 +18,13 @@
 // 41 -> 77, k_tile_build 47 -> 74, k_rs_scatter 19.8 -> 23.9; bucketing 0.32 -> 0.49 ms per step, profiles/r04_xcd_rows.txt): eight XCDs walking
 // eight far-apart address streams lose more in DRAM locality than the L2s gain.
 struct M3dRB { int row, blk; };
+// The batched launches below have one ROW per LEVEL build (round 5): a point-to-plane cloud's first build, the normal grid, carries geometry and a voxel table but is
+// never keyed, sorted or tabled — as a row of these launches it was a third to a half of their workgroups, every one of which left at once (a dispatch slot each:
+// ~0.4 ns, 50 000 of them per launch with 64 pairs in one chain). `rows` packs the batch's shape: levels per cloud | builds per cloud << 16.
+__device__ __forceinline__ int m3d_row_build(int row, int rows) {
+    const int lv = rows & 0xFFFF, gpc = rows >> 16;
+    return (row / lv) * gpc + (gpc - lv) + (row % lv);
+}
 __device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr, int id = (int)blockIdx.x) {
     M3dRB r;
     r.row = id / bpr; r.blk = id - r.row * bpr;
@@ -163,7 +170,7 @@ __global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int g
 // ---- a3: voxel key per point ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     const int i = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= B.n) return;
     const float4 pi = B.xyz[i];
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const M3dBuild* __restrict__
 // coarse voxel the points then lie in the finest level's Morton order
 __global__ __launch_bounds__(256) void k_rekey(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     if (B.fine < 0) return;
     const int i = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= B.n) return;
@@ -227,7 +234,7 @@ __device__ __forceinline__ uint32_t nrm_slot_of(const uint32_t* __restrict__ nke
 #define RS_FUSED_TILES 128
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     if (pass >= B.sort_passes || rb.blk >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;   // phase 1: the grids that wait for their cloud's finest level
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
@@ -252,8 +259,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const M3dBuild* __restri
 // neighbouring lanes, took 223 us per pass for the 1.5 M-point map of config 5: 1.8 of the 2.8 ms its bucketing took.)
 #define RS_SCAN_CHUNKS 64
 __device__ __forceinline__ int rs_scan_chunk_len(int total) { return ((total + RS_SCAN_CHUNKS - 1) / RS_SCAN_CHUNKS + 255) & ~255; }
-__global__ __launch_bounds__(256) void k_rs_scan_sums(const M3dBuild* __restrict__ builds, int pass, int phase) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_rs_scan_sums(const M3dBuild* __restrict__ builds, int pass, int phase, int rows) {
+    const M3dBuild& B = builds[m3d_row_build((int)blockIdx.y, rows)];
     if (pass >= B.sort_passes || (B.fine >= 0) != (phase == 1)) return;
     const int total = 256 * B.ntiles, len = rs_scan_chunk_len(total);
     const int b0 = blockIdx.x * len, e0 = min(b0 + len, total);
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(256) void k_rs_scan_sums(const M3dBuild* __restrict
     __syncthreads();
     if (threadIdx.x == 0) B.hist[total + blockIdx.x] = w[0] + w[1] + w[2] + w[3];   // (the workspace holds 256 spare counters behind the tiles')
 }
-__global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restrict__ builds, int pass, int phase) {
-    const M3dBuild& B = builds[blockIdx.y];
+__global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restrict__ builds, int pass, int phase, int rows) {
+    const M3dBuild& B = builds[m3d_row_build((int)blockIdx.y, rows)];
     if (pass >= B.sort_passes || (B.fine >= 0) != (phase == 1)) return;
     const int total = 256 * B.ntiles, len = rs_scan_chunk_len(total);
     const int b0 = blockIdx.x * len, e0 = min(b0 + len, total);
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void k_rs_scan_apply(const M3dBuild* __restric
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __restrict__ builds, int pass, int fused, int phase, int rows, int bpr, int sliced) {
     const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
     const int tile = rb.blk;
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     if (tile >= bpr || pass >= B.sort_passes || tile >= B.ntiles || (B.fine >= 0) != (phase == 1)) return;
     const uint32_t *kin, *vin; uint32_t *kout, *vout;
     sort_buffers(B, pass, kin, vin, kout, vout);
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
 // address retire at ~5 per microsecond on this chip — 1500 of them were the whole cost of every variant that used them)
 __global__ __launch_bounds__(256) void k_count_cells(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     const int n = B.n;
     if (rb.blk * 256 >= n) return;
     const uint32_t* skey = sorted_keys(B);
@@ -456,8 +463,8 @@ __host__ __device__ inline void m3d_table_size(uint32_t n_buckets, uint32_t hcap
 
 // one workgroup per build: totals of the per-block counts (dyn[0] voxels, dyn[3] buckets), exclusive prefix of the voxel
 // heads in place (where each block of k_finalize_level appends its heads), table geometry
-__global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict__ builds, int n_builds) {
-    const M3dBuild& B = builds[blockIdx.x];
+__global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict__ builds, int rows) {
+    const M3dBuild& B = builds[m3d_row_build((int)blockIdx.x, rows)];
     const int nblk = (B.n + 255) / 256;
     __shared__ uint32_t sh[2][4];
     __shared__ uint32_t wv[M3D_ORDER_CAP];   // occupied voxels of every 256-point block (k_count_cells), for the block order below
@@ -532,10 +539,11 @@ __global__ __launch_bounds__(256) void k_table_params(const M3dBuild* __restrict
 
 __global__ __launch_bounds__(256) void k_clear_table(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
-    if (B.nkeys) {   // a normal grid: its voxel table (keys only: a slot's moments are zeroed by the thread that takes it)
-        uint4* t4 = reinterpret_cast<uint4*>(B.nkeys);   // [ncap] keys, then [ncap] "further runs of this voxel" counters
-        const uint32_t n4 = B.ncap >> 2;   // (a power of two >= 16)
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
+    if (B.nrm_feed) {   // the level that feeds its cloud's normal grid clears that grid's voxel table (keys only: a slot's moments are zeroed by the thread that takes it)
+        const M3dBuild& G = builds[B.nrm_build];
+        uint4* t4 = reinterpret_cast<uint4*>(G.nkeys);   // [ncap] keys, then [ncap] "further runs of this voxel" counters
+        const uint32_t n4 = G.ncap >> 2;   // (a power of two >= 16)
         for (uint32_t i = (uint32_t)rb.blk * blockDim.x + threadIdx.x; i < 2u * n4; i += (uint32_t)bpr * blockDim.x) {
             const uint32_t f = i < n4 ? M3D_INVALID_KEY : 0u;
             t4[i] = make_uint4(f, f, f, f);
@@ -567,7 +575,7 @@ __device__ __forceinline__ uint32_t bucket_key_of_point(const M3dGrid& g, const 
 
 __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restrict__ builds, int rows, int bpr, int sliced) {
     const M3dRB rb = m3d_row_block_sliced(bpr, sliced);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     const int n = B.n;
     if (rb.blk >= bpr || rb.blk * (int)blockDim.x >= n) return;   // block-uniform
@@ -1112,7 +1120,7 @@ __device__ __forceinline__ void nrm_moments_part(const M3dBuild& G, const M3dBui
 __global__ __launch_bounds__(256) void k_post_finalize(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     static_assert(NRM_PPT == 4 && M3D_CHUNK == 16, "a chunk = four threads' positions");
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     const int n = B.n;
     if (rb.blk * 256 * NRM_PPT >= n) return;   // (block-uniform; n = 0: a build the pipeline skips)
     const int nv = B.grid.n_valid;
@@ -1368,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_tiles_normals(const M3dBuild* __restric
 // point; neighbours share their voxel's slot). Non-finite points (sorted last) get {0,0,0,0}.
 __global__ __launch_bounds__(256) void k_nrm_handout(const M3dBuild* __restrict__ builds, int rows, int bpr) {
     const M3dRB rb = m3d_row_block(rows, bpr);
-    const M3dBuild& B = builds[rb.row];
+    const M3dBuild& B = builds[m3d_row_build(rb.row, rows)];
     if (!B.nrm_sorted || B.nrm_build < 0) return;
     const int j = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (j >= B.n) return;
@@ -1408,44 +1416,45 @@ hipError_t m3d_launch_decode_aabb(hipStream_t s, const M3dDecode* d_descs, int n
 // the whole bucketing pipeline of n_builds grids (dyn counters must be zeroed by the caller)
 hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clouds, int grids_per_cloud, int max_n, bool any_normals,
                                    int any_tiles, float plane_ratio, int min_pts, float min_spread, bool pyramid) {
-    const int n_builds = n_clouds * grids_per_cloud;
+    const int lv = grids_per_cloud - (any_normals ? 1 : 0);   // level builds per cloud: the rows of the batched launches (m3d_row_build)
+    const int n_rows = n_clouds * lv, rows = lv | (grids_per_cloud << 16);
     const int max_passes = 4;   // a build whose keys need fewer skips the later ones on the device
     hipLaunchKernelGGL(k_grid_params, dim3((n_clouds + 63) / 64), dim3(64), 0, s, d_builds, n_clouds, grids_per_cloud);
     M3D_DBG(s, "k_grid_params");
     const int blocks = (max_n + 255) / 256;
     const int ntiles = m3d_sort_tiles(max_n);
     const int cb = blocks > 256 ? 256 : blocks;
-    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks * n_rows), dim3(256), 0, s, d_builds, rows, blocks);
     M3D_DBG(s, "k_voxel_keys");
     for (int phase = 0; phase < (pyramid ? 2 : 1); phase++) {
         if (phase == 1) {   // the coarser levels of pyramids: keyed in their cloud's finest-level order, then sorted (stable) by their own keys
-            hipLaunchKernelGGL(k_rekey, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+            hipLaunchKernelGGL(k_rekey, dim3(blocks * n_rows), dim3(256), 0, s, d_builds, rows, blocks);
             M3D_DBG(s, "k_rekey");
         }
         for (int pass = 0; pass < max_passes; pass++) {
             const int fused = ntiles <= RS_FUSED_TILES ? 1 : 0;   // (ntiles = the batch's largest cloud)
-            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles);
+            hipLaunchKernelGGL(k_rs_hist, dim3(ntiles * n_rows), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, rows, ntiles);
             M3D_DBG(s, "k_rs_hist");
             if (!fused) {
-                hipLaunchKernelGGL(k_rs_scan_sums, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
-                hipLaunchKernelGGL(k_rs_scan_apply, dim3(RS_SCAN_CHUNKS, n_builds), dim3(256), 0, s, d_builds, pass, phase);
+                hipLaunchKernelGGL(k_rs_scan_sums, dim3(RS_SCAN_CHUNKS, n_rows), dim3(256), 0, s, d_builds, pass, phase, rows);
+                hipLaunchKernelGGL(k_rs_scan_apply, dim3(RS_SCAN_CHUNKS, n_rows), dim3(256), 0, s, d_builds, pass, phase, rows);
                 M3D_DBG(s, "k_rs_scan");
             }
-            hipLaunchKernelGGL(k_rs_scatter, dim3(m3d_sliced_grid(ntiles) * n_builds), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, n_builds, ntiles, (m3d_sliced_on() >> 1) & 1);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(m3d_sliced_grid(ntiles) * n_rows), dim3(RS_THREADS), 0, s, d_builds, pass, fused, phase, rows, ntiles, (m3d_sliced_on() >> 1) & 1);
             M3D_DBG(s, "k_rs_scatter");
         }
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_count_cells, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+    hipLaunchKernelGGL(k_count_cells, dim3(blocks * n_rows), dim3(256), 0, s, d_builds, rows, blocks);
     M3D_DBG(s, "k_count_cells");
-    hipLaunchKernelGGL(k_table_params, dim3(n_builds), dim3(256), 0, s, d_builds, n_builds);
+    hipLaunchKernelGGL(k_table_params, dim3(n_rows), dim3(256), 0, s, d_builds, rows);
     M3D_DBG(s, "k_table_params");
-    hipLaunchKernelGGL(k_clear_table, dim3(cb * n_builds), dim3(256), 0, s, d_builds, n_builds, cb);
+    hipLaunchKernelGGL(k_clear_table, dim3(cb * n_rows), dim3(256), 0, s, d_builds, rows, cb);
     M3D_DBG(s, "k_clear_table");
-    hipLaunchKernelGGL(k_finalize_level, dim3(m3d_sliced_grid(blocks) * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks, m3d_sliced_on() & 1);
+    hipLaunchKernelGGL(k_finalize_level, dim3(m3d_sliced_grid(blocks) * n_rows), dim3(256), 0, s, d_builds, rows, blocks, m3d_sliced_on() & 1);
     M3D_DBG(s, "k_finalize_level");
     const int nb_p = (blocks + NRM_PPT - 1) / NRM_PPT;
-    hipLaunchKernelGGL(k_post_finalize, dim3(nb_p * n_builds), dim3(256), 0, s, d_builds, n_builds, nb_p);   // table populations, chunk boxes, normal-grid moments: one pass over the sorted points
+    hipLaunchKernelGGL(k_post_finalize, dim3(nb_p * n_rows), dim3(256), 0, s, d_builds, rows, nb_p);   // table populations, chunk boxes, normal-grid moments: one pass over the sorted points
     M3D_DBG(s, "k_post_finalize");
     {
         const int tile_bpr = m3d_tiles_of(max_n), n_tile_blocks = any_tiles ? m3d_sliced_grid(tile_bpr) * n_clouds : 0;
@@ -1457,7 +1466,7 @@ hipError_t m3d_launch_bucket_batch(hipStream_t s, M3dBuild* d_builds, int n_clou
         }
     }
     if (any_normals) {
-        hipLaunchKernelGGL(k_nrm_handout, dim3(blocks * n_builds), dim3(256), 0, s, d_builds, n_builds, blocks);
+        hipLaunchKernelGGL(k_nrm_handout, dim3(blocks * n_rows), dim3(256), 0, s, d_builds, rows, blocks);
         M3D_DBG(s, "k_nrm_handout");
     }
     return hipGetLastError();
