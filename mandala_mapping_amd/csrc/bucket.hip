@@ -841,6 +841,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     uint32_t kk[SPT], cnt[SPT], nvx[SPT], gst[SPT]; uint4 hi[SPT];
     bool occ[SPT];
     bool anybig = false, crowd = false;
+    uint32_t vmax = 0u;   // largest voxel population among this thread's staged buckets
     uint32_t my_p = 0u, my_v = 0u;
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -857,7 +858,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
             uint32_t c0 = 0u;
             for (int sub = 0; sub < 8; sub++) {
                 const uint32_t c1 = (uint32_t)(((sub < 4) ? cumA : cumB) >> (16 * (sub & 3))) & 0xFFFFu;
-                nvx[q] += c1 > c0 ? 1u : 0u; crowd = crowd || (c1 - c0 > (uint32_t)M3D_LONG_ROW); c0 = c1;
+                nvx[q] += c1 > c0 ? 1u : 0u; crowd = crowd || (c1 - c0 > (uint32_t)M3D_LONG_ROW); vmax = max(vmax, c1 - c0); c0 = c1;
             }
         }
         my_p += cnt[q]; my_v += nvx[q];
@@ -907,9 +908,13 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
         __syncthreads();
         if (s_cnt == 0xFFFFFFFFu) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
     } else if (tid == 0) { s_ip[0] = tot_p | (tot_v << 16); s_cnt = 0u; }
-    if (crowd) s_over = 1u;   // (re-used: some voxel of the tile is crowded: every image of the tile then gets chunk boxes)
+    if (crowd) atomicMax(&s_over, vmax);   // (re-used: some voxel of the tile is crowded — the tile's largest voxel population, > M3D_LONG_ROW)
     __syncthreads();
     const bool crowded = s_over != 0u;
+    // How crowded (round 5; rounds 2-4: one flag = eight lanes per record): the lanes that share a record of k_nn_tiles split each voxel's points, so their number follows the
+    // largest voxel — 2 lanes up to 64 points, 4 up to 160, 8 beyond — and with it the records per work item (512 / lanes): an item stages the whole image whatever
+    // it holds, and a tile with one 40-point voxel used to be cut into eight items of 64 records.
+    const uint32_t crowd_level = !crowded ? 0u : (s_over > 160u ? 3u : (s_over > 64u ? 2u : 1u));
     const uint32_t extra = s_cnt;
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     // 6. the images: per image the list of its voxels {key, LDS position | population - 1 | staged bucket} and the copies of its points; per tile
@@ -970,7 +975,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
         __syncthreads();
     }
     TB_STAMP(8);
-    if (tid == 0) *H = M3dTileHdr{ extra, n_img, n_e << 16, (s_ip[0] & 0xFFFFu) | (crowded ? 0x80000000u : 0u) };
+    if (tid == 0) *H = M3dTileHdr{ extra, n_img, n_e << 16, (s_ip[0] & 0xFFFFu) | (crowd_level << 30) };
 #ifdef M3D_TB_STAMPS
     if (tid == 0 && tb_slot < 4096u) g_tb_stamp[tb_slot][9] = ((unsigned long long)n_img << 32) | n_e;
 #endif

@@ -383,7 +383,7 @@ __device__ __forceinline__ float m3d_axis_gap(int ic, int v0, int v1, float gl, 
 #define M3D_LATE_QPT 7      // queries per thread at most in k_icp_late / k_accumulate_matches<.., true> (launch_iteration checks; m3d_acc_blocks sizes the grid for it)
 #define M3D_LATE_CAP (M3D_LATE_QPT * 256)   // their worklist: every query a workgroup owns, if it must (k_icp_late: 7 x 256 x 20 B + the reductions' arrays = 39 KB of LDS)
 #define M3D_TILE_CHUNK 512            // records per work item of k_nn_tiles (one per thread) when the batch has enough of them to fill the GPU; else 256 (M3dNnArgs::tile_chunk: 2 lanes per record; M3DREG_TILE_CHUNK forces 512 / 256 / 128)
-#define M3D_TILE_CHUNK_CROWDED 64     // ... of a tile with crowded voxels (one per eighth lane)
+#define M3D_TILE_CHUNK_CROWDED 64     // ... at least, of a tile with crowded voxels (m3d_tile_records_per_item: 256 / 128 / 64 by the tile's largest voxel)
 #define M3D_NN_HEAVY (-2147483647 - 1)   // internal: the light path hands this query to the compacted full search
 __device__ __forceinline__ long long m3d_voxel_code(const M3dQuery& Q) {
     return (long long)(Q.ic[0] + 1) | ((long long)(Q.ic[1] + 1) << 16) | ((long long)(Q.ic[2] + 1) << 32);
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                 // all — k_nn_tiles testing every (tile, chunk) against the counters itself — made k_nn_iter as fast and k_nn_tiles
                 // 12-25 us slower: whatever clumps the items of a crowded tile, or hands a workgroup 3 items and its neighbour none,
                 // shows up as the tail of that kernel.)
-                const uint32_t cs = (hmeta0 >> 31) ? (uint32_t)M3D_TILE_CHUNK_CROWDED : (uint32_t)A.tile_chunk;
+                const uint32_t cs = m3d_tile_records_per_item(hmeta0, (uint32_t)A.tile_chunk);
                 const uint32_t end = min(base + cnt, (uint32_t)M3D_TILE_QCAP);
                 for (uint32_t c = (base + cs - 1u) / cs; c * cs < end; c++) {
                     const uint32_t wl = ((uint32_t)t0 + c + (uint32_t)pair) & (uint32_t)(M3D_TILE_LISTS - 1);   // (per item, not per workgroup: a crowded tile's chunks spread over all lists)
@@ -1578,8 +1578,8 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         H.extra = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.extra); H.n_img = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.n_img);
         H.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.flags); H.meta0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.meta0);
         const unsigned int qn = (unsigned int)__builtin_amdgcn_readfirstlane((int)min((A.tcnt + (size_t)pair * A.cnt_stride)[blk], (unsigned int)M3D_TILE_QCAP));
-        const bool sparse = (H.meta0 >> 31) != 0u;   // a tile with crowded voxels: 64 records per item, eight lanes per record (m3d_tile_search)
-        const unsigned int cs = (unsigned int)__builtin_amdgcn_readfirstlane((int)(sparse ? (unsigned int)M3D_TILE_CHUNK_CROWDED : (unsigned int)A.tile_chunk));
+        // (a tile with crowded voxels: 256 / 128 / 64 records per item, two / four / eight lanes per record: m3d_tile_search's group mode)
+        const unsigned int cs = (unsigned int)__builtin_amdgcn_readfirstlane((int)m3d_tile_records_per_item(H.meta0, (uint32_t)A.tile_chunk));
         const unsigned int lstride = M3D_TILE_THREADS / cs;
         M3D_GLOBAL m3d_i32x2* out = (M3D_GLOBAL m3d_i32x2*)(void M3D_GLOBAL*)(A.match + (size_t)pair * A.match_stride);
         M3D_GLOBAL long long* cache = (M3D_GLOBAL long long*)(void M3D_GLOBAL*)(A.cache + (size_t)pair * A.match_stride);

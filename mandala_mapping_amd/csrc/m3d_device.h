@@ -87,7 +87,15 @@ struct M3dBucket {         // 32 bytes, 32-byte aligned
 #define M3D_OCC_BITS 23         // the occupancy bitmap covers grids of up to 2^23 bucket positions (1 MiB per level)
 #define M3D_TILE_MAXIMG 32
 #define M3D_TILE_LISTS 8      // work-item lists of k_nn_tiles (one counter per list, each on its own 128-B line; list l is served by the workgroups with blockIdx & 7 == l)
-struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; flags = M3D_TILE_OVERSIZE | staged buckets << 16; meta0 = staged points of image t | crowded << 31
+struct M3dTileHdr { uint32_t extra, n_img, flags, meta0; };   // images of the tile: image t, then images extra .. extra + n_img - 2; flags = M3D_TILE_OVERSIZE | staged buckets << 16; meta0 = staged points of image t | crowd level << 30
+// crowd level of a tile (0: no voxel of more than M3D_LONG_ROW points; 1 / 2 / 3: largest voxel <= 64 / <= 160 / larger): 2^level lanes share a record of k_nn_tiles, 512 >> level records make a work item
+// (a SMALL batch — fewer than 768 plain items, launch_iteration: one or two pairs alone on the GPU — keeps rounds 2-4's rule, 64 records and eight lanes for every crowded tile: there the
+//  items are what fills the chip, and a lone crowded pair's k_nn_tiles took 255 instead of 181 us per registration with the graded rule)
+__host__ __device__ inline uint32_t m3d_tile_records_per_item(uint32_t meta0, uint32_t plain_chunk) {
+    const uint32_t lvl = meta0 >> 30;
+    if (lvl == 0u) return plain_chunk;
+    return plain_chunk < 512u ? 64u : (512u >> lvl);
+}
 struct M3dTileImgMeta { uint32_t n_points, n_voxels; };   // n_voxels bit 31: the image holds a voxel of more than M3D_LONG_ROW points
 static_assert(sizeof(M3dTileHdr) == 16 && sizeof(M3dTileImgMeta) == 8, "tile image layout");
 __host__ __device__ inline int m3d_tile_pool(int n_tiles) { return n_tiles / 2 + 8; }   // extra images per level
