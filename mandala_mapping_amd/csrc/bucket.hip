@@ -914,7 +914,11 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     // How crowded (round 5; rounds 2-4: one flag = eight lanes per record): the lanes that share a record of k_nn_tiles split each voxel's points, so their number follows the
     // largest voxel — 2 lanes up to 64 points, 4 up to 160, 8 beyond — and with it the records per work item (512 / lanes): an item stages the whole image whatever
     // it holds, and a tile with one 40-point voxel used to be cut into eight items of 64 records.
-    const uint32_t crowd_level = !crowded ? 0u : (s_over > 160u ? 3u : (s_over > 64u ? 2u : 1u));
+#ifndef M3D_CROWD_T1
+#define M3D_CROWD_T1 64u
+#define M3D_CROWD_T2 160u
+#endif
+    const uint32_t crowd_level = !crowded ? 0u : (s_over > M3D_CROWD_T2 ? 3u : (s_over > M3D_CROWD_T1 ? 2u : 1u));
     const uint32_t extra = s_cnt;
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     // 6. the images: per image the list of its voxels {key, LDS position | population - 1 | staged bucket} and the copies of its points; per tile
