@@ -316,7 +316,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
     __shared__ uint32_t cnt[RS_ROUNDS * RS_WAVES][256];   // 32 KiB: per (round, wave) digit counts
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t goff;   // where this tile's keys of digit t go: after all keys of smaller digits and this digit's keys of the tiles before
-    __shared__ uint32_t wsum[RS_WAVES];
+    // (the four wave sums of the scan below ride in cnt itself — wave w's in cnt[w][64 w + 63], a word only wave w's lanes write afterwards: with 16 bytes of
+    //  their own the kernel's LDS was 32 784 B, four workgroups per CU instead of five)
     uint32_t total = 0, inc = 0;
     if (fused) {
         // the scan a separate single-workgroup launch did (10 us per pass, launch gap included), redone by every workgroup for its own
@@ -335,12 +336,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
         inc = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-        if (lane == 63) wsum[wave] = inc;
+        for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
+        if (lane == 63) cnt[wave][t] = inc;   // (behind this thread's own zeroing of that word)
         goff = before;
-    } else goff = scanned[t * ntiles + tile];
-    for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
+    } else {
+        goff = scanned[t * ntiles + tile];
+        for (int s = 0; s < RS_ROUNDS * RS_WAVES; s++) cnt[s][t] = 0;
+    }
     __syncthreads();
-    if (fused) { for (int w = 0; w < wave; w++) goff += wsum[w]; goff += inc - total; }
+    if (fused) {   // (uniform)
+        for (int w = 0; w < wave; w++) goff += cnt[w][64 * w + 63];
+        goff += inc - total;
+        __syncthreads();   // every wave has read the sums
+        if (lane == 63) cnt[wave][t] = 0;   // (LDS operations of one wave complete in order: the counts this wave writes below come behind it)
+    }
     const int base = tile * RS_TILE;
     uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rank[RS_ROUNDS];
     const unsigned long long lt = (1ull << lane) - 1ull;

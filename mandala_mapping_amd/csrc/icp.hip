@@ -1146,15 +1146,18 @@ __device__ __forceinline__ int m3d_coop_query(const M3dGrid& g, m3d_gu4 tab, m3d
     return m;
 }
 
-#ifdef M3D_NN_WAVES   // A/B builds: force the occupancy of the search kernel (make CXXFLAGS+=-DM3D_NN_WAVES=6)
-#define M3D_NN_OCC __attribute__((amdgpu_waves_per_eu(M3D_NN_WAVES, M3D_NN_WAVES)))
-#else
-#define M3D_NN_OCC
+// Occupancy of k_nn_iter<true>: its 41 VGPRs allow 8 waves per SIMD, but left to itself the compiler takes 105 SGPRs (800 per SIMD, granules of 16: 7 waves).
+// Asked for 8 it makes do with 77 (more of them parked in VGPR lanes): the kernel is a chain of dependent round trips (record, previous match, occupancy
+// words, table entry, two returning atomics) whose speed is the number of waves in flight — 21.9 -> 19.8 us alone, 139.9 -> 121.2 us per 64-pair launch,
+// headline +0.8 %, serial steps +1.3 % (round 5, same box). k_nn_iter<false> (128 VGPRs: the walks) is left alone.
+#ifndef M3D_NN_WAVES
+#define M3D_NN_WAVES 8   // (A/B builds: make CXXFLAGS+=-DM3D_NN_WAVES=7)
 #endif
+#define M3D_NN_OCC __attribute__((amdgpu_waves_per_eu(LEAN ? M3D_NN_WAVES : 1, 8)))
 // LEAN (k_nn_iter<true>, the tile iterations of a level whose target has tiles): classify + bin ONLY — every query that must search goes
 // to its tile's slab however few they are, and the rare one that cannot (a tile that could not be staged, a full slab, more than 64
 // tiles in one workgroup) is left M3D_NN_PENDING for the reduction pass's workgroup that streams it. Without the two walks compiled in the kernel
-// needs 41 VGPRs instead of 124: 7 waves per SIMD instead of 4 — worth 4-6 % of the headline, where three chains compete for the
+// needs 41 VGPRs instead of 124: 7 (round 5: 8) waves per SIMD instead of 4 — worth 4-6 % of the headline, where three chains compete for the
 // register file (alone it is only 2-5 us faster per launch).
 template <bool LEAN>
 __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __restrict__ jobs, int n_pairs, int bpp, int first_of_level, M3dNnArgs A) {
