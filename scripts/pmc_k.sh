@@ -5,7 +5,7 @@ B=$1; shift
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
-  i=$((i+1)); rm -rf $R/gpurun_out/pk_$i
+  i=$((i+1)); rm -rf $R/gpurun_out/pk_$i; echo "pass $i: $set"   # (a line per pass: a silent GPU command is taken to be hung after 7 minutes)
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pk_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --inflight 1 --queue-depth 1 --no-events --min-seconds 0 --pairs-per-gpu $B > /dev/null 2>&1
 done
 python3 - <<PY
