@@ -2278,6 +2278,9 @@ int m3d_acc_blocks(int max_n_src, int n_pairs) {
     int t = (512 + n_pairs - 1) / n_pairs;
     if (t > hi) t = hi;
     if (t > b) b = t;
+    // the pair's last workgroup loads the partials 8 x M3D_TAIL_LOADS = 256 per round trip (m3d_pair_tail): a lone 100 k-point pair got 260 workgroups, and its tail a
+    // second round trip for the last four (round 5) — a few workgroups over a multiple of 256 are not worth one
+    if (b > 256 && b <= 320 && (long long)256 * 256 * M3D_LATE_QPT >= (long long)max_n_src) b = 256;
     return b;
 }
 int m3d_ticket_words(int n_pairs, int max_n_src) {
