@@ -1847,6 +1847,13 @@ __device__ __forceinline__ void m3d_report_progress(const M3dJob* __restrict__ j
 }
 
 __host__ __device__ inline int m3d_ticket_group(int bpp);
+#ifdef M3D_LATE_STAMPS   // (diagnosis build) the tail of pair 0's LAST workgroup, phase by phase: entry, stores drained, tickets taken, partials added, solved, reported
+__device__ unsigned long long g_tail_stamp[8];
+extern "C" hipError_t m3d_debug_read_tail(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamp), sizeof(unsigned long long) * 8); }
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && pair == 0) g_tail_stamp[k] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(k) ((void)0)
+#endif
 #ifndef M3D_TAIL_LOADS
 #define M3D_TAIL_LOADS 32
 #endif
@@ -1868,8 +1875,14 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     // the pair's counter: at most ~7 + 7 serialised arrivals instead of 49.
     __shared__ int s_last;
     __shared__ long long s_part[8][M3D_PARTIAL_STRIDE];
+#ifdef M3D_LATE_STAMPS
+    const unsigned long long ts0 = wall_clock64();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef M3D_LATE_STAMPS
+    const unsigned long long ts1 = wall_clock64();
+#endif
     if (threadIdx.x == 0) {
         const int gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs, grp = blk / gs;
         unsigned int* tk = tickets + (size_t)pair * (size_t)(ng + 1) * 32u;
@@ -1886,6 +1899,10 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     }
     __syncthreads();
     if (!s_last) return;
+#ifdef M3D_LATE_STAMPS
+    if (threadIdx.x == 0 && pair == 0) { g_tail_stamp[0] = ts0; g_tail_stamp[1] = ts1; }
+#endif
+    TAIL_STAMP(2);
     if (zero_word && threadIdx.x == 0) *zero_word = 0u;   // (every workgroup of the pair has read it: they all arrived)
     {
         const int slot = threadIdx.x & 31, seg = threadIdx.x >> 5;
@@ -1913,8 +1930,11 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
+    TAIL_STAMP(3);
     m3d_solve_pair(J, first_of_level, s_part[0], T_pre);
+    TAIL_STAMP(4);
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
+    TAIL_STAMP(5);
 }
 
 // WALK (the tile iterations of a lean registration): a query k_nn_iter<lean> left M3D_NN_PENDING is walked HERE, by the workgroup that streams it

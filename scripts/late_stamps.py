@@ -32,3 +32,9 @@ for i, nm in enumerate(["pose+setup", "stream", "walk", "reduce", "tail"]):
 nw = a[:, 6]
 print("  worklist entries per workgroup: mean %.1f p50 %d p90 %d max %d; end of stream p50 %.1f max %.1f, end of walk p50 %.1f max %.1f, end of reduce max %.1f (us after the first start)" % (
     nw.mean(), np.median(nw), np.percentile(nw, 90), nw.max(), np.median(t[:, 2]) - base, t[:, 2].max() - base, np.median(t[:, 3]) - base, t[:, 3].max() - base, t[:, 4].max() - base))
+
+if hasattr(L, "m3d_debug_read_tail"):   # pair 0's last workgroup, phase by phase
+    tb = (C.c_ulonglong * 8)()
+    L.m3d_debug_read_tail(tb)
+    tt = np.array(tb[:6], dtype=np.int64) / 100.0
+    print("  tail of pair 0's last workgroup: stores drained + barrier %.2f, tickets %.2f, partial loads + LDS sums %.2f, solve %.2f, progress report %.2f us" % tuple(np.diff(tt)))
