@@ -203,6 +203,31 @@ def test_internal_chains_of_the_synchronous_call_give_the_same_bits(reg, orc):
                     c.free()
 
 
+@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
+def test_internal_chains_on_a_pyramid(reg, orc, metric):
+    """The same cut on a two-level registration (every chain runs its own level loop and polls its own progress word), both metrics, convergence-terminated:
+    pairs of a batch finish their levels after different numbers of iterations, chains of a batch therefore enqueue different numbers of launches."""
+    p = _params(leaf=(0.5, 0.25), iterations=(6, 10), max_corr_dist=(1.5, 0.6), metric=metric, normal_leaf=0.5, eps_rot=1e-5, eps_trans=1e-5)
+    R = reg.Registrar(p)
+    raw, ref = [], []
+    for k in range(6):
+        tgt = synth.planes_cloud(3500 + 500 * k, 250 + k)
+        Tg = synth.random_T(np.random.default_rng(300 + k), 1.5 + 0.3 * k, 0.08)
+        src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(3000 + 350 * k, 280 + k)).astype(np.float32)
+        raw.append((src, tgt))
+        ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+    for n, chains in ((6, 2), (6, 3), (5, 4), (4, 2)):
+        R.set_batch_chains(chains)
+        cl = R.clouds([a for s_, t_ in raw[:n] for a in (s_, t_)], wait=False)
+        Tb, stb = R.align_batch([(cl[2 * i], cl[2 * i + 1], None) for i in range(n)])
+        for k in range(n):
+            assert np.array_equal(Tb[k], ref[k][0]), (metric, n, chains, k)
+            _same_stats(stb[k], ref[k][1])
+        for c in cl:
+            c.free()
+    R.set_batch_chains(0)
+
+
 def test_status_codes(reg, orc):
     p = _params(leaf=0.5, iterations=5, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
     R = reg.Registrar(p)
