@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 6   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+#define M3DREG_ABI_VERSION 7   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
                                      M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
                                   3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
                                      exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
@@ -56,7 +56,8 @@ extern "C" {
                                   5: + m3dreg_pair_desc.target_group (shared targets are co-located and bucketed once), m3dagg_set_scan_trig,
                                      m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight
                                   6: + m3dreg_set_batch_chains (opt-in: the SYNCHRONOUS m3dreg_align_batch may cut a batch of >= 4 pairs into internal
-                                     launch chains, same results); m3dreg_pair_desc.reserved must be 0 */
+                                     launch chains, same results); m3dreg_pair_desc.reserved must be 0
+                                  7: + m3dreg_set_latency_mode (a serial caller states that its batches have the GPU to themselves) */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -223,6 +224,13 @@ int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dr
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T,
                        m3dreg_stats* stats);
 int m3dreg_set_batch_chains(m3dreg_handle* h, int chains);
+/* (ABI 7) A caller that makes ONE call at a time on this GPU — the ROS node: one spin thread, one registration or one batch per sweep
+ * (m3d_aggregator.cpp:185) — says so: on != 0 sizes this handle's launch grids for a GPU it has to itself (the reduction pass takes all
+ * three workgroups a CU holds instead of leaving one to other batches): +3.6 % for synchronous 8-pair steps, measured; -3.4 % when other
+ * handles' batches DO share the GPU (bench.py's headline keeps four in flight: leave it off there). Same results either way (the sums are
+ * integers). The library never guesses this from what the process has in flight. Refused (M3DREG_ERR_INVALID_ARG) between
+ * m3dreg_align_batch_async and its wait. Default off. */
+int m3dreg_set_latency_mode(m3dreg_handle* h, int on);
 /* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. A handle holds the state of ONE batch: a second
  * m3dreg_align_batch_async before the wait is refused (M3DREG_ERR_INVALID_ARG) — to queue batches behind each other, give
  * several handles the same stream (m3dreg_create's `stream`), as bench.py does. */

@@ -5,7 +5,7 @@ HIP library and to the CPU oracle in the parity tests.
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LEVELS = 4
 NSUMS = 29
 

@@ -2288,14 +2288,17 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 // no other batch of the process was in flight — a process-global counter for 1 % of a serial step, profiles/r04_zoo_ab.txt: gone.)
 // Bounds: at most 7 queries per thread (M3D_LATE_QPT: k_icp_late's worklist; the amortisation of the 29-term block reduction has little left to give
 // beyond), at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
-int m3d_acc_blocks(int max_n_src, int n_pairs) {
+int m3d_acc_blocks(int max_n_src, int n_pairs, int alone) {
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
     int b = (max_n_src + 256 * M3D_LATE_QPT - 1) / (256 * M3D_LATE_QPT);
     if (b < 1) b = 1;
     if (b < b_min) b = b_min;
     if (n_pairs <= 0) return b;
     int hi = max_n_src / 384; if (hi < b) hi = b;
-    int t = (512 + n_pairs - 1) / n_pairs;
+    // 512 workgroups per batch: two per CU, a third stays free for whatever else shares the GPU (the headline keeps four chains in flight: with 768 it loses 3.4 %).
+    // alone (m3dreg_set_latency_mode: the caller states that this handle's batches have the GPU to themselves): 768, all three a CU holds — serial steps +3.6 %
+    // (round 5, profiles/r05_latency_mode.txt). A function of the batch and of that statement, never of what the process happens to have in flight.
+    int t = ((alone ? 768 : 512) + n_pairs - 1) / n_pairs;
     if (t > hi) t = hi;
     if (t > b) b = t;
     // the pair's last workgroup loads the partials 8 x M3D_TAIL_LOADS = 256 per round trip (m3d_pair_tail): a lone 100 k-point pair got 260 workgroups, and its tail a
@@ -2303,8 +2306,8 @@ int m3d_acc_blocks(int max_n_src, int n_pairs) {
     if (b > 256 && b <= 320 && (long long)256 * 256 * M3D_LATE_QPT >= (long long)max_n_src) b = 256;
     return b;
 }
-int m3d_ticket_words(int n_pairs, int max_n_src) {
-    const int bpp = m3d_acc_blocks(max_n_src, n_pairs), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
+int m3d_ticket_words(int n_pairs, int max_n_src, int alone) {
+    const int bpp = m3d_acc_blocks(max_n_src, n_pairs, alone), gs = m3d_ticket_group(bpp), ng = (bpp + gs - 1) / gs;
     return n_pairs * (ng + 1) * 32;
 }
 
@@ -2345,7 +2348,7 @@ static void launch_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, i
     const int late = first_of_level < 0;
     const bool fused_ok = first_of_level == -2;   // -2: a late iteration that may run as one launch
     if (late) first_of_level = 0;
-    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs);
+    const int bpp_a = m3d_acc_blocks(max_n_src, n_pairs, w.alone);
     // A late iteration nobody brackets runs as ONE launch (k_icp_late). With an event bracket around the correspondence step (bench.py
     // samples some iterations; its untimed roofline step brackets all of them) the same iteration runs as the two-launch chain — same
     // bits — because the bracket's two halves do not exist inside a fused launch.

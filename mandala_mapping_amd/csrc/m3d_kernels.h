@@ -159,6 +159,7 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
     uint2* witems;               // [wcap] work items of k_nn_tiles
     unsigned int* wcount;        // items published this iteration; zero between iterations
     int wcap;
+    int alone;                   // m3dreg_set_latency_mode: the batch has the GPU to itself (m3d_acc_blocks)
 };
 // k0/k1 (optional): events recorded immediately before / after the dominant kernel of the iteration (k_nn_iter)
 // seq / progress: the solve step stores {seq, pairs still active at this level} to *progress (device view of
@@ -166,8 +167,8 @@ struct M3dNnWork {               // workspace of the batch, all per pair with th
 hipError_t m3d_launch_icp_iteration(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, int first_of_level,
                                     const M3dNnWork& w, unsigned int seq, unsigned long long* progress, hipEvent_t k0, hipEvent_t k1);
 hipError_t m3d_launch_patch_jobs(hipStream_t s, M3dJob* d_jobs, int n_pairs, int cap_pairs, int n_levels);
-int m3d_ticket_words(int n_pairs, int max_n_src);
-int m3d_acc_blocks(int max_n_src, int n_pairs);   // workgroups per pair of the reduction pass
+int m3d_ticket_words(int n_pairs, int max_n_src, int alone);
+int m3d_acc_blocks(int max_n_src, int n_pairs, int alone);   // workgroups per pair of the reduction pass (alone: m3dreg_set_latency_mode)
 hipError_t m3d_launch_accumulate_only(hipStream_t s, const M3dJob* d_jobs, int n_pairs, int max_n_src, int metric, const M3dNnWork& w);
 hipError_t m3d_launch_debug_candidates(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, int32_t* out_cnt);
 hipError_t m3d_launch_debug_nn(hipStream_t s, const M3dLevelDev& L, const float* q_xyz, int nq, float dmax2, int32_t* out_idx,

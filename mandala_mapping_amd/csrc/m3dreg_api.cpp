@@ -176,6 +176,7 @@ struct m3dreg_handle {
     hipEvent_t fork_ev = nullptr;      // recorded on this handle's stream in front of a split batch: the lanes' streams wait for it
     std::vector<hipEvent_t> join_ev;   // recorded behind a lane's part of the batch: this handle's stream waits for them
     std::vector<size_t> split;         // pairs per chain of the split batch awaiting m3dreg_batch_wait (empty: not split)
+    int alone = 0;                     // m3dreg_set_latency_mode: this handle's batches have the GPU to themselves (grids sized for latency)
     int batch_chains = 0;              // m3dreg_set_batch_chains: 0 = library default, 1 = never split, k = at most k chains
     bool is_lane = false;
 };
@@ -638,7 +639,8 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // {match, certificate word} (8 B) | cache (int64)
         h->match_cap = cap;
     }
-    const size_t n_part = n_pairs * size_t(m3d_acc_blocks(max_n_src, int(n_pairs))) * M3D_PARTIAL_STRIDE;
+    // (sized for either setting of m3dreg_set_latency_mode: the mode may change between batches)
+    const size_t n_part = n_pairs * size_t(std::max(m3d_acc_blocks(max_n_src, int(n_pairs), 0), m3d_acc_blocks(max_n_src, int(n_pairs), 1))) * M3D_PARTIAL_STRIDE;
     if (n_part > h->partials_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_partials) hipFree(h->d_partials);
@@ -646,7 +648,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipMalloc((void**)&h->d_partials, sizeof(long long) * (n_part + n_part / 4)));
         h->partials_cap = n_part + n_part / 4;
     }
-    const size_t n_tk = size_t(m3d_ticket_words(int(n_pairs), max_n_src));
+    const size_t n_tk = size_t(std::max(m3d_ticket_words(int(n_pairs), max_n_src, 0), m3d_ticket_words(int(n_pairs), max_n_src, 1)));
     if (n_tk > h->tickets_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_tickets) hipFree(h->d_tickets);
@@ -702,6 +704,7 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
     w.rot = h->xcd_rot;
+    w.alone = h->alone;
     // (lean per LEVEL: only on the finest level of a registration — a pyramid's coarse levels put more points into a bucket than a tile image holds,
     // their queries would all take the fallback list: config 5 with lean on every level took 6.5 instead of 5.9 ms)
     // (one-level registrations only; on the finest level of a pyramid it was measured on config 5: 4.21 vs 4.14 ms, no gain, and a crowded finest level would leave every query pending)
@@ -1195,6 +1198,12 @@ static int chains_for(const m3dreg_handle* h, size_t n_pairs) {
     if (want > 4) want = 4;
     const int by_size = int(n_pairs / 2);   // at least two pairs per chain
     return want < by_size ? want : by_size;
+}
+
+int m3dreg_set_latency_mode(m3dreg_handle* h, int on) {
+    if (!h || h->pending_pairs) return M3DREG_ERR_INVALID_ARG;   // (not between an asynchronous call and its wait: the batch's grids are laid out)
+    h->alone = on ? 1 : 0;
+    return M3DREG_OK;
 }
 
 int m3dreg_set_batch_chains(m3dreg_handle* h, int chains) {

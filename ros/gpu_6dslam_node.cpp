@@ -69,6 +69,7 @@ public:
             ros::shutdown();
             return;
         }
+        m3dreg_set_latency_mode(h_, 1);   // ONE spin thread, one registration per sweep: this handle's work has the GPU to itself (ABI 7)
         if (mode_ == "scan_to_map" && m3dmap_create(h_, float(map_leaf_), size_t(map_capacity_), &map_) != M3DREG_OK) {
             ROS_FATAL("m3dmap_create: %s", m3dreg_last_error(h_));
             ros::shutdown();

@@ -228,6 +228,37 @@ def test_internal_chains_on_a_pyramid(reg, orc, metric):
     R.set_batch_chains(0)
 
 
+def test_latency_mode_gives_the_same_bits(reg, orc):
+    """ABI 7, m3dreg_set_latency_mode: a serial caller's statement that its batches have the GPU to themselves changes launch grids (the reduction pass's
+    workgroups per pair), never a bit: batches and single registrations with the mode on, off and toggled between batches equal the oracle; the call is refused
+    between an asynchronous call and its wait."""
+    p = _params(leaf=0.25, iterations=10, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
+    R = reg.Registrar(p)
+    raw, ref = [], []
+    for k in range(8):
+        tgt = synth.planes_cloud(9000 + 1500 * k, 400 + k)
+        Tg = synth.random_T(np.random.default_rng(500 + k), 2.0, 0.1)
+        src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(8000 + 1000 * k, 430 + k)).astype(np.float32)
+        raw.append((src, tgt))
+        ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+    for on, n in ((True, 8), (False, 8), (True, 3), (True, 1), (False, 1), (True, 8)):
+        R.set_latency_mode(on)
+        cl = R.clouds([a for s_, t_ in raw[:n] for a in (s_, t_)])
+        pairs = [(cl[2 * i], cl[2 * i + 1], None) for i in range(n)]
+        Tb, stb = R.align_batch(pairs)
+        for k in range(n):
+            assert np.array_equal(Tb[k], ref[k][0]), (on, n, k)
+            _same_stats(stb[k], ref[k][1])
+        if n == 3:
+            R.align_batch_async(R._pairs(pairs), n)
+            with pytest.raises(Exception):
+                R.set_latency_mode(False)
+            Ta, _ = R.batch_wait(n)
+            assert np.array_equal(Ta, Tb)
+        for c in cl:
+            c.free()
+
+
 def test_status_codes(reg, orc):
     p = _params(leaf=0.5, iterations=5, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.5)
     R = reg.Registrar(p)
