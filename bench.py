@@ -558,7 +558,7 @@ def main():
                                    "decode of both clouds, sort of the source (m3dreg_cloud_desc.source_only), bucketing + tile images + normals of the target inside the timed region",
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step",
-                       "overlap": (("none (serial steps, synchronous calls: the library's internal chains)" if serial_calls else "none (serial steps, one chain)") if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
+                       "overlap": ((("none (serial steps, synchronous calls" + ("" if args.no_latency_mode else ", m3dreg_set_latency_mode on: the caller says its batches have the GPU to themselves") + ")") if serial_calls else "none (serial steps, one chain)") if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
                                   (f"; {Q} steps queued per stream" if Q > 1 else "")},
             "ms_per_icp_iter_batch": chain_iter_ms if chain_iter_ms > 0 else iter_ms / max(1, iters_timed),
             "ms_per_icp_iter_per_pair": (chain_iter_ms if chain_iter_ms > 0 else iter_ms / max(1, iters_timed)) / B,
