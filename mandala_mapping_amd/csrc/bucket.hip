@@ -325,14 +325,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
         // (shuffles inside a wave, the four wave sums through LDS at the barrier below)
         uint32_t before = 0;
         int j = 0;
-        for (; j + 8 <= ntiles; j += 8) {
-            uint32_t v[8];
+        // (32 loads in flight, then 8, then the rest: a 100 k-point cloud has 49 tiles — seven trips of eight were seven round trips at the head of every scatter workgroup)
+        for (; j + 32 <= ntiles; j += 32) {
+            uint32_t v[32];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = scanned[(j + k) * 256 + t];
+            for (int k = 0; k < 32; k++) v[k] = scanned[(j + k) * 256 + t];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { total += v[k]; before += (j + k < tile) ? v[k] : 0u; }
+            for (int k = 0; k < 32; k++) { total += v[k]; before += (j + k < tile) ? v[k] : 0u; }
         }
-        for (; j < ntiles; j++) { const uint32_t v = scanned[j * 256 + t]; total += v; before += (j < tile) ? v : 0u; }
+        {   // up to 31 left: 32 predicated loads in ONE trip
+            uint32_t v[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) v[k] = (j + k < ntiles) ? scanned[(j + k) * 256 + t] : 0u;
+#pragma unroll
+            for (int k = 0; k < 32; k++) { total += v[k]; before += (j + k < tile) ? v[k] : 0u; }
+        }
         inc = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
