@@ -2288,6 +2288,9 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 // no other batch of the process was in flight — a process-global counter for 1 % of a serial step, profiles/r04_zoo_ab.txt: gone.)
 // Bounds: at most 7 queries per thread (M3D_LATE_QPT: k_icp_late's worklist; the amortisation of the 29-term block reduction has little left to give
 // beyond), at least 1.5 unless that contradicts the first; a thread's 32-bit running sums count their carries in 8-bit fields: never more than 128 per thread.
+#ifndef M3D_ALONE_WGS
+#define M3D_ALONE_WGS 768
+#endif
 int m3d_acc_blocks(int max_n_src, int n_pairs, int alone) {
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
     int b = (max_n_src + 256 * M3D_LATE_QPT - 1) / (256 * M3D_LATE_QPT);
@@ -2298,7 +2301,7 @@ int m3d_acc_blocks(int max_n_src, int n_pairs, int alone) {
     // 512 workgroups per batch: two per CU, a third stays free for whatever else shares the GPU (the headline keeps four chains in flight: with 768 it loses 3.4 %).
     // alone (m3dreg_set_latency_mode: the caller states that this handle's batches have the GPU to themselves): 768, all three a CU holds — serial steps +3.6 %
     // (round 5, profiles/r05_latency_mode.txt). A function of the batch and of that statement, never of what the process happens to have in flight.
-    int t = ((alone ? 768 : 512) + n_pairs - 1) / n_pairs;
+    int t = ((alone ? M3D_ALONE_WGS : 512) + n_pairs - 1) / n_pairs;
     if (t > hi) t = hi;
     if (t > b) b = t;
     // the pair's last workgroup loads the partials 8 x M3D_TAIL_LOADS = 256 per round trip (m3d_pair_tail): a lone 100 k-point pair got 260 workgroups, and its tail a
