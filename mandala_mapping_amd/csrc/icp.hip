@@ -1782,9 +1782,11 @@ __device__ int m3d_solve_update(const long long sums[M3D_NSUMS], const int exps[
 }
 
 // One thread per pair: consume the sums of the iteration that just ran, update the pose, decide.
-__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr, const double* T_pre = nullptr) {
+// active_known: the caller's workgroups left at once had the pair been finished (the reduction kernels) — the state's flags are not loaded again: the solve's other loads
+// then do not wait behind that round trip
+__device__ __forceinline__ void m3d_solve_pair(const M3dJob& J, int first_of_level, const long long* raw = nullptr, const double* T_pre = nullptr, bool active_known = false) {
     M3dPairState* st = J.st;
-    if (st->done || (!first_of_level && st->level_done)) return;
+    if (!active_known && (st->done || (!first_of_level && st->level_done))) return;
     long long sums[M3D_NSUMS];
     const bool own = raw == nullptr;   // sums accumulated by atomics in the state (fused variants) or handed in (block partials)
     if (own) raw = st->sums;
@@ -1931,7 +1933,7 @@ __device__ __forceinline__ void m3d_pair_tail(const M3dJob* __restrict__ jobs, c
     }
     if (threadIdx.x != 0) return;
     TAIL_STAMP(3);
-    m3d_solve_pair(J, first_of_level, s_part[0], T_pre);
+    m3d_solve_pair(J, first_of_level, s_part[0], T_pre, true);   // (every caller of this tail returned at its first line for a finished pair)
     TAIL_STAMP(4);
     m3d_report_progress(jobs, n_pairs, !st->done && !st->level_done, seq, progress);
     TAIL_STAMP(5);
