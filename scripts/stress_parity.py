@@ -27,6 +27,8 @@ for case in range(n_cases):
     sched["M3DREG_TILE_ITERS"] = sched["M3DREG_FUSE_FROM"]
     os.environ.update(sched)
     R = binding.Registrar(p)
+    lat = bool(rng.integers(0, 2))
+    R.set_latency_mode(lat)   # (ABI 7: the serial caller's statement changes launch grids, never a bit)
     k_pairs = int(rng.integers(1, 10))
     pairs, refs = [], []
     for k in range(k_pairs):
