@@ -226,8 +226,9 @@ int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pair
 int m3dreg_set_batch_chains(m3dreg_handle* h, int chains);
 /* (ABI 7) A caller that makes ONE call at a time on this GPU — the ROS node: one spin thread, one registration or one batch per sweep
  * (m3d_aggregator.cpp:185) — says so: on != 0 sizes this handle's launch grids for a GPU it has to itself (the reduction pass takes all
- * three workgroups a CU holds instead of leaving one to other batches): +3.6 % for synchronous 8-pair steps, measured; -3.4 % when other
- * handles' batches DO share the GPU (bench.py's headline keeps four in flight: leave it off there). Same results either way (the sums are
+ * three workgroups a CU holds — 768 per batch — where the default, sized for a GPU that other batches share, takes 448): +6 % for
+ * synchronous 8-pair steps, measured; -4 % when other handles' batches DO share the GPU (bench.py's headline keeps four in flight:
+ * leave it off there). Same results either way (the sums are
  * integers). The library never guesses this from what the process has in flight. Refused (M3DREG_ERR_INVALID_ARG) between
  * m3dreg_align_batch_async and its wait. Default off. */
 int m3dreg_set_latency_mode(m3dreg_handle* h, int on);

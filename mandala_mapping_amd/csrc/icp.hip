@@ -2293,6 +2293,9 @@ __host__ __device__ inline int m3d_ticket_group(int bpp) { int g = 1; while (g *
 #ifndef M3D_ALONE_WGS
 #define M3D_ALONE_WGS 768
 #endif
+#ifndef M3D_SHARED_WGS
+#define M3D_SHARED_WGS 448
+#endif
 int m3d_acc_blocks(int max_n_src, int n_pairs, int alone) {
     const int b_min = (max_n_src + 256 * 128 - 1) / (256 * 128);
     int b = (max_n_src + 256 * M3D_LATE_QPT - 1) / (256 * M3D_LATE_QPT);
@@ -2300,10 +2303,11 @@ int m3d_acc_blocks(int max_n_src, int n_pairs, int alone) {
     if (b < b_min) b = b_min;
     if (n_pairs <= 0) return b;
     int hi = max_n_src / 384; if (hi < b) hi = b;
-    // 512 workgroups per batch: two per CU, a third stays free for whatever else shares the GPU (the headline keeps four chains in flight: with 768 it loses 3.4 %).
+    // M3D_SHARED_WGS workgroups per batch by default — the default is sized for a GPU that other batches share (the headline keeps four chains in flight: 448 / 512 / 768
+    // give 8693 / 8652 / 8366 registrations/s; fewer than 448 would exceed M3D_LATE_QPT queries per thread for 100 k-point pairs).
     // alone (m3dreg_set_latency_mode: the caller states that this handle's batches have the GPU to themselves): 768, all three a CU holds — serial steps +3.6 %
     // (round 5, profiles/r05_latency_mode.txt). A function of the batch and of that statement, never of what the process happens to have in flight.
-    int t = ((alone ? M3D_ALONE_WGS : 512) + n_pairs - 1) / n_pairs;
+    int t = ((alone ? M3D_ALONE_WGS : M3D_SHARED_WGS) + n_pairs - 1) / n_pairs;
     if (t > hi) t = hi;
     if (t > b) b = t;
     // the pair's last workgroup loads the partials 8 x M3D_TAIL_LOADS = 256 per round trip (m3d_pair_tail): a lone 100 k-point pair got 260 workgroups, and its tail a

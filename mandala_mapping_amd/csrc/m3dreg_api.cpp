@@ -1187,7 +1187,7 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
 // after all parts). Results do not depend on the cut: every pair's sums are integers, its schedule inside a chain is the schedule of a smaller batch, which
 // gives the same bits (tests/test_gpu_parity.py: test_internal_chains_...). MEASURED (profiles/r05_batch_chains.txt, 8 pairs x 100 k per call, serial
 // calls): 1 chain 4982 registrations/s, 2 chains 4642, 3 chains 4430, 4 chains 3233; 64 pairs: 7179 / 7110 / - / 6449. The iteration kernels of one chain
-// are latency-bound at a duration that hardly shrinks with the batch (k_nn_tiles' persistent grid, the reduction's 512 workgroups, the serial solve tail), so
+// are latency-bound at a duration that hardly shrinks with the batch (k_nn_tiles' persistent grid, the reduction's few hundred workgroups, the serial solve tail), so
 // two half-size chains each take ~85 % of the full chain's time and share the chip: the split loses. What round 4 measured as "two 4-pair chains beat one
 // 8-pair chain" (5553 vs 4755) was two STEPS in flight — the bucketing of step i + 1 under the iterations of step i — which a caller gets from the
 // asynchronous API (two handles), not from a cut inside one call. Hence the default: one chain.
