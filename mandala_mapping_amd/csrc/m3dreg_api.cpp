@@ -176,6 +176,8 @@ struct m3dreg_handle {
     hipEvent_t fork_ev = nullptr;      // recorded on this handle's stream in front of a split batch: the lanes' streams wait for it
     std::vector<hipEvent_t> join_ev;   // recorded behind a lane's part of the batch: this handle's stream waits for them
     std::vector<size_t> split;         // pairs per chain of the split batch awaiting m3dreg_batch_wait (empty: not split)
+    hipEvent_t done_ev = nullptr;      // recorded behind a batch's last operation (m3dreg_batch_wait waits for it, not for the whole stream)
+    bool done_recorded = false;
     int alone = 0;                     // m3dreg_set_latency_mode: this handle's batches have the GPU to themselves (grids sized for latency)
     int batch_chains = 0;              // m3dreg_set_batch_chains: 0 = library default, 1 = never split, k = at most k chains
     bool is_lane = false;
@@ -853,6 +855,7 @@ void release_handle(m3dreg_handle* h) {
     sync_handle(h);
     for (m3dreg_handle* lane : h->lanes) release_handle(lane);   // (a lane owns no cloud)
     h->lanes.clear();
+    if (h->done_ev) hipEventDestroy(h->done_ev);
     if (h->fork_ev) hipEventDestroy(h->fork_ev);
     for (hipEvent_t e : h->join_ev) hipEventDestroy(e);
     for (Block& b : h->pool) hipFree(b.p);
@@ -1134,6 +1137,11 @@ static int batch_end(m3dreg_handle* h, const m3dreg_pair* pairs) {
         if ((rc = note_foreign_use(h, pairs[i].target))) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_states, h->d_states, sizeof(M3dPairState) * n_pairs, hipMemcpyDeviceToHost, h->stream));
+    // m3dreg_batch_wait waits for THIS point of the stream, not for the stream: handles that share a stream queue batches behind each other (bench.py: two per
+    // stream), and a wait for the whole stream also waited for the batch queued behind this one — the stream then ran dry until the host had enqueued the next
+    if (!h->done_ev) HIPCHK(h, hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->done_ev, h->stream));
+    h->done_recorded = true;
     // (the pose trace of pair 0 stays on the device: m3dreg_debug_trace fetches it when asked — a 32 KB copy per batch otherwise)
     h->pending_pairs = n_pairs;
     return M3DREG_OK;
@@ -1152,7 +1160,8 @@ int m3dreg_align_batch_async(m3dreg_handle* h, const m3dreg_pair* pairs, size_t 
 int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     return m3d_guarded(h, "m3dreg_batch_wait", [&]() -> int {
     if (!h || h->pending_pairs == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "batch_wait: nothing pending");
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->done_recorded) { HIPCHK(h, hipEventSynchronize(h->done_ev)); h->done_recorded = false; }
+    else HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->split.empty()) {   // a batch the synchronous call spread over internal chains: this stream has waited for the lanes' (join events)
         size_t off = h->split[0];
         for (size_t c = 1; c < h->split.size(); c++) {
