@@ -178,6 +178,7 @@ struct m3dreg_handle {
     std::vector<size_t> split;         // pairs per chain of the split batch awaiting m3dreg_batch_wait (empty: not split)
     hipEvent_t done_ev = nullptr;      // recorded behind a batch's last operation (m3dreg_batch_wait waits for it, not for the whole stream)
     bool done_recorded = false;
+    bool throttle = false;             // inside the synchronous m3dreg_align_batch: the enqueue of a convergence-terminated batch stays a few iterations ahead of the device, not a level
     int alone = 0;                     // m3dreg_set_latency_mode: this handle's batches have the GPU to themselves (grids sized for latency)
     int batch_chains = 0;              // m3dreg_set_batch_chains: 0 = library default, 1 = never split, k = at most k chains
     bool is_lane = false;
@@ -1091,6 +1092,21 @@ static int batch_step(m3dreg_handle* h) {
         if (R.it >= P.iterations[R.l]) { R.l++; R.it = 0; continue; }
         if (R.it == 0) R.level_first_seq = h->seq + 1;
         if (R.can_stop_early && R.it > 0) {   // nothing left to do at this level? (a stale value only delays the exit)
+            if (h->throttle) {
+                // The SYNCHRONOUS call (the host waits for the batch anyway): never more than M3D_AHEAD iterations ahead of the device. The host enqueues an
+                // iteration in a quarter of the time the device takes to run it, so by the time a level's last useful iteration ran, a dozen more were queued —
+                // launches that find the level finished and leave, ~5 us each (config 2: 29 of its 212 launches). Four queued iterations are >= 100 us of work:
+                // the device never runs dry. (Not in m3dreg_align_batch_async: a caller that feeds several handles must not be held up inside one of them.)
+#ifndef M3D_AHEAD_ITERS
+#define M3D_AHEAD_ITERS 4
+#endif
+                constexpr unsigned int M3D_AHEAD = M3D_AHEAD_ITERS;
+                for (int spin = 0; spin < 200000; spin++) {   // (bounded: a device that stopped reporting only costs the wait)
+                    const unsigned int done = (unsigned int)(*h->h_progress >> 32);
+                    if (h->seq - done <= M3D_AHEAD || done > h->seq) break;   // (done > seq: a word of an earlier life of the counter)
+                    __builtin_ia32_pause();
+                }
+            }
             const unsigned long long v = *h->h_progress;
             if ((unsigned int)(v >> 32) >= R.level_first_seq && (unsigned int)(v >> 32) <= h->seq && (unsigned int)v == 0u) {
                 h->skipped_iters += uint64_t(P.iterations[R.l] - R.it);
@@ -1226,7 +1242,9 @@ int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pair
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
     const int K = chains_for(h, n_pairs);
     if (K <= 1) {
+        h->throttle = true;
         int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
+        h->throttle = false;
         if (rc) return rc;
         return m3dreg_batch_wait(h, out_T, stats);
     }
