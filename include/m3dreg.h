@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define M3DREG_ABI_VERSION 7   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
+#define M3DREG_ABI_VERSION 8   /* 2: + m3dreg_cloud_create_batch_async, m3dreg_cloud_status, M3DREG_BAD_CLOUD, m3dreg_cloud_desc.source_only,
                                      M3DREG_CLOUD_* flags; m3dreg_align_batch_async refuses a second pending batch
                                   3: + m3dreg_multi_* (one process, several devices), M3DREG_ERR_OUT_OF_MEMORY (every entry point is
                                      exception-guarded), M3DREG_PROFILE_BUCKETING / _REDUCE_SOLVE, cloud lifetime rules (below),
@@ -357,6 +357,63 @@ int m3dmap_size(m3dmap* m, size_t* n_points);
 int m3dmap_as_cloud(m3dmap* m, m3dreg_cloud** out);          /* the map as a bucketed target (the map itself keeps growing) */
 int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
 int m3dmap_clear(m3dmap* m);
+
+/* ---- loop-closure candidate generation (second half; ABI 8) -----------------
+ * Decides WHICH pairs a loop-closure batch registers — the step in front of m3dreg_align_batch / m3dreg_multi_align (BASELINE config 4:
+ * "batch of 64 loop-closure scan pairs"). No reference source exists (the node the reference launches is called gpu_6dslam_node,
+ * m3d_husky_bringup.launch:13, and its repository is an empty submodule): the behaviour is this library's own, specified in DESIGN.md §10
+ * and restated by oracle/m3d_loop_oracle.c.
+ *   keyframe k  = (pose T_k of the sweep in the map frame, a bucketed cloud resident in HBM), numbered in insertion order;
+ *   signature   = a bitmap of 2^sig_log2_bits bits: every finite point p of the cloud sets the bit hash(floor((R_k p + t_k) / sig_leaf)) —
+ *                 the coarse voxels of the MAP frame the sweep saw (built on the device from the cloud's resident points, never downloaded);
+ *   candidates  of keyframe i: every older keyframe j with i - j >= min_gap and |t_i - t_j| <= radius whose overlap
+ *                 popcount(sig_i & sig_j) is at least min_overlap * min(popcount(sig_i), popcount(sig_j)); the top_k of them by overlap (ties: the
+ *                 older keyframe first). All integer arithmetic: the result does not depend on launch geometry.
+ * A candidate names source = i (the later sweep), target = j, and carries init_T = inv(T_j) * T_i, the odometry's guess of source -> target.
+ * m3dloop_make_pairs turns candidates into m3dreg_pair[] (the keyframes' resident clouds) for m3dreg_align_batch;
+ * m3dloop_make_pair_descs into m3dreg_pair_desc[] (the payload descriptors given with the keyframes, target_group = target + 1: pairs against
+ * one keyframe stay on one device and its cloud is bucketed once) for m3dreg_multi_align. m3dloop_gate is the acceptance test on the
+ * registration's statistics. Keyframe clouds stay the caller's: they must outlive the m3dloop (or its m3dloop_clear) and must not be
+ * source-only when they are to be targets. */
+typedef struct m3dloop m3dloop;
+typedef struct m3dloop_params {
+    float sig_leaf;          /* edge of the signature's voxels [m] (default 2.0: coarse enough to survive the drift a loop accumulates) */
+    int32_t sig_log2_bits;   /* signature size = 2^this bits, 10 .. 18 (default 16: 8 KB per keyframe) */
+    float radius;            /* [m] keyframe positions at most this far apart (default 10) */
+    int32_t min_gap;         /* >= 1: keyframes at least this many insertions apart (default 10: not the odometry's own neighbours) */
+    int32_t top_k;           /* 1 .. 16 candidates per keyframe at most (default 2) */
+    float min_overlap;       /* 0 .. 1 (default 0.5) */
+    int32_t max_keyframes;   /* capacity (default 4096) */
+    int32_t reserved;        /* must be 0 */
+} m3dloop_params;
+typedef struct m3dloop_candidate {
+    int32_t source, target;            /* keyframe indices, source > target */
+    uint32_t overlap;                  /* popcount(sig_source & sig_target) */
+    uint32_t pop_source, pop_target;   /* popcount of either signature */
+    float dist2;                       /* |t_source - t_target|^2 as the prefilter computed it */
+    float init_T[16];                  /* column-major inv(T_target) * T_source */
+} m3dloop_candidate;
+int m3dloop_default_params(m3dloop_params* out);
+int m3dloop_create(m3dreg_handle* h, const m3dloop_params* params, m3dloop** out);
+int m3dloop_destroy(m3dloop* l);
+int m3dloop_clear(m3dloop* l);
+/* `payload` (may be NULL): the descriptor of the sweep's raw PointCloud2 payload, kept by value for m3dloop_make_pair_descs. */
+int m3dloop_add_keyframe(m3dloop* l, const m3dreg_cloud* cloud, const float T[16], const m3dreg_cloud_desc* payload, int32_t* index);
+/* a pose graph moved keyframe `index`: its signature is rebuilt from its cloud at the new pose */
+int m3dloop_update_pose(m3dloop* l, int32_t index, const float T[16]);
+int m3dloop_size(m3dloop* l, size_t* n_keyframes);
+/* Candidates of keyframes first .. first + count - 1 (count < 0: to the newest), row by row, best first inside a row; at most `cap` are
+ * written, *n_out receives how many exist. A node calls it with the keyframe it has just added (one row against the whole database: one
+ * streaming pass over the older signatures); a back end that rebuilds its graph calls it for all rows. Waits for the device. */
+int m3dloop_candidates(m3dloop* l, int32_t first, int32_t count, m3dloop_candidate* out, size_t cap, size_t* n_out);
+int m3dloop_make_pairs(m3dloop* l, const m3dloop_candidate* cands, size_t n, m3dreg_pair* out);
+int m3dloop_make_pair_descs(m3dloop* l, const m3dloop_candidate* cands, size_t n, m3dreg_pair_desc* out);
+/* accept[i] = 1 iff the registration ended CONVERGED or MAX_ITERATIONS with n_corr >= min_corr and rms <= max_rms */
+int m3dloop_gate(const m3dloop_candidate* cands, const m3dreg_stats* stats, size_t n, int64_t min_corr, double max_rms, uint8_t* accept);
+/* tests: the signature words (2^sig_log2_bits / 32 of them) and its popcount */
+int m3dloop_signature(m3dloop* l, int32_t index, uint32_t* words, uint32_t* pop);
+/* device time of the last m3dloop_candidates call's kernels [ms] (hipEvents on the handle's stream) and the bytes of signatures they had to read */
+int m3dloop_last_profile(m3dloop* l, double* ms, uint64_t* algorithmic_bytes);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Per-stage device times of the path ("ms per stage"). on = 0: off; on = n >= 1: every n-th Gauss-Newton iteration

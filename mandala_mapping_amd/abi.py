@@ -5,7 +5,7 @@ HIP library and to the CPU oracle in the parity tests.
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LEVELS = 4
 NSUMS = 29
 
@@ -131,6 +131,25 @@ class Pair(C.Structure):
 
 class PairDesc(C.Structure):   # m3dreg_pair_desc (m3dreg_multi_align)
     _fields_ = [("source", CloudDesc), ("target", CloudDesc), ("init_T", C.c_float * 16), ("target_group", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LoopParams(C.Structure):   # m3dloop_params
+    _fields_ = [("sig_leaf", C.c_float), ("sig_log2_bits", C.c_int32), ("radius", C.c_float), ("min_gap", C.c_int32), ("top_k", C.c_int32),
+                ("min_overlap", C.c_float), ("max_keyframes", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def make(cls, sig_leaf=2.0, sig_log2_bits=16, radius=10.0, min_gap=10, top_k=2, min_overlap=0.5, max_keyframes=4096):
+        p = cls()
+        p.sig_leaf, p.sig_log2_bits, p.radius, p.min_gap, p.top_k, p.min_overlap, p.max_keyframes, p.reserved = sig_leaf, sig_log2_bits, radius, min_gap, top_k, min_overlap, max_keyframes, 0
+        return p
+
+
+class LoopCandidate(C.Structure):   # m3dloop_candidate
+    _fields_ = [("source", C.c_int32), ("target", C.c_int32), ("overlap", C.c_uint32), ("pop_source", C.c_uint32), ("pop_target", C.c_uint32),
+                ("dist2", C.c_float), ("init_T", C.c_float * 16)]
+
+    def as_tuple(self):
+        return (self.source, self.target, self.overlap, self.pop_source, self.pop_target, bytes(C.c_float(self.dist2)), bytes(self.init_T))
 
 
 class M3dregError(RuntimeError):

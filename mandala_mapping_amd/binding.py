@@ -36,6 +36,8 @@ EXPORTS = [
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
     "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error", "m3dreg_debug_multi_clouds",
     "m3dreg_debug_fail_alloc", "m3dreg_debug_throw",
+    "m3dloop_default_params", "m3dloop_create", "m3dloop_destroy", "m3dloop_clear", "m3dloop_add_keyframe", "m3dloop_update_pose", "m3dloop_size", "m3dloop_candidates",
+    "m3dloop_make_pairs", "m3dloop_make_pair_descs", "m3dloop_gate", "m3dloop_signature", "m3dloop_last_profile",
     "m3dreg_debug_candidates", "m3dreg_host_alloc", "m3dreg_host_free", "m3dreg_host_register", "m3dreg_host_unregister",
 ]
 
@@ -131,6 +133,19 @@ def lib():
     L.m3dreg_multi_last_error.argtypes = [vp]
     L.m3dreg_debug_multi_clouds.argtypes = [vp]
     L.m3dreg_multi_last_error.restype = C.c_char_p
+    L.m3dloop_default_params.argtypes = [C.POINTER(abi.LoopParams)]
+    L.m3dloop_create.argtypes = [vp, C.POINTER(abi.LoopParams), C.POINTER(vp)]
+    L.m3dloop_destroy.argtypes = [vp]
+    L.m3dloop_clear.argtypes = [vp]
+    L.m3dloop_add_keyframe.argtypes = [vp, vp, f32p, C.POINTER(abi.CloudDesc), i32p]
+    L.m3dloop_update_pose.argtypes = [vp, C.c_int32, f32p]
+    L.m3dloop_size.argtypes = [vp, C.POINTER(sz)]
+    L.m3dloop_candidates.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(abi.LoopCandidate), sz, C.POINTER(sz)]
+    L.m3dloop_make_pairs.argtypes = [vp, C.POINTER(abi.LoopCandidate), sz, C.POINTER(abi.Pair)]
+    L.m3dloop_make_pair_descs.argtypes = [vp, C.POINTER(abi.LoopCandidate), sz, C.POINTER(abi.PairDesc)]
+    L.m3dloop_gate.argtypes = [C.POINTER(abi.LoopCandidate), C.POINTER(abi.Stats), sz, C.c_int64, C.c_double, C.POINTER(C.c_uint8)]
+    L.m3dloop_signature.argtypes = [vp, C.c_int32, u32p, u32p]
+    L.m3dloop_last_profile.argtypes = [vp, f64p, C.POINTER(C.c_uint64)]
     L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
     L.m3dreg_debug_throw.argtypes = [C.c_int]
     _lib = L
@@ -627,6 +642,94 @@ class Map:
 
     def clear(self):
         self._reg._check(lib().m3dmap_clear(self._m), "m3dmap_clear")
+
+
+class LoopCloser:
+    """Loop-closure candidate generation (m3dloop_*): keyframes = (pose, resident cloud); candidates (i, j) are scored on the
+    device by the overlap of their coarse-voxel signatures and come out as m3dreg_pair[] / m3dreg_pair_desc[] for the batch path."""
+
+    def __init__(self, reg: Registrar, params=None):
+        self._reg = reg
+        self._l = C.c_void_p()
+        if params is None:
+            params = abi.LoopParams()
+            lib().m3dloop_default_params(C.byref(params))
+        self.params = params
+        self._clouds = []   # keeps the keyframes' Cloud objects alive (the library holds their pointers)
+        reg._check(lib().m3dloop_create(reg._h, C.byref(params), C.byref(self._l)), "m3dloop_create")
+
+    def close(self):
+        if self._l:
+            lib().m3dloop_destroy(self._l)
+            self._l = None
+        self._clouds = []
+
+    def __del__(self):
+        try:
+            if self._reg._h:
+                self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_size_t()
+        self._reg._check(lib().m3dloop_size(self._l, C.byref(n)), "m3dloop_size")
+        return n.value
+
+    def add_keyframe(self, cloud: Cloud, T, payload=None):
+        """T: 4x4 pose of the sweep in the map frame; payload: an abi.CloudDesc of its raw PointCloud2 payload (for pair_descs) or None"""
+        t = T_to_colmajor16(T)
+        k = C.c_int32(-1)
+        self._reg._check(lib().m3dloop_add_keyframe(self._l, cloud._p, _ptr(t, C.c_float), C.byref(payload) if payload is not None else None, C.byref(k)), "m3dloop_add_keyframe")
+        self._clouds.append((cloud, payload))
+        return k.value
+
+    def update_pose(self, index, T):
+        t = T_to_colmajor16(T)
+        self._reg._check(lib().m3dloop_update_pose(self._l, index, _ptr(t, C.c_float)), "m3dloop_update_pose")
+
+    def clear(self):
+        self._reg._check(lib().m3dloop_clear(self._l), "m3dloop_clear")
+        self._clouds = []
+
+    def signature(self, index):
+        w = np.zeros(1 << (self.params.sig_log2_bits - 5), np.uint32)
+        pop = C.c_uint32()
+        self._reg._check(lib().m3dloop_signature(self._l, index, _ptr(w, C.c_uint32), C.byref(pop)), "m3dloop_signature")
+        return w, pop.value
+
+    def candidates(self, first=0, count=-1):
+        """-> ctypes array of abi.LoopCandidate (rows first .. first + count - 1; count < 0: to the newest keyframe)"""
+        n = C.c_size_t()
+        cap = max(1, (len(self) if count < 0 else count) * self.params.top_k)
+        arr = (abi.LoopCandidate * cap)()
+        self._reg._check(lib().m3dloop_candidates(self._l, first, count, arr, cap, C.byref(n)), "m3dloop_candidates")
+        return (abi.LoopCandidate * n.value).from_buffer_copy(bytes(arr)[: n.value * C.sizeof(abi.LoopCandidate)]) if n.value else (abi.LoopCandidate * 0)()
+
+    def last_profile(self):
+        ms, b = C.c_double(), C.c_uint64()
+        self._reg._check(lib().m3dloop_last_profile(self._l, C.byref(ms), C.byref(b)), "m3dloop_last_profile")
+        return ms.value, b.value
+
+    def pairs(self, cands):
+        arr = (abi.Pair * max(1, len(cands)))()
+        self._reg._check(lib().m3dloop_make_pairs(self._l, cands, len(cands), arr), "m3dloop_make_pairs")
+        return arr
+
+    def pair_descs(self, cands):
+        arr = (abi.PairDesc * max(1, len(cands)))()
+        self._reg._check(lib().m3dloop_make_pair_descs(self._l, cands, len(cands), arr), "m3dloop_make_pair_descs")
+        return arr
+
+    @staticmethod
+    def gate(cands, stats, min_corr, max_rms):
+        n = len(cands)
+        st = (abi.Stats * max(1, n))(*stats)
+        acc = (C.c_uint8 * max(1, n))()
+        rc = lib().m3dloop_gate(cands, st, n, int(min_corr), float(max_rms), acc)
+        if rc != 0:
+            raise abi.M3dregError(rc, "m3dloop_gate")
+        return [bool(acc[i]) for i in range(n)]
 
 
 class Calibrator:

@@ -132,6 +132,29 @@ struct M3dMapArgs {
 };
 hipError_t m3d_launch_map_insert(hipStream_t s, const M3dMapArgs& A);
 
+// loop.hip (second half: loop-closure candidate generation)
+struct M3dLoopSignArgs {
+    const float4* src;           // [n] the keyframe cloud's points in input order (m3dreg_cloud::xyz)
+    int n;
+    float R[9], t[3];            // pose of the keyframe in the map frame, rounded to float (row-major R)
+    float inv_leaf;              // 1.0f / sig_leaf
+    uint32_t* sig;               // [2^log2_bits / 32] the keyframe's signature (zeroed by the launcher)
+    int log2_bits;               // 10 .. 18
+};
+struct M3dLoopScoreArgs {
+    const uint32_t* sig;         // [keyframes][W] signatures
+    const float4* pos;           // [keyframes] {t.x, t.y, t.z, bits(popcount of the signature)}
+    int W;                       // words per signature (a multiple of 4)
+    int row0, n_rows;            // query rows (keyframes) row0 .. row0 + n_rows - 1
+    int min_gap;                 // columns of row i: j <= i - min_gap
+    float r2;                    // radius^2
+    uint32_t* ov;                // [n_rows][ov_stride] out: overlap of (row, j), or 0xFFFFFFFF where gap / distance rule the pair out
+    int ov_stride;
+    int j_per_wg, tr;            // set by the launcher: columns per workgroup, rows per tile
+};
+hipError_t m3d_launch_loop_sign(hipStream_t s, const M3dLoopSignArgs& A, float4* pos_k);
+hipError_t m3d_launch_loop_score(hipStream_t s, M3dLoopScoreArgs A, uint2* d_out /* [n_rows][top_k] {j or ~0, overlap} */, int top_k, uint32_t thr_q16);
+
 // icp.hip: one Gauss-Newton iteration = k_nn_iter (classify + search / bin), k_nn_tiles (binned searches from LDS), k_accumulate_matches
 // (residuals + reduction; its last block per pair also solves and updates the pose)
 struct M3dNnWork {               // workspace of the batch, all per pair with the same stride (a whole number of 256-query blocks)

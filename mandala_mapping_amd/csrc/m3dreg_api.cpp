@@ -1927,6 +1927,264 @@ int m3dmap_download(m3dmap* m, float* xyzw, size_t cap_points, size_t* n_out) {
     });
 }
 
+// ---- loop-closure candidate generation (second half; include/m3dreg.h) ---------------------------
+}  // extern "C"
+
+struct m3dloop {
+    m3dreg_handle* h = nullptr;
+    m3dloop_params P{};
+    int W = 0;                             // words per signature
+    uint32_t* d_sig = nullptr;             // [max_keyframes][W]
+    float4* d_pos = nullptr;               // [max_keyframes] {t, bits(popcount)}
+    uint32_t* d_ov = nullptr;              // [LOOP_ROWS][max_keyframes] scores of the rows of one launch
+    uint2* d_out = nullptr;                // [LOOP_ROWS][top_k]
+    std::vector<const m3dreg_cloud*> clouds;
+    std::vector<float> poses;              // 16 per keyframe, column-major, as given
+    std::vector<m3dreg_cloud_desc> payloads;
+    std::vector<uint8_t> has_payload;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0; uint64_t last_bytes = 0;
+};
+
+namespace {
+constexpr int LOOP_ROWS = 256;   // query rows per launch of the scoring pass (their score rows live in d_ov)
+
+int loop_sign(m3dloop* l, int32_t k, const m3dreg_cloud* c, const float T[16]) {
+    m3dreg_handle* h = l->h;
+    if (c->owner && c->owner != h && c->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, c->ready->ev, 0));
+    M3dLoopSignArgs A{};
+    A.src = c->xyz; A.n = c->n;
+    for (int r = 0; r < 3; r++) { for (int cc = 0; cc < 3; cc++) A.R[3 * r + cc] = T[cc * 4 + r]; A.t[r] = T[12 + r]; }
+    A.inv_leaf = 1.0f / l->P.sig_leaf;
+    A.sig = l->d_sig + size_t(k) * size_t(l->W);
+    A.log2_bits = l->P.sig_log2_bits;
+    HIPCHK(h, m3d_launch_loop_sign(h->stream, A, l->d_pos + k));
+    return note_foreign_use(h, c);
+}
+
+// inv(T_j) * T_i in double from the float poses, fixed operation order (oracle/m3d_loop_oracle.c: orc_loop_rel)
+void loop_rel(const float* Tj, const float* Ti, float out[16]) {
+    double Rj[3][3], Ri[3][3], d[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { Rj[r][c] = double(Tj[c * 4 + r]); Ri[r][c] = double(Ti[c * 4 + r]); } d[r] = double(Ti[12 + r]) - double(Tj[12 + r]); }
+    for (int k = 0; k < 16; k++) out[k] = 0.0f;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) out[c * 4 + r] = float((Rj[0][r] * Ri[0][c] + Rj[1][r] * Ri[1][c]) + Rj[2][r] * Ri[2][c]);
+        out[12 + r] = float((Rj[0][r] * d[0] + Rj[1][r] * d[1]) + Rj[2][r] * d[2]);
+    }
+    out[15] = 1.0f;
+}
+}  // namespace
+
+extern "C" {
+
+int m3dloop_default_params(m3dloop_params* p) {
+    if (!p) return M3DREG_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->sig_leaf = 2.0f; p->sig_log2_bits = 16; p->radius = 10.0f; p->min_gap = 10; p->top_k = 2; p->min_overlap = 0.5f; p->max_keyframes = 4096;
+    return M3DREG_OK;
+}
+
+int m3dloop_destroy(m3dloop* l) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_destroy", [&]() -> int {
+    if (!l) return M3DREG_ERR_INVALID_ARG;
+    hipSetDevice(l->h->device);
+    hipStreamSynchronize(l->h->stream);
+    for (void* p : { (void*)l->d_sig, (void*)l->d_pos, (void*)l->d_ov, (void*)l->d_out }) if (p) hipFree(p);
+    if (l->ev0) hipEventDestroy(l->ev0);
+    if (l->ev1) hipEventDestroy(l->ev1);
+    delete l;
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_create(m3dreg_handle* h, const m3dloop_params* P, m3dloop** out) {
+    return m3d_guarded(h, "m3dloop_create", [&]() -> int {
+    if (!h || !P || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_create: bad argument");
+    *out = nullptr;
+    if (!(P->sig_leaf > 0.f) || !std::isfinite(P->sig_leaf) || P->sig_log2_bits < 10 || P->sig_log2_bits > 18 || !(P->radius >= 0.f) || !std::isfinite(P->radius) ||
+        P->min_gap < 1 || P->top_k < 1 || P->top_k > 16 || !(P->min_overlap >= 0.f && P->min_overlap <= 1.f) || P->max_keyframes < 1 || P->max_keyframes > (1 << 20) || P->reserved != 0)
+        return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_create: parameter out of range (see m3dloop_params)");
+    HIPCHK(h, hipSetDevice(h->device));
+    alloc_point();
+    m3dloop* l = new m3dloop();
+    l->h = h; l->P = *P; l->W = 1 << (P->sig_log2_bits - 5);
+    const size_t cap = size_t(P->max_keyframes);
+    hipError_t e = hipMalloc((void**)&l->d_sig, sizeof(uint32_t) * cap * size_t(l->W));
+    if (e == hipSuccess) e = hipMalloc((void**)&l->d_pos, sizeof(float4) * cap);
+    if (e == hipSuccess) e = hipMalloc((void**)&l->d_ov, sizeof(uint32_t) * cap * size_t(LOOP_ROWS));
+    if (e == hipSuccess) e = hipMalloc((void**)&l->d_out, sizeof(uint2) * size_t(LOOP_ROWS) * size_t(P->top_k));
+    if (e == hipSuccess) e = hipEventCreate(&l->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&l->ev1);
+    if (e != hipSuccess) { m3dloop_destroy(l); return fail(h, M3DREG_ERR_HIP, "m3dloop_create", e); }
+    *out = l;
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_clear(m3dloop* l) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_clear", [&]() -> int {
+    if (!l) return M3DREG_ERR_INVALID_ARG;
+    HIPCHK(l->h, hipSetDevice(l->h->device));
+    HIPCHK(l->h, hipStreamSynchronize(l->h->stream));   // (the keyframes' clouds may be released after this call)
+    l->clouds.clear(); l->poses.clear(); l->payloads.clear(); l->has_payload.clear();
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_size(m3dloop* l, size_t* n) {
+    if (!l || !n) return M3DREG_ERR_INVALID_ARG;
+    *n = l->clouds.size();
+    return M3DREG_OK;
+}
+
+int m3dloop_add_keyframe(m3dloop* l, const m3dreg_cloud* cloud, const float T[16], const m3dreg_cloud_desc* payload, int32_t* index) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_add_keyframe", [&]() -> int {
+    if (!l || !cloud || !T) return M3DREG_ERR_INVALID_ARG;
+    m3dreg_handle* h = l->h;
+    if (l->clouds.size() >= size_t(l->P.max_keyframes)) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_add_keyframe: max_keyframes reached");
+    if (cloud->owner && cloud->owner->device != h->device) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_add_keyframe: the cloud lives on another device");
+    for (int k = 0; k < 16; k++) if (!std::isfinite(T[k])) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_add_keyframe: non-finite pose");
+    HIPCHK(h, hipSetDevice(h->device));
+    alloc_point();
+    const int32_t k = int32_t(l->clouds.size());
+    l->clouds.reserve(size_t(k) + 1); l->poses.reserve(16 * (size_t(k) + 1)); l->payloads.reserve(size_t(k) + 1); l->has_payload.reserve(size_t(k) + 1);   // (nothing throws between the pushes below)
+    int rc = loop_sign(l, k, cloud, T);
+    if (rc) return rc;
+    l->clouds.push_back(cloud);
+    l->poses.insert(l->poses.end(), T, T + 16);
+    l->payloads.push_back(payload ? *payload : m3dreg_cloud_desc{});
+    l->has_payload.push_back(payload ? 1 : 0);
+    if (index) *index = k;
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_update_pose(m3dloop* l, int32_t index, const float T[16]) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_update_pose", [&]() -> int {
+    if (!l || !T || index < 0 || size_t(index) >= l->clouds.size()) return M3DREG_ERR_INVALID_ARG;
+    for (int k = 0; k < 16; k++) if (!std::isfinite(T[k])) return fail(l->h, M3DREG_ERR_INVALID_ARG, "m3dloop_update_pose: non-finite pose");
+    HIPCHK(l->h, hipSetDevice(l->h->device));
+    int rc = loop_sign(l, index, l->clouds[size_t(index)], T);
+    if (rc) return rc;
+    std::copy(T, T + 16, l->poses.begin() + 16 * size_t(index));
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_signature(m3dloop* l, int32_t index, uint32_t* words, uint32_t* pop) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_signature", [&]() -> int {
+    if (!l || index < 0 || size_t(index) >= l->clouds.size()) return M3DREG_ERR_INVALID_ARG;
+    m3dreg_handle* h = l->h;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (words) HIPCHK(h, hipMemcpy(words, l->d_sig + size_t(index) * size_t(l->W), sizeof(uint32_t) * size_t(l->W), hipMemcpyDeviceToHost));
+    if (pop) { float4 p; HIPCHK(h, hipMemcpy(&p, l->d_pos + index, sizeof(p), hipMemcpyDeviceToHost)); memcpy(pop, &p.w, 4); }
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_candidates(m3dloop* l, int32_t first, int32_t count, m3dloop_candidate* out, size_t cap, size_t* n_out) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_candidates", [&]() -> int {
+    if (!l || !n_out || (cap && !out)) return M3DREG_ERR_INVALID_ARG;
+    m3dreg_handle* h = l->h;
+    *n_out = 0;
+    const int32_t n = int32_t(l->clouds.size());
+    if (first < 0 || first > n) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_candidates: first row out of range");
+    const int32_t last = (count < 0 || first + count > n) ? n : first + count;
+    l->last_ms = 0.0; l->last_bytes = 0;
+    if (last <= first) return M3DREG_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int K = l->P.top_k;
+    const uint32_t thr_q16 = uint32_t(lrintf(l->P.min_overlap * 65536.0f));
+    std::vector<uint2> res(size_t(last - first) * size_t(K));
+    std::vector<float4> pos(static_cast<size_t>(n), make_float4(0.f, 0.f, 0.f, 0.f));
+    HIPCHK(h, hipEventRecord(l->ev0, h->stream));
+    for (int32_t r0 = first; r0 < last; r0 += LOOP_ROWS) {
+        M3dLoopScoreArgs A{};
+        A.sig = l->d_sig; A.pos = l->d_pos; A.W = l->W; A.row0 = r0; A.n_rows = std::min<int32_t>(LOOP_ROWS, last - r0);
+        A.min_gap = l->P.min_gap; A.r2 = l->P.radius * l->P.radius; A.ov = l->d_ov; A.ov_stride = l->P.max_keyframes;
+        HIPCHK(h, m3d_launch_loop_score(h->stream, A, l->d_out, K, thr_q16));
+        HIPCHK(h, hipMemcpyAsync(res.data() + size_t(r0 - first) * size_t(K), l->d_out, sizeof(uint2) * size_t(A.n_rows) * size_t(K), hipMemcpyDeviceToHost, h->stream));
+        // what the launch pair has to move: every signature it touches once, every score written and read once
+        const long long jmax = std::max<long long>(0, (long long)(r0 + A.n_rows - 1) - A.min_gap + 1);
+        long long cells = 0;
+        for (int32_t i = r0; i < r0 + A.n_rows; i++) cells += std::max<long long>(0, (long long)i - A.min_gap + 1);
+        l->last_bytes += uint64_t(jmax + A.n_rows) * uint64_t(l->W) * 4ull + uint64_t(cells) * 8ull;
+        if (r0 + LOOP_ROWS < last) HIPCHK(h, hipStreamSynchronize(h->stream));   // (d_out / d_ov are re-used by the next chunk)
+    }
+    HIPCHK(h, hipEventRecord(l->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pos.data(), l->d_pos, sizeof(float4) * size_t(n), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, l->ev0, l->ev1) == hipSuccess) l->last_ms = double(ms); }
+    size_t found = 0;
+    for (int32_t i = first; i < last; i++) {
+        for (int k = 0; k < K; k++) {
+            const uint2 e = res[size_t(i - first) * size_t(K) + size_t(k)];
+            if (e.x == 0xFFFFFFFFu) break;
+            if (found < cap) {
+                m3dloop_candidate& c = out[found];
+                const int32_t j = int32_t(e.x);
+                c.source = i; c.target = j; c.overlap = e.y;
+                memcpy(&c.pop_source, &pos[size_t(i)].w, 4); memcpy(&c.pop_target, &pos[size_t(j)].w, 4);
+                const float dx = pos[size_t(i)].x - pos[size_t(j)].x, dy = pos[size_t(i)].y - pos[size_t(j)].y, dz = pos[size_t(i)].z - pos[size_t(j)].z;
+                c.dist2 = std::fmaf(dz, dz, std::fmaf(dy, dy, dx * dx));
+                loop_rel(&l->poses[16 * size_t(j)], &l->poses[16 * size_t(i)], c.init_T);
+            }
+            found++;
+        }
+    }
+    *n_out = found;
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_last_profile(m3dloop* l, double* ms, uint64_t* bytes) {
+    if (!l) return M3DREG_ERR_INVALID_ARG;
+    if (ms) *ms = l->last_ms;
+    if (bytes) *bytes = l->last_bytes;
+    return M3DREG_OK;
+}
+
+int m3dloop_make_pairs(m3dloop* l, const m3dloop_candidate* cands, size_t n, m3dreg_pair* out) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_make_pairs", [&]() -> int {
+    if (!l || (n && (!cands || !out))) return M3DREG_ERR_INVALID_ARG;
+    const int32_t nk = int32_t(l->clouds.size());
+    for (size_t i = 0; i < n; i++) {
+        if (cands[i].source < 0 || cands[i].source >= nk || cands[i].target < 0 || cands[i].target >= nk) return fail(l->h, M3DREG_ERR_INVALID_ARG, "m3dloop_make_pairs: keyframe index out of range");
+        out[i].source = l->clouds[size_t(cands[i].source)];
+        out[i].target = l->clouds[size_t(cands[i].target)];
+        memcpy(out[i].init_T, cands[i].init_T, sizeof(float) * 16);
+    }
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_make_pair_descs(m3dloop* l, const m3dloop_candidate* cands, size_t n, m3dreg_pair_desc* out) {
+    return m3d_guarded((l ? l->h : nullptr), "m3dloop_make_pair_descs", [&]() -> int {
+    if (!l || (n && (!cands || !out))) return M3DREG_ERR_INVALID_ARG;
+    const int32_t nk = int32_t(l->clouds.size());
+    for (size_t i = 0; i < n; i++) {
+        const int32_t s = cands[i].source, t = cands[i].target;
+        if (s < 0 || s >= nk || t < 0 || t >= nk) return fail(l->h, M3DREG_ERR_INVALID_ARG, "m3dloop_make_pair_descs: keyframe index out of range");
+        if (!l->has_payload[size_t(s)] || !l->has_payload[size_t(t)]) return fail(l->h, M3DREG_ERR_INVALID_ARG, "m3dloop_make_pair_descs: a keyframe was added without its payload descriptor");
+        memset(&out[i], 0, sizeof(out[i]));
+        out[i].source = l->payloads[size_t(s)]; out[i].source.source_only = 1;
+        out[i].target = l->payloads[size_t(t)]; out[i].target.source_only = 0;
+        memcpy(out[i].init_T, cands[i].init_T, sizeof(float) * 16);
+        out[i].target_group = t + 1;   // every pair against keyframe t: one device, one upload, one bucketing
+    }
+    return M3DREG_OK;
+    });
+}
+
+int m3dloop_gate(const m3dloop_candidate* cands, const m3dreg_stats* stats, size_t n, int64_t min_corr, double max_rms, uint8_t* accept) {
+    if (n && (!stats || !accept)) return M3DREG_ERR_INVALID_ARG;
+    (void)cands;
+    for (size_t i = 0; i < n; i++)
+        accept[i] = ((stats[i].status == M3DREG_CONVERGED || stats[i].status == M3DREG_MAX_ITERATIONS) && stats[i].n_corr >= min_corr && stats[i].rms <= max_rms) ? 1 : 0;
+    return M3DREG_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------
 int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     return m3d_guarded(h, "m3dreg_profile_enable", [&]() -> int {

@@ -278,3 +278,24 @@ def calibration_sweep(n_seg=480, n_rays=480, true_params=(0.0, 0.03, -0.02, 0.03
         keep = (r > 1.0) & np.isfinite(r)            # the calibration node drops r <= 1 (m3d_calibration_twiddle.cpp:479)
         segs.append(((d_l[keep] * r[keep, None]).astype(np.float32), head.astype(np.float32)))
     return segs
+
+
+def loop_trajectory(n_keyframes=50, per_lap=40, n_azimuth=400, seed=9000, step_noise_deg=0.15, step_noise_m=0.01, self_filter=1.0):
+    """A closed trajectory for the loop-closure candidate generation: the unit drives an ellipse (12 m x 8 m
+    semi-axes) through the room, `per_lap` keyframes per lap, n_keyframes in all — with the defaults a lap and a quarter, so keyframes
+    40 .. 49 stand where 0 .. 9 stood. Returns [(cloud in the sensor frame, T_true, T_odom)]: T_true = sensor -> world, T_odom = the pose a
+    drifting odometry would report (the true steps chained with a small random error each: what the signatures are built from)."""
+    rng = np.random.default_rng(seed)
+    out, T_odo, T_prev = [], None, None
+    for k in range(n_keyframes):
+        a = 2.0 * np.pi * k / per_lap
+        x, y = 12.0 * np.cos(a), 8.0 * np.sin(a)
+        yaw = np.degrees(np.arctan2(8.0 * np.cos(a), -12.0 * np.sin(a)))   # tangent of the ellipse
+        T = sensor_pose(x, y, yaw)
+        if T_odo is None:
+            T_odo = T.copy()
+        else:
+            T_odo = T_odo @ (inv_T(T_prev) @ T) @ random_T(rng, step_noise_deg, step_noise_m)
+        T_prev = T
+        out.append((hdl32_scan(T, n_azimuth, seed + 1 + k, self_filter=self_filter), T, T_odo.copy()))
+    return out

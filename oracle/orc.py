@@ -77,6 +77,18 @@ def _lib(omp=False):
         L.orc_map_points.restype = None
         L.orc_map_insert.argtypes = [vp, f32p, C.c_size_t, f32p]
         L.orc_map_insert.restype = C.c_size_t
+        L.orc_loop_create.argtypes = [C.POINTER(abi.LoopParams)]
+        L.orc_loop_create.restype = vp
+        L.orc_loop_destroy.argtypes = [vp]
+        L.orc_loop_destroy.restype = None
+        L.orc_loop_size.argtypes = [vp]
+        L.orc_loop_add.argtypes = [vp, f32p, C.c_size_t, f32p]
+        L.orc_loop_update.argtypes = [vp, C.c_int, f32p, C.c_size_t, f32p]
+        L.orc_loop_update.restype = None
+        L.orc_loop_signature.argtypes = [vp, C.c_int, u32p, u32p]
+        L.orc_loop_signature.restype = None
+        L.orc_loop_candidates.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.LoopCandidate), C.c_size_t]
+        L.orc_loop_candidates.restype = C.c_size_t
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -311,6 +323,44 @@ class Map:
         out = np.zeros((max(n, 1), 3), np.float32)
         self._L.orc_map_points(self._m, _ptr(out, C.c_float))
         return out[:n]
+
+
+class Loop:
+    """oracle/m3d_loop_oracle.c: loop-closure candidate generation of SURVEY §8 row f4 (keyframes = pose + points; candidates by signature overlap)."""
+
+    def __init__(self, params):
+        self._L = _lib()
+        self.params = params
+        self._l = C.c_void_p(self._L.orc_loop_create(C.byref(params)))
+
+    def __del__(self):
+        try:
+            self._L.orc_loop_destroy(self._l)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.orc_loop_size(self._l))
+
+    def add_keyframe(self, xyz, T):
+        a = np.ascontiguousarray(xyz, np.float32)
+        return int(self._L.orc_loop_add(self._l, _ptr(a, C.c_float), len(a), _ptr(_T16(T), C.c_float)))
+
+    def update_pose(self, k, xyz, T):
+        a = np.ascontiguousarray(xyz, np.float32)
+        self._L.orc_loop_update(self._l, k, _ptr(a, C.c_float), len(a), _ptr(_T16(T), C.c_float))
+
+    def signature(self, k):
+        w = np.zeros(1 << (self.params.sig_log2_bits - 5), np.uint32)
+        pop = C.c_uint32()
+        self._L.orc_loop_signature(self._l, k, _ptr(w, C.c_uint32), C.byref(pop))
+        return w, pop.value
+
+    def candidates(self, first=0, count=-1):
+        cap = max(1, (len(self) if count < 0 else count) * self.params.top_k)
+        arr = (abi.LoopCandidate * cap)()
+        n = int(self._L.orc_loop_candidates(self._l, first, count, arr, cap))
+        return [arr[i] for i in range(n)]
 
 
 # ---- bench.py's cpu_baseline legs: -O3 -march=native builds, compiled on the box that runs them -------------------------------

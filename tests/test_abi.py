@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     txt = open(os.path.join(ROOT, "include", "m3dreg.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(m3d(?:reg|agg|cal|map)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(m3d(?:reg|agg|cal|map|loop)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -37,7 +37,9 @@ def test_struct_layouts_match_header(tmp_path):
               ("m3dreg_stats", abi.Stats, ["status", "iterations", "n_corr", "rms", "last_rot", "last_trans"]),
               ("m3dreg_grid_info", abi.GridInfo, ["n", "n_valid", "n_cells", "dims", "bits", "mn", "mx", "center", "leaf", "inv_leaf",
                                                  "lbound", "has_normals"]),
-              ("m3dreg_pair", abi.Pair, ["source", "target", "init_T"])]
+              ("m3dreg_pair", abi.Pair, ["source", "target", "init_T"]),
+              ("m3dloop_params", abi.LoopParams, ["sig_leaf", "sig_log2_bits", "radius", "min_gap", "top_k", "min_overlap", "max_keyframes", "reserved"]),
+              ("m3dloop_candidate", abi.LoopCandidate, ["source", "target", "overlap", "pop_source", "pop_target", "dist2", "init_T"])]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "m3dreg.h"', 'int main(void){']
     for cname, _, fields in probes:
         src.append(f'printf("%zu", sizeof({cname}));')
