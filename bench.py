@@ -71,7 +71,7 @@ def parse():
                          "a-priori cost estimate (synth.crowdedness of both clouds), the same number to every rank (SURVEY 8d config 4: "
                          "LPT-sharded); consecutive = rank r takes pairs r * B ... r * B + B - 1")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the cpu_baseline 'all cores' legs (0 = every core of the host)")
-    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"],
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5", "loop64"],
                     help="config4 (default, the headline): B loop-closure pairs per GPU per step; config3: the single 100k pair, point-to-plane, leaf 0.1; "
                          "config2: the single 70k pair, point-to-point, leaf 0.2, eps 1e-5 / 30 iterations; config5: 100k live scan against the 2 M-point map, "
                          "leaves 0.4 / 0.2 / 0.1 (own code path: run_config5)")
@@ -88,6 +88,13 @@ def parse():
     ap.add_argument("--batch-chains", type=int, default=None, help="m3dreg_set_batch_chains for every handle (the synchronous call's internal chains: 1 = none, default: the library's)")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
     ap.add_argument("--all-legs", action="store_true", help="also the legs the default run leaves out to stay short (batch16 / batch32 / batch64 with two chains, from_host_converge)")
+    ap.add_argument("--verify-steps", action="store_true",
+                    help="compare EVERY step's poses and statistics (timed steps included) byte for byte with the first result of the same shard; the default run "
+                         "verifies --verify-extra untimed steps of the same schedule right after the timed region instead")
+    ap.add_argument("--verify-extra", type=int, default=64, help="untimed steps of the headline schedule whose results are checked byte for byte after the timed region (0 = none)")
+    ap.add_argument("--rotate-pairs", action="store_true",
+                    help="step k registers shard k mod 8 of the 64 config-4 pairs (the eight LPT shards bench.py --gpus 8 forms) instead of the same 8 pairs every step: "
+                         "64 pairs' payloads resident, inputs no longer repeat from step to step")
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="the block of --steps timed steps is repeated (each block bracketed by barrier + synchronize on both sides, exactly --steps steps) "
                          "until the blocks add up to this much wall time; the MEDIAN block is reported (0 = one block)")
@@ -188,6 +195,8 @@ def main():
     args = parse()
     if args.workload == "config5":
         return run_config5(args)
+    if args.workload == "loop64":
+        return run_loop64(args)
     if args.multi_devices:
         return run_multi(args)
     if (args.gpus > 1 or args.spawn) and "M3D_BENCH_RANK_PROCESS" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -201,7 +210,15 @@ def main():
             time.sleep(300)
         return
     pregen = {}
-    if args.workload == "config4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.pairs_per_gpu >= 16 and args.pair_list is None:
+    if args.rotate_pairs:
+        if args.workload != "config4" or int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.pairs_per_gpu != 8 or args.pair_list is not None or args.from_host:
+            raise SystemExit("--rotate-pairs: the N = 1 config-4 headline with 8 pairs per step and device-resident payloads only")
+        import multiprocessing as mp
+        from mandala_mapping_amd import synth as synth_
+        with mp.get_context("fork").Pool(min(host_cores(), 16)) as pool:
+            got = pool.starmap(synth_.config4_pair, [(i, args.azimuth) for i in range(64)])
+        pregen = dict(enumerate(got))
+    elif args.workload == "config4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.pairs_per_gpu >= 16 and args.pair_list is None:
         # a big batch's clouds are ray-cast by a pool of forked workers BEFORE this process touches the GPU (64 pairs: 20 s of numpy on one core)
         import multiprocessing as mp
         from mandala_mapping_amd import synth as synth_
@@ -276,7 +293,7 @@ def main():
         if args.workload == "config4" and os.path.exists(tab):
             t_ = json.load(open(tab))
             if t_.get("azimuth") == args.azimuth and len(t_["costs"]) >= world * B:
-                costs = t_["costs"][: world * B]
+                costs, _ = sharding.table_costs(t_, world * B)
         if costs is None:   # any other workload: the cost estimate comes from the DEVICE (m3dreg_cloud_density: the bucketing pipeline's own sum of squared
             # voxel populations) — every rank buckets all world * B pairs once, untimed, and reads the same numbers
             generated = {k: gen_pair(k) for k in range(world * B)}
@@ -289,17 +306,34 @@ def main():
         generated = {k: generated[k] for k in pair_ids if k in generated}
     else:
         pair_ids, generated = [rank * B + i for i in range(B)], {}
-    for i in range(B):
-        src, tgt, Tgt = generated[pair_ids[i]] if pair_ids[i] in generated else gen_pair(pair_ids[i])
-        ms, mt = encode_xyz(src), encode_xyz(tgt)
-        ds = torch.frombuffer(bytearray(ms.data), dtype=torch.uint8).to(dev)
-        dt = torch.frombuffer(bytearray(mt.data), dtype=torch.uint8).to(dev)
-        payloads.append((ds, ms.n, dt, mt.n))
-        host_msgs += [ms, mt]
-        gts.append(Tgt)
-        inits.append(init_of(Tgt))
-        if rank == 0 and i < 8:
-            host_pairs.append((src, tgt))
+    # shards[s] = the pairs step k registers when k % len(shards) == s: ONE shard (this rank's pairs) unless --rotate-pairs, which cycles through the
+    # eight LPT shards `bench.py --gpus 8` forms out of config 4's 64 pairs
+    shard_ids = [list(pair_ids)]
+    if args.rotate_pairs:
+        t_ = json.load(open(os.path.join(ROOT, "mandala_mapping_amd", "config4_costs.json")))
+        if t_.get("azimuth") == args.azimuth:
+            c64, shard_source = sharding.table_costs(t_, 64)
+            shard_ids = sharding.lpt_assign(c64, 8, capacity=8)
+        else:
+            shard_ids, shard_source = [list(range(8 * s_, 8 * s_ + 8)) for s_ in range(8)], "consecutive (no cost table for this azimuth)"
+        pair_ids = shard_ids[0]
+    shard_payloads, shard_gts = [], []
+    for si, ids in enumerate(shard_ids + ([list(range(B))] if args.rotate_pairs else [])):   # (--rotate-pairs: pairs 0 .. 7, the N = 1 line's own workload, as a ninth list: timed beside the shards, never part of the rotation)
+        pl_, gt_ = [], []
+        for i in range(B):
+            src, tgt, Tgt = generated[ids[i]] if ids[i] in generated else gen_pair(ids[i])
+            ms, mt = encode_xyz(src), encode_xyz(tgt)
+            ds = torch.frombuffer(bytearray(ms.data), dtype=torch.uint8).to(dev)
+            dt = torch.frombuffer(bytearray(mt.data), dtype=torch.uint8).to(dev)
+            pl_.append((ds, ms.n, dt, mt.n))
+            gt_.append(Tgt)
+            if si == 0:
+                host_msgs += [ms, mt]
+                inits.append(init_of(Tgt))
+                if rank == 0 and i < 8:
+                    host_pairs.append((src, tgt))
+        shard_payloads.append(pl_); shard_gts.append(gt_)
+    payloads, gts = shard_payloads[0], shard_gts[0]
     torch.cuda.synchronize()
     if args.from_host and not args.pageable:   # the payloads a producer hands over live in pinned memory: the copies are asynchronous DMA, not staged
         pinned_views = [np.frombuffer(m.data, np.uint8) for m in host_msgs]
@@ -309,25 +343,44 @@ def main():
 
     last = {}
 
-    def make_clouds(r):
+    n_rot = len(shard_ids)
+    shard_items = []
+    for pl_ in shard_payloads:
+        items = []
+        for ds, ns, dt, nt in pl_:
+            items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
+        shard_items.append(items)
+
+    def make_clouds(r, shard=0):
         """decode + AABB + bucketing + normals of this rank's 2B clouds, one batched pipeline on r's stream"""
         if args.from_host:
             cl = r.clouds(host_msgs, wait=False, source_only=[True, False] * B)   # host buffers (they outlive the step) cross PCIe inside the timed region
         else:
-            items = []
-            for ds, ns, dt, nt in payloads:
-                items += [(ds.data_ptr(), ns), (dt.data_ptr(), nt)]
-            cl = r.clouds_from_device(items, wait=False, source_only=[True, False] * B)   # no host synchronisation anywhere in a step's chain; sources: no normals
-        return [(cl[2 * i], cl[2 * i + 1]) for i in range(len(payloads))]
+            cl = r.clouds_from_device(shard_items[shard], wait=False, source_only=[True, False] * B)   # no host synchronisation anywhere in a step's chain; sources: no normals
+        return [(cl[2 * i], cl[2 * i + 1]) for i in range(B)]
 
-    def finish(T, st, clouds):
+    # --verify-steps / the untimed verification leg: every step's poses + statistics against the FIRST result of the same shard, byte for byte
+    verify = {"on": bool(args.verify_steps), "ref": {}, "checked": 0, "mismatches": 0, "first_bad": None}
+
+    def check_step(idx, shard, T, st):
+        sig = np.asarray(T, np.float64).tobytes() + b"".join(bytes(x) for x in st)
+        ref = verify["ref"].setdefault(shard, sig)
+        verify["checked"] += 1
+        if sig != ref:
+            verify["mismatches"] += 1
+            if verify["first_bad"] is None:
+                verify["first_bad"] = {"step": int(idx), "shard": int(shard)}
+
+    def finish(T, st, clouds, idx=0, shard=0):
+        if verify["on"]:
+            check_step(idx, shard, T, st)
         if world > 1:   # the only collective of the path: one all_gather of poses + status per step (RCCL over xGMI).
             # It is enqueued here and read one step later (or at the end of the timed region): the ranks exchange every
             # step's results without falling into lock-step at every step.
             ticket = sharding.gather_results_start(pair_ids, T, [x.status for x in st], world * B, dist, cdev)
             drain_gather()
             last["pending_gather"] = ticket
-        last["T"], last["st"] = T, st
+        last["T"], last["st"], last["shard"] = T, st, shard
 
     def drain_gather():
         if last.get("pending_gather") is not None:
@@ -343,10 +396,15 @@ def main():
         for r_ in regs:
             r_.set_batch_chains(args.batch_chains)
 
+    force_shard = [None]   # per-shard timing of --rotate-pairs: every step registers this shard
+
+    def shard_of(i):
+        return force_shard[0] if force_shard[0] is not None else i % n_rot
+
     def enqueue(i):
         r = regs[i % len(regs)]
         ta = time.perf_counter()
-        clouds = make_clouds(bregs[i % len(bregs)])
+        clouds = make_clouds(bregs[i % len(bregs)], shard_of(i))
         tb = time.perf_counter()
         arr = r._pairs([(s_, t_, inits[j]) for j, (s_, t_) in enumerate(clouds)])
         if serial_calls:   # a serial caller's call: the synchronous m3dreg_align_batch (which spreads a batch over internal chains: include/m3dreg.h)
@@ -369,7 +427,7 @@ def main():
             ta = time.perf_counter()
             T, st = sync_result[0] if serial_calls else regs[idx % len(regs)].batch_wait(B)
             host_log.append(("wait", idx, 1e3 * (time.perf_counter() - ta), 0.0))
-            finish(T, st, clouds)
+            finish(T, st, clouds, idx, shard_of(idx))
             if not (keep_clouds and i == k - 1):
                 for s_, t_ in clouds:
                     s_.free(); t_.free()
@@ -443,6 +501,41 @@ def main():
         g_, h_ = r.profile_read(4, reset=True)     # ALL iterations of a batch as they ship (fused late launches included): iterations, ms
         launches, kern_ms, iters_timed, iter_ms, buck_n, buck_ms = launches + a, kern_ms + b, iters_timed + c, iter_ms + d, buck_n + e_, buck_ms + f_
         chain_n, chain_ms = chain_n + g_, chain_ms + h_
+    # ---- untimed: the SAME schedule (handles, streams, queue depth, event brackets, recycled blocks), every step's 8 poses + statistics compared byte
+    # for byte with the first result of its shard. The timed region keeps only its last step's poses (checked against ground truth below); this
+    # leg is what says that the pipelined schedule returns the same bits step after step (tests/test_gpu_pipelined.py holds it against the single-handle result).
+    if args.verify_extra > 0:
+        was = verify["on"]
+        verify["on"] = True
+        run_steps(args.verify_extra)
+        torch.cuda.synchronize()
+        verify["on"] = was
+    if verify["mismatches"]:
+        print(f"[bench] VERIFY FAILED: {verify['mismatches']} of {verify['checked']} steps returned other bits than the first step of their shard (first: {verify['first_bad']})", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    scale_ceiling = None
+    if args.rotate_pairs:
+        # every LPT shard of the N = 8 job as the whole workload of this one GPU, same schedule, back to back on this box; and pairs 0 .. 7, what the N = 1 line runs.
+        # At N = 8 a step of the job lasts as long as its slowest shard's: value(8) <= 64 / max_s t_s, value(1) = 8 / t_1.
+        per = []
+        for sh in range(len(shard_items)):
+            force_shard[0] = sh
+            run_steps(len(regs))
+            torch.cuda.synchronize()
+            ts_ = []
+            for _ in range(3):
+                t0 = time.perf_counter(); run_steps(K); torch.cuda.synchronize(); ts_.append((time.perf_counter() - t0) / K)
+            per.append(1e3 * sorted(ts_)[1])
+        force_shard[0] = None
+        t_sh, t_1 = per[:n_rot], per[n_rot]
+        cm = [sum(c64[k] for k in ids) for ids in shard_ids] if t_.get("azimuth") == args.azimuth else None
+        scale_ceiling = {"status": "UNMEASURED on 8 GPUs: one GPU ran every shard in turn", "per_shard_ms_per_step": t_sh, "n1_workload_ms_per_step": t_1,
+                         "n8_over_n1_measured_shards": 8.0 * t_1 / max(t_sh), "balance_mean_over_max": sum(t_sh) / len(t_sh) / max(t_sh),
+                         "n8_over_n1_cost_model": (8.0 * (sum(cm) / len(cm)) / max(cm)) if cm else None,
+                         "shards": [[int(k) for k in ids] for ids in shard_ids], "shard_source": shard_source}
+    for r in regs:
+        for w_ in (0, 1, 2, 4):
+            r.profile_read(w_, reset=True)
         r.profile_enable(False)
     # After the timed region, untimed: the same kernel with NOTHING else on the GPU (one step, one handle, every launch bracketed).
     # With several chains sharing the GPU a launch takes longer although more launches complete per second; this is the kernel's own
@@ -489,21 +582,28 @@ def main():
             except Exception as ex:   # diagnostics only: never fail the bench line over them
                 gather_model = {"error": repr(ex)}
         del c_
-        last["T"], last["st"] = last_T, last_st
+        last["T"], last["st"] = last_T, last_st   # (last["shard"] still names the shard of that step)
     elapsed = sorted(blocks)[len(blocks) // 2]   # the median block (already the max over ranks)
     per_rank = None
     if world > 1:   # every rank's own block times beside the max-over-ranks figure: the loss to the slowest shard is visible in the line itself
         mine = {"rank": rank, "pairs": [int(x) for x in pair_ids], "own_work_ms_median": 1e3 * sorted(blocks_local)[len(blocks_local) // 2],
                 "own_work_ms_min": 1e3 * min(blocks_local), "own_work_ms_max": 1e3 * max(blocks_local)}
-        try:   # (diagnostics: a failure here must not cost the run its line; every rank takes the same path — the call is collective)
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine)
-            per_rank = gathered
+        try:   # (diagnostics: a failure here must not cost the run its line. A fixed-size float64 tensor through the SAME collective the timed region used every step —
+            # all_gather_object pickles through a second code path (byte tensors, size exchange) that has never run on this fabric)
+            rec = torch.full((4 + 16,), -1.0, dtype=torch.float64)
+            rec[0], rec[1], rec[2], rec[3] = rank, mine["own_work_ms_median"], mine["own_work_ms_min"], mine["own_work_ms_max"]
+            for q_, pid in enumerate(mine["pairs"][:16]):
+                rec[4 + q_] = pid
+            rec = rec.to(cdev) if cdev is not None else rec
+            allr = torch.empty((world * rec.numel(),), dtype=torch.float64, device=rec.device)
+            dist.all_gather_into_tensor(allr, rec)
+            allr = allr.cpu().numpy().reshape(world, -1)
+            per_rank = [{"rank": int(a[0]), "pairs": [int(x) for x in a[4:] if x >= 0], "own_work_ms_median": float(a[1]), "own_work_ms_min": float(a[2]), "own_work_ms_max": float(a[3])} for a in allr]
         except Exception as ex:
-            per_rank = [dict(mine, error="all_gather_object failed: " + repr(ex)[:120])]
+            per_rank = [dict(mine, error="per-rank gather failed: " + repr(ex)[:120])]
 
     # sanity of the timed work: poses against the generator's ground truth
-    errs = [synth.pose_error(last["T"][i], gts[i]) for i in range(B)]
+    errs = [synth.pose_error(last["T"][i], shard_gts[last.get("shard", 0)][i]) for i in range(B)]
     max_rot, max_tr = max(e[0] for e in errs), max(e[1] for e in errs)
 
     if rank == 0:
@@ -556,6 +656,8 @@ def main():
                                    ("point-to-point, leaves 0.8 / 0.4 / 0.2 m, eps 1e-5 / at most 30 + 30 + 150 iterations, " if args.workload == "config2" else
                                     f"point-to-plane, leaf 0.1 m, {args.iters} " + ("iterations at most (eps 1e-5), " if args.converge else "fixed iterations, ")) +
                                    "decode of both clouds, sort of the source (m3dreg_cloud_desc.source_only), bucketing + tile images + normals of the target inside the timed region",
+                       "payload": "host (pinned PointCloud2 buffers cross PCIe inside the timed region)" if args.from_host else "hbm-resident",
+                       "pipelining": ("none: one synchronous call per step" if serial_calls else f"caller-side: {len(regs)} handles / {D} streams" + (", the same 8 pairs every step" if n_rot == 1 else f", step k registers shard k mod {n_rot}")),
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step",
                        "overlap": ((("none (serial steps, synchronous calls" + ("" if args.no_latency_mode else ", m3dreg_set_latency_mode on: the caller says its batches have the GPU to themselves") + ")") if serial_calls else "none (serial steps, one chain)") if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
@@ -566,6 +668,9 @@ def main():
             "ms_per_icp_iter_batch_bracketed_chain": iter_ms / max(1, iters_timed),
             "ms_bucketing_batch": buck_ms / max(1, buck_n), "ms_bucketing_batch_alone": alone_bucket_ms,
             "max_rot_err_deg": max_rot, "max_trans_err_m": max_tr,
+            "verify": {"steps_checked": verify["checked"], "mismatches": verify["mismatches"], "timed_steps_checked": bool(args.verify_steps),
+                       "what": "poses + statistics of every checked step == the first result of the same shard, byte for byte, under the timed region's schedule"},
+            "scale_ceiling": scale_ceiling,
             "iterations_executed_pair0": int(last["st"][0].iterations),
             # roofline_definition_version 2 (rounds 3-4): frac = the correspondence step INSIDE the timed region (what the timed region ran, several chains
             # sharing the GPU, sampled brackets); `alone` = the same bracket with nothing else on the GPU; `iteration` = a whole linearisation of the
@@ -603,6 +708,14 @@ def main():
             out["data"] = "synthetic (host PointCloud2 buffers: PCIe-inclusive, not the headline configuration)"
         if world == 1 and not args.no_extra and not args.no_cpu_baseline and args.workload == "config4" and not (args.from_host or args.converge):
             out["legs"] = extra_legs(args)
+            # what a caller gets, beside the pipelined headline: one synchronous call at a time, host payloads, one 64-pair call, rotating inputs
+            for key, leg in (("value_serial", "serial"), ("value_from_host", "from_host"), ("value_batch64", "batch64_one_chain"), ("value_rotate_pairs", "rotate_pairs")):
+                v_ = (out["legs"].get(leg) or {}).get("value")
+                if v_ is not None:
+                    out[key] = v_
+            sc = (out["legs"].get("rotate_pairs") or {}).get("scale_ceiling")
+            if sc is not None:
+                out["scale_ceiling"] = sc
         emit(out)
     if world > 1:
         dist.barrier()
@@ -633,9 +746,14 @@ def compact_line(full):
     for k, cap in (("metric", 120), ("unit", 24), ("scaling", 16), ("dtype", 48), ("data", 100)):
         if isinstance(line.get(k), str):
             line[k] = line[k][:cap]
+    line.update(pick(full, ("value_serial", "value_from_host", "value_batch64", "value_rotate_pairs")))
+    if isinstance(full.get("verify"), dict):
+        line["verify"] = pick(full["verify"], ("steps_checked", "mismatches", "timed_steps_checked"))
+    if isinstance(full.get("scale_ceiling"), dict):
+        line["scale_ceiling"] = pick(full["scale_ceiling"], ("n8_over_n1_measured_shards", "n8_over_n1_cost_model", "status"))
     cfg = full.get("config") or {}
-    line["config"] = pick(cfg, ("workload", "pairs_per_gpu", "points_per_cloud", "iterations", "parallelism", "overlap"))
-    for k in ("workload", "parallelism", "overlap"):
+    line["config"] = pick(cfg, ("workload", "payload", "pipelining", "pairs_per_gpu", "points_per_cloud", "iterations", "parallelism", "overlap"))
+    for k in ("workload", "payload", "pipelining", "parallelism", "overlap"):
         if isinstance(line["config"].get(k), str):
             line["config"][k] = line["config"][k][:480 if k == "workload" else 120]
     line.update(pick(full, ("ms_per_icp_iter_batch", "ms_per_icp_iter_per_pair", "ms_per_icp_iter_batch_alone", "ms_bucketing_batch", "ms_bucketing_batch_alone",
@@ -681,7 +799,7 @@ def compact_line(full):
             if not isinstance(d, dict) or "error" in d:
                 legs[name] = {"error": str((d or {}).get("error", "?"))[-80:]} if isinstance(d, dict) else None
                 continue
-            e = pick(d, ("value", "ms_per_step", "registration_ms", "bucket_map_ms"))
+            e = pick(d, ("value", "ms_per_step", "registration_ms", "bucket_map_ms", "generation_ms", "pairs", "accepted", "frac"))
             al = ((d.get("roofline") or {}).get("alone") or {}).get("frac")
             if al is not None:
                 e["frac_alone"] = al
@@ -781,6 +899,11 @@ def extra_legs(args):
         # the big-batch regime: B pairs per step in ONE launch chain — 64 = ALL of config 4 on one GPU (pairs 0 ... 63: also the ones next to
         # obstacles, which rank 0's 8-pair shard does not hold) — with one chain (the kernels' own throughput: nothing else on the GPU) and with two in flight
         "batch64_one_chain": ["--pairs-per-gpu", "64", "--inflight", "1", "--queue-depth", "1", "--steps", "6", "--warmup", "2"],
+        # the headline's schedule with the inputs changing under it: step k registers LPT shard k mod 8 of the 64 pairs (every step checked byte for byte against the
+        # first result of its shard), then every shard as the whole workload in turn: the ceiling of the 8-GPU line (scale_ceiling)
+        "rotate_pairs": ["--rotate-pairs", "--verify-steps", "--steps", "24", "--warmup", "8"],
+        # f4: loop-closure candidate generation + the 64-pair batch it emits, end to end (run_loop64)
+        "loop64": ["--workload", "loop64", "--steps", "4", "--warmup", "1"],
     }
     if args.all_legs:   # not in the driver's command: its run must stay well under a minute
         runs.update({
@@ -806,7 +929,8 @@ def extra_legs(args):
             keep["overlap"] = d.get("config", {}).get("overlap")
             if "roofline" in d:
                 keep["roofline"] = {k: d["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "unit", "alone", "iteration")}
-            for k in ("levels", "map_points", "bucket_map_ms", "bucket_map_wall_ms", "registration_ms", "blocks"):
+            for k in ("levels", "map_points", "bucket_map_ms", "bucket_map_wall_ms", "registration_ms", "blocks", "scale_ceiling", "verify", "generation_ms", "pairs", "accepted", "keyframes",
+                      "candidates_per_s", "batch_ms"):
                 if k in d:
                     keep[k] = d[k]
             legs[name] = keep
@@ -890,6 +1014,74 @@ def run_config5(args):
         "max_rot_err_deg": rot, "max_trans_err_m": tra, "iterations_executed_pair0": int(st.iterations),
         "roofline": {"bound": "hbm", "kernel": "k_nn_iter + k_nn_tiles, finest level", "achieved": fin["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": fin["frac"], "avg_launch_ms": fin["ms_correspondence_step"], "algorithmic_bytes_per_launch": fin["algorithmic_bytes_per_iteration"], "traffic": None},
+    })
+
+
+def run_loop64(args):
+    """SURVEY §8 row f4, second half, end to end: a closed trajectory of 80 full-size keyframes (two laps of synth.loop_trajectory's ellipse,
+    100 000 rays per sweep, resident in HBM as bucketed clouds with their signatures — what a node has after driving it); a step = candidate generation for
+    the second lap's keyframes (m3dloop_candidates: one scoring pass over the signature database, top-2 per keyframe) -> the first 64 candidates as
+    m3dreg_pair[] (m3dloop_make_pairs) -> ONE m3dreg_align_batch (the headline's parameters: point-to-plane, leaf 0.1 m, 20 fixed iterations) -> m3dloop_gate.
+    value = 64 registrations / (generation + batch). Also: the device time and the bytes of the scoring pass for the WHOLE table (all 80 rows)."""
+    import multiprocessing as mp
+    from mandala_mapping_amd import synth
+    poses = synth.loop_poses(n_keyframes=80, per_lap=40, seed=9300)
+    with mp.get_context("fork").Pool(min(host_cores(), 16)) as pool:   # (before this process touches the GPU)
+        scans = pool.starmap(synth.hdl32_scan, [(T, args.azimuth, sd, 0.02, 0.4, 100.0, 1.0) for T, _, sd in poses])
+    from mandala_mapping_amd import abi, binding
+    params = abi.Params.make(leaf=0.1, iterations=args.iters, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    R = binding.Registrar(params)
+    R.set_latency_mode(True)
+    P = abi.LoopParams.make(sig_leaf=2.0, sig_log2_bits=16, radius=3.0, min_gap=20, top_k=2, min_overlap=0.5, max_keyframes=128)
+    G = binding.LoopCloser(R, P)
+    clouds = []
+    for i in range(0, len(scans), 16):
+        clouds += R.clouds(scans[i:i + 16])
+    t0 = time.perf_counter()
+    for c, (_, T_odo, _) in zip(clouds, poses):
+        G.add_keyframe(c, T_odo)
+    R.synchronize()
+    sign_ms = 1e3 * (time.perf_counter() - t0) / len(clouds)
+    NP = 64
+    gen, bat, acc_n = [], [], 0
+    worst = (0.0, 0.0)
+    for it in range(args.warmup + args.steps):
+        R.synchronize()
+        t0 = time.perf_counter()
+        cands = G.candidates(40, -1)
+        if len(cands) < NP:
+            raise SystemExit(f"loop64: only {len(cands)} candidates")
+        sel = (abi.LoopCandidate * NP)(*[cands[i] for i in range(NP)])
+        pairs = G.pairs(sel)
+        t1 = time.perf_counter()
+        T, st = R.align_batch_arr(pairs, NP)
+        acc = G.gate(sel, st, min_corr=20000, max_rms=0.05)
+        t2 = time.perf_counter()
+        if it >= args.warmup:
+            gen.append(1e3 * (t1 - t0)); bat.append(1e3 * (t2 - t1))
+        acc_n = sum(acc)
+        for i in range(NP):
+            if acc[i]:
+                e = synth.pose_error(T[i], synth.inv_T(poses[sel[i].target][0]) @ poses[sel[i].source][0])
+                worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+    G.candidates(0, -1)                                  # the whole table: every row against every older keyframe
+    all_ms, all_bytes = G.last_profile()
+    G.candidates(len(clouds) - 1, 1)                     # the node's call: the newest keyframe against the database
+    row_ms, row_bytes = G.last_profile()
+    gen_ms, bat_ms = sorted(gen)[len(gen) // 2], sorted(bat)[len(bat) // 2]
+    ach = all_bytes / (all_ms / 1e3) / 1e9 if all_ms > 0 else 0.0
+    emit({
+        "metric": "loop-closure registrations/sec, candidate generation included (64 pairs of 100k-pt keyframes, point-to-plane, 0.1 m voxel NN)",
+        "value": NP / ((gen_ms + bat_ms) / 1e3), "unit": "registrations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": gen_ms + bat_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (int64 fixed-point sums, f64 solve); u32 bitmaps", "data": "synthetic",
+        "config": {"workload": f"f4 loop closure: {len(clouds)} keyframes x {args.azimuth * 32} rays on a closed two-lap trajectory, resident in HBM; per step: m3dloop_candidates for rows 40.. "
+                               f"(top-2, radius 3 m, gap 20) -> first {NP} candidates -> m3dloop_make_pairs -> one synchronous m3dreg_align_batch ({args.iters} fixed iterations) -> m3dloop_gate",
+                   "payload": "hbm-resident", "pipelining": "none: synchronous calls"},
+        "keyframes": len(clouds), "pairs": NP, "accepted": int(acc_n), "generation_ms": gen_ms, "batch_ms": bat_ms, "signature_ms_per_keyframe": sign_ms,
+        "max_rot_err_deg": worst[0], "max_trans_err_m": worst[1],
+        "roofline": {"bound": "hbm", "kernel": "k_loop_score + k_loop_topk, all 80 rows", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "avg_launch_ms": all_ms, "algorithmic_bytes_per_launch": int(all_bytes), "traffic": None,
+                     "newest_row": {"ms": row_ms, "bytes": int(row_bytes)}},
     })
 
 

@@ -311,6 +311,9 @@ int m3dagg_status(m3dagg* a, double* progress, int* ready, double* angle, size_t
  * restarts the aggregator (clearPointCloud :108-114; the node is re-armed by requestCallback :224-229). */
 int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out);
 int m3dagg_restart(m3dagg* a);                       /* requestCallback (:224-229) */
+/* (ABI 8) automatic != 0 (default): m3dagg_take_cloud re-arms the aggregator itself; 0: it leaves the aggregator idle — messages are ignored (:55), progress
+ * reads -1 (:121) — until m3dagg_restart, exactly like the reference's node between a published cloud and the next ~request (:211, :224-229). */
+int m3dagg_set_rearm(m3dagg* a, int automatic);
 int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out);   /* tests: 16 bytes per point */
 
 /* ---- calibration cost on the device ------------------------------------------

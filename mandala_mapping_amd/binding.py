@@ -30,7 +30,7 @@ EXPORTS = [
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
     "m3dreg_cloud_create_pc2", "m3dreg_cloud_density",
-    "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_set_scan_trig", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
+    "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_set_scan_trig", "m3dagg_set_rearm", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
     "m3dagg_download",
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
@@ -105,6 +105,7 @@ def lib():
     L.m3dagg_add_cloud.argtypes = [vp, vp, sz, sz, sz, sz, sz, f64p]
     L.m3dagg_add_scan.argtypes = [vp, f32p, sz, C.c_float, C.c_float, f64p]
     L.m3dagg_set_scan_trig.argtypes = [vp, C.c_int]
+    L.m3dagg_set_rearm.argtypes = [vp, C.c_int]
     L.m3dagg_status.argtypes = [vp, f64p, C.POINTER(C.c_int), f64p, C.POINTER(sz)]
     L.m3dagg_take_cloud.argtypes = [vp, C.POINTER(vp)]
     L.m3dagg_restart.argtypes = [vp]
@@ -570,6 +571,10 @@ class Aggregator:
         """which cos / sin m3d_aggregator.cpp:281-282 resolves to: False (default) = double cos(double), True = the float overload"""
         self._reg._check(lib().m3dagg_set_scan_trig(self._a, int(bool(float_overload))), "m3dagg_set_scan_trig")
 
+    def set_rearm(self, automatic: bool):
+        """False: take_cloud leaves the aggregator idle until restart(), like the reference's node between a published cloud and the next ~request"""
+        self._reg._check(lib().m3dagg_set_rearm(self._a, int(bool(automatic))), "m3dagg_set_rearm")
+
     def add_scan(self, ranges, angle_min, angle_increment, tf7):
         r = np.ascontiguousarray(ranges, np.float32)
         t = np.asarray(tf7, np.float64)
@@ -782,6 +787,19 @@ class Calibrator:
         return p, err.value, ev.value
 
 
+def _mul4_f32(A, B):
+    """A * B in float, the sums in the order ros/gpu_6dslam_node.cpp forms them (s = 0; s += A[r][k] * B[k][c], k = 0 .. 3)"""
+    A32, B32 = np.asarray(A, np.float64).astype(np.float32), np.asarray(B, np.float64).astype(np.float32)
+    out = np.zeros((4, 4), np.float32)
+    for c in range(4):
+        for r in range(4):
+            acc = np.float32(0.0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(A32[r, k] * B32[k, c]))
+            out[r, c] = acc
+    return out.astype(np.float64)
+
+
 class Gpu6dSlamNode:
     """Host-side mirror of the node the reference launches as `gpu_6dslam_node`
     (m3d_husky_bringup.launch:13): it receives the aggregator's clouds one at a time (queue depth 1,
@@ -789,21 +807,55 @@ class Gpu6dSlamNode:
     into an odometry estimate. The ROS wiring itself (subscriber, tf broadcaster) is the source-only
     shim in ros/gpu_6dslam_node.cpp; this class is what tests and bench drive."""
 
-    def __init__(self, params=None, device=0, mode="scan_to_scan", map_leaf=0.05, map_capacity=1 << 22):
-        """mode: "scan_to_scan" (every sweep against the previous one, poses chained) or "scan_to_map" (every sweep against the
-        voxel-deduplicated map of all earlier sweeps, kept in HBM: SURVEY §8 row f4)."""
+    def __init__(self, params=None, device=0, mode="scan_to_scan", map_leaf=0.05, map_capacity=1 << 22, loop_params=None, loop_min_corr=2000,
+                 loop_max_rms=0.05, aggregate_on_device=False, bbox=(1.0, -1.0, 1.0, -1.0, 1.0, -1.0), aggregate_capacity=1 << 21, scan_trig_float=False):
+        """mode: "scan_to_scan" (every sweep against the previous one, poses chained), "scan_to_map" (every sweep against the
+        voxel-deduplicated map of all earlier sweeps, kept in HBM: SURVEY §8 row f4) or "slam" (scan-to-scan odometry, every registered sweep a
+        keyframe, loop-closure candidates of each new keyframe registered in one batch: self.closures).
+        aggregate_on_device: the node takes the aggregator's INPUTS (on_scan / on_laser_cloud with the tf of each message) and aggregates on the
+        device: sweeps are born in HBM."""
         self.reg = Registrar(params, device)
+        self.reg.set_latency_mode(True)
         self.mode = mode
         self.pose = np.eye(4)          # pose of the latest cloud in the frame of the first
         self.last_delta = np.eye(4)    # constant-velocity prior for the next registration
         self._prev = None              # scan_to_scan: the previous sweep, already bucketed: target of the next registration
         self._map = Map(self.reg, map_leaf, map_capacity) if mode == "scan_to_map" else None
+        self._loop = LoopCloser(self.reg, loop_params) if mode == "slam" else None
+        self._gate = (loop_min_corr, loop_max_rms)
+        self.keyframes = []            # slam: (Cloud, pose) of every keyframe
+        self.closures = []             # slam: (source, target, T source -> target, Stats) of every accepted loop closure
+        self._agg = Aggregator(self.reg, bbox, aggregate_capacity) if aggregate_on_device else None
+        if self._agg is not None:
+            self._agg.set_rearm(False)      # like the reference's node: idle after a sweep until ~request
+            if scan_trig_float:
+                self._agg.set_scan_trig(True)
         self.history = []
 
     def on_cloud(self, msg: PointCloud2):
         """Topic callback for `/m3d_test/aggregator/cloud`. Returns (pose 4x4, Stats or None). Like the shim, the message
         crosses the ABI with its own field table and every sweep is bucketed once."""
-        cur = self.reg.cloud_pc2(msg, source_only=self._map is not None)   # scan-to-map: a sweep is only ever a source and a map insert
+        return self.on_sweep(self.reg.cloud_pc2(msg, source_only=self._map is not None))   # scan-to-map: a sweep is only ever a source and a map insert
+
+    # ---- aggregate_on_device: the aggregator's callbacks (m3d_aggregator.cpp:231-288), the sweep never leaves HBM ------------------------------
+    def on_scan(self, ranges, angle_min, angle_increment, tf7):
+        self._agg.add_scan(ranges, angle_min, angle_increment, tf7)
+        return self._after_message()
+
+    def on_laser_cloud(self, msg: PointCloud2, tf7):
+        self._agg.add_cloud(msg, tf7)
+        return self._after_message()
+
+    def on_request(self):
+        self._agg.restart()
+
+    def _after_message(self):
+        if not self._agg.status()["ready"]:
+            return None
+        return self.on_sweep(self._agg.take_cloud())
+
+    # ---- one sweep, bucketed and resident ------------------------------------------------------------------------------------------------------------
+    def on_sweep(self, cur: Cloud):
         if self._map is not None:
             if len(self._map) == 0:
                 self._map.insert(cur, self.pose)
@@ -819,12 +871,34 @@ class Gpu6dSlamNode:
             return self.pose.copy(), st
         if self._prev is None:
             self._prev = cur
+            if self._loop is not None:
+                self._add_keyframe(cur)
             self.history.append((self.pose.copy(), None))
             return self.pose.copy(), None
         T, st = self.reg.align(cur, self._prev, self.last_delta)
         if st.status in (abi.CONVERGED, abi.MAX_ITERATIONS):
             self.last_delta = T
-            self.pose = self.pose @ T
+            self.pose = _mul4_f32(self.pose, T)   # (float, operation for operation like the shim's pose_: the keyframes' signatures are built from these bits)
+            if self._loop is not None:
+                self._add_keyframe(cur)
+        elif self._loop is not None:                         # slam: a sweep the odometry could not place is no keyframe
+            self.history.append((self.pose.copy(), st))
+            return self.pose.copy(), st
         self._prev = cur
         self.history.append((self.pose.copy(), st))
         return self.pose.copy(), st
+
+    def _add_keyframe(self, cur: Cloud):
+        k = self._loop.add_keyframe(cur, self.pose)
+        self.keyframes.append((cur, self.pose.copy()))
+        cands = self._loop.candidates(k, 1)
+        n = len(cands)
+        if n == 0:
+            return
+        out = np.zeros((n, 16), np.float32)
+        st = (abi.Stats * n)()
+        self.reg._check(lib().m3dreg_align_batch(self.reg._h, self._loop.pairs(cands), n, _ptr(out, C.c_float), st), "align_batch")
+        acc = LoopCloser.gate(cands, list(st), *self._gate)
+        for i in range(n):
+            if acc[i]:
+                self.closures.append((cands[i].source, cands[i].target, colmajor16_to_T(out[i]), st[i]))

@@ -1350,6 +1350,7 @@ struct m3dagg {
     uint8_t* d_stage = nullptr;    // staged message payload
     size_t capacity = 0, stage_bytes = 0, blocks_cap = 0;
     int scan_trig_float = 0;       // m3dagg_set_scan_trig: 0 = cos(double) (default), 1 = the float overload
+    bool auto_rearm = true;        // m3dagg_set_rearm: m3dagg_take_cloud re-arms the aggregator itself (default) / leaves it idle until m3dagg_restart, like the reference's node
 };
 
 namespace {
@@ -1531,8 +1532,16 @@ int m3dagg_take_cloud(m3dagg* a, m3dreg_cloud** out) {
     if (n == 0) return fail(a->h, M3DREG_ERR_EMPTY_CLOUD, "m3dagg_take_cloud: nothing aggregated");
     rc = m3dreg_cloud_create(a->h, a->d_pts, n, 16, 0, 4, 8, 1, out);   // bucketed in place: no PCIe transfer of the sweep
     if (rc) return rc;
-    return m3dagg_restart(a);
+    rc = m3dagg_restart(a);
+    if (rc == M3DREG_OK && !a->auto_rearm) { a->creating = false; a->first_scan = false; }   // clearPointCloud (:108-114): idle until the next request (:224-229)
+    return rc;
     });
+}
+
+int m3dagg_set_rearm(m3dagg* a, int automatic) {
+    if (!a) return M3DREG_ERR_INVALID_ARG;
+    a->auto_rearm = automatic != 0;
+    return M3DREG_OK;
 }
 
 int m3dagg_download(m3dagg* a, float* xyzw, size_t cap_points, size_t* n_out) {

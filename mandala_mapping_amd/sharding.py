@@ -40,6 +40,16 @@ def lpt_assign(costs: Sequence[float], n_ranks: int, groups: Sequence[int] = Non
     return [sorted(x) for x in out]
 
 
+def table_costs(table: dict, n: int) -> Tuple[List[float], str]:
+    """(costs, source) of the first n pairs of a tabulated workload (mandala_mapping_amd/config4_costs.json): the MEASURED additive per-pair costs when the
+    table holds them ("measured_ms": least-squares fit of the step times of random 8-pair batches on an MI355X, scripts/measure_pair_costs.py), else the
+    a-priori estimate density(source) + density(target) ("costs")."""
+    m = table.get("measured_ms")
+    if m and len(m) >= n:
+        return [float(x) for x in m[:n]], "measured_ms (scripts/measure_pair_costs.py)"
+    return [float(x) for x in table["costs"][:n]], "a-priori density estimate"
+
+
 def _balance_by_swaps(out, load, costs, rounds: int = 1000):
     """Greedy LPT under an equal-count capacity leaves the ranks' estimated loads several per cent apart (config 4: 9 %), and at N ranks the step
     takes what the HEAVIEST rank takes. Local search on top of it: swap one item of the heaviest rank against one of another rank whenever that lowers

@@ -280,11 +280,8 @@ def calibration_sweep(n_seg=480, n_rays=480, true_params=(0.0, 0.03, -0.02, 0.03
     return segs
 
 
-def loop_trajectory(n_keyframes=50, per_lap=40, n_azimuth=400, seed=9000, step_noise_deg=0.15, step_noise_m=0.01, self_filter=1.0):
-    """A closed trajectory for the loop-closure candidate generation (SURVEY §8 row f4): the unit drives an ellipse (12 m x 8 m
-    semi-axes) through the room, `per_lap` keyframes per lap, n_keyframes in all — with the defaults a lap and a quarter, so keyframes
-    40 .. 49 stand where 0 .. 9 stood. Returns [(cloud in the sensor frame, T_true, T_odom)]: T_true = sensor -> world, T_odom = the pose a
-    drifting odometry would report (the true steps chained with a small random error each: what the signatures are built from)."""
+def loop_poses(n_keyframes=50, per_lap=40, seed=9000, step_noise_deg=0.15, step_noise_m=0.01):
+    """[(T_true, T_odom, scan seed)] of loop_trajectory (the poses alone: the sweeps can then be ray-cast in parallel)."""
     rng = np.random.default_rng(seed)
     out, T_odo, T_prev = [], None, None
     for k in range(n_keyframes):
@@ -297,5 +294,39 @@ def loop_trajectory(n_keyframes=50, per_lap=40, n_azimuth=400, seed=9000, step_n
         else:
             T_odo = T_odo @ (inv_T(T_prev) @ T) @ random_T(rng, step_noise_deg, step_noise_m)
         T_prev = T
-        out.append((hdl32_scan(T, n_azimuth, seed + 1 + k, self_filter=self_filter), T, T_odo.copy()))
+        out.append((T, T_odo.copy(), seed + 1 + k))
+    return out
+
+
+def loop_trajectory(n_keyframes=50, per_lap=40, n_azimuth=400, seed=9000, step_noise_deg=0.15, step_noise_m=0.01, self_filter=1.0):
+    """A closed trajectory for the loop-closure candidate generation (SURVEY §8 row f4): the unit drives an ellipse (12 m x 8 m
+    semi-axes) through the room, `per_lap` keyframes per lap, n_keyframes in all — with the defaults a lap and a quarter, so keyframes
+    40 .. 49 stand where 0 .. 9 stood. Returns [(cloud in the sensor frame, T_true, T_odom)]: T_true = sensor -> world, T_odom = the pose a
+    drifting odometry would report (the true steps chained with a small random error each: what the signatures are built from)."""
+    return [(hdl32_scan(T, n_azimuth, sd, self_filter=self_filter), T, T_odo)
+            for T, T_odo, sd in loop_poses(n_keyframes, per_lap, seed, step_noise_deg, step_noise_m)]
+
+
+def rotating_laser_sweep(pose, n_msgs=260, n_rays=541, seed=0, turn=1.15 * np.pi, sigma=0.01, fov_deg=270.0):
+    """The INPUT of m3d_aggregator for one sweep: a 2-D laser scanner on a head that turns about the unit's x axis —
+    `n_msgs` sensor_msgs/LaserScan messages over `turn` radians of head rotation (the aggregator publishes after 1.1 pi, m3d_aggregator.cpp:30),
+    each with the tf of its callback's lookup (laser frame -> unit frame: the head angle). Returns [(ranges float32[n_rays], angle_min,
+    angle_increment, tf7)], ranges ray-cast into the box room from the unit's world pose `pose`."""
+    rng = np.random.default_rng(seed)
+    a_min = np.float32(-np.radians(fov_deg) / 2.0)
+    a_inc = np.float32(np.radians(fov_deg) / (n_rays - 1))
+    ang = (a_min + np.arange(n_rays, dtype=np.float32) * a_inc).astype(np.float64)
+    d_l = np.stack([np.cos(ang), np.sin(ang), np.zeros_like(ang)], axis=-1)
+    out = []
+    for m in range(n_msgs):
+        th = turn * m / (n_msgs - 1)
+        Rh = rot_x(th)
+        d_w = d_l @ (pose[:3, :3] @ Rh).T
+        o_w = np.broadcast_to(pose[:3, 3], d_w.shape)
+        t = _ray_box_exit(o_w, d_w, *ROOM)
+        for bmin, bmax in OBSTACLES:
+            t = np.minimum(t, _ray_box_enter(o_w, d_w, bmin, bmax))
+        r = (t + rng.normal(0.0, sigma, size=t.shape)).astype(np.float32)
+        tf7 = np.array([0.0, 0.0, 0.0, np.sin(th / 2.0), 0.0, 0.0, np.cos(th / 2.0)])
+        out.append((r, float(a_min), float(a_inc), tf7))
     return out

@@ -173,7 +173,7 @@ def test_candidates_feed_the_batch_path_unchanged(reg, orc):
         G.add_keyframe(c, t[2], payload=d)
     cands = G.candidates()
     n = len(cands)
-    assert 10 <= n <= 2 * 10 and all(c.source - c.target >= 15 for c in cands)
+    assert 10 <= n <= 40 and all(c.source - c.target >= 15 for c in cands)
     out = np.zeros((n, 16), np.float32)
     st = (abi.Stats * n)()
     R._check(reg.lib().m3dreg_align_batch(R._h, G.pairs(cands), n, out.ctypes.data_as(C.POINTER(C.c_float)), st), "align_batch")

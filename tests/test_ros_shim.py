@@ -70,3 +70,89 @@ def _pose_matrix(p):
                   [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
     T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [x, y, z]
     return T
+
+
+@pytest.mark.gpu
+def test_shim_slam_mode_publishes_the_loop_closures_the_binding_finds(reg, tmp_path):
+    """~mode:=slam on a closed trajectory (a lap and a quarter of synth.loop_trajectory, 50 sweeps): scan-to-scan odometry, every sweep a keyframe, each new keyframe's
+    candidates (m3dloop_candidates) registered in one m3dreg_align_batch, gated, published on ~loop_closure. The shim's closures are the ones
+    binding.Gpu6dSlamNode(mode="slam") finds with the same parameters — same pairs, same floats — and each is the TRUE relative pose of its two keyframes."""
+    from mandala_mapping_amd import abi, synth
+    exe = _build(tmp_path)
+    tr = synth.loop_trajectory(n_keyframes=50, per_lap=40, n_azimuth=600, seed=9400)
+    files = []
+    for k, (cloud, _, _) in enumerate(tr):
+        p = str(tmp_path / f"sweep{k:02d}.f32"); np.ascontiguousarray(cloud, np.float32).tofile(p); files.append(p)
+    env = dict(os.environ, M3D_STUB_CLOUDS=":".join(files), M3D_STUB_PARAMS="mode=slam;loop_min_gap=30;loop_radius=3.0;loop_top_k=2;loop_min_corr=1000;loop_max_rms=0.05")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    poses = [l for l in r.stdout.splitlines() if l.startswith("pose ")]
+    shim = [l.split() for l in r.stdout.splitlines() if l.startswith("closure ")]
+    assert len(poses) == 49, r.stderr[-2000:]
+    node = reg.Gpu6dSlamNode(reg.default_params(), mode="slam", loop_params=abi.LoopParams.make(radius=3.0, min_gap=30, top_k=2, max_keyframes=1024), loop_min_corr=1000, loop_max_rms=0.05)
+    from mandala_mapping_amd.pointcloud2 import encode_xyz
+    for cloud, _, _ in tr:
+        node.on_cloud(encode_xyz(cloud))
+    assert len(node.keyframes) == 50 and 8 <= len(node.closures) == len(shim), (len(node.closures), len(shim))
+    for (s_, t_, T, st), line in zip(node.closures, shim):
+        assert line[1] == f"keyframe_{s_}" and line[2] == f"keyframe_{t_}"
+        assert np.array_equal(np.asarray([float(x) for x in line[3:6]], np.float32), T[:3, 3].astype(np.float32))
+        rot, tra = synth.pose_error(T, synth.inv_T(tr[t_][1]) @ tr[s_][1])
+        assert rot < 0.15 and tra < 0.03, (s_, t_, rot, tra)
+
+
+def _write_scans(path, sweeps):
+    """the stub's M3D_STUB_SCANS file: LaserScan records {uint32 n, float angle_min, float angle_increment, 7 doubles tf, n float ranges}; a ~request = n 0xFFFFFFFF"""
+    with open(path, "wb") as f:
+        for si, msgs in enumerate(sweeps):
+            if si:
+                f.write(np.uint32(0xFFFFFFFF).tobytes())
+            for r, a0, ai, tf7 in msgs:
+                f.write(np.uint32(len(r)).tobytes()); f.write(np.float32(a0).tobytes()); f.write(np.float32(ai).tobytes())
+                f.write(np.asarray(tf7, np.float64).tobytes()); f.write(np.ascontiguousarray(r, np.float32).tobytes())
+
+
+@pytest.mark.gpu
+def test_shim_aggregates_on_device_from_the_laser_scans(reg, orc, tmp_path):
+    """~aggregate_on_device:=true: the node takes the AGGREGATOR's input — the rotating laser's LaserScan messages with the tf of each — aggregates on the
+    device (m3dagg_*: m3d_aggregator.cpp:53-124,256-288), and registers the sweeps it gives birth to in HBM. Two sweeps of the box room from two poses, a
+    ~request between them: one pose published, equal to binding.Gpu6dSlamNode(aggregate_on_device=True)'s floats; the sweeps are the CPU restatement's
+    (oracle/m3d_agg_oracle.c) point for point; the pose is the true relative pose."""
+    from mandala_mapping_amd import synth
+    exe = _build(tmp_path)
+    P1 = synth.sensor_pose(1.0, -2.0, 20.0)
+    P2 = P1 @ synth.make_T(synth.rot_z(np.radians(2.0)), np.array([0.3, 0.1, 0.0]))
+    sweeps = [synth.rotating_laser_sweep(P1, seed=31), synth.rotating_laser_sweep(P2, seed=32)]
+    path = str(tmp_path / "scans.bin")
+    _write_scans(path, sweeps)
+    env = dict(os.environ, M3D_STUB_SCANS=path, M3D_STUB_PARAMS="aggregate_on_device=1;iterations=20")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    poses = [[float(x) for x in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("pose ")]
+    assert len(poses) == 1 and r.stdout.count("done 1") == 2, (r.stdout[-500:], r.stderr[-1000:])
+    pr = reg.default_params()
+    pr.iterations[1] = 20
+    node = reg.Gpu6dSlamNode(pr, aggregate_on_device=True)
+    O = orc.Aggregator()
+    got, clouds = [], []
+    for si, msgs in enumerate(sweeps):
+        if si:
+            node.on_request(); O.restart()
+        for rr, a0, ai, tf7 in msgs:
+            was_ready = O.status()["ready"]
+            if not was_ready:
+                O.add_scan(rr, a0, ai, tf7)
+                if O.status()["ready"]:
+                    clouds.append(O.points()[:, :3].copy())
+            out = node.on_scan(rr, a0, ai, tf7)
+            if out is not None:
+                got.append(out)
+    assert len(got) == 2 and got[0][1] is None and len(clouds) == 2
+    T, st = got[1]
+    assert np.array_equal(np.asarray(poses[0][:3], np.float32), T[:3, 3].astype(np.float32))
+    rot, tra = synth.pose_error(T, synth.inv_T(P1) @ P2)
+    assert rot < 0.1 and tra < 0.02, (rot, tra)
+    # the sweep the device aggregated is the oracle's, point for point: register the oracle's clouds through the ordinary path — same bits
+    R = reg.Registrar(pr)
+    T2, _ = R.align(R.cloud(np.ascontiguousarray(clouds[1], np.float32)), R.cloud(np.ascontiguousarray(clouds[0], np.float32)))
+    assert np.array_equal(T2, T)
