@@ -489,6 +489,10 @@ int m3dreg_debug_counters(m3dreg_handle* h, uint64_t out[2]);
  * m3dreg_debug_throw runs a guarded body that throws (kind 0: std::bad_alloc, else: something else) and returns what the
  * boundary made of it (M3DREG_ERR_OUT_OF_MEMORY / M3DREG_ERR_HIP). Neither needs a device. */
 int m3dreg_debug_fail_alloc(int nth);
+/* (ABI 8) Report of the DIAGNOSIS build (csrc: `make checked` -> libm3dreg_checked.so, -DM3D_CHECKED): every index a kernel reads from memory is compared with its
+ * bound before it addresses global memory; out[0..3] = {offences, site, index, bound} of the iteration kernels, out[4..7] of the bucketing pipeline (first offence
+ * kept; reset != 0 clears). The shipped library has no checks compiled in: M3DREG_ERR_INVALID_ARG. */
+int m3dreg_debug_checks(m3dreg_handle* h, uint32_t out[8], int reset);
 int m3dreg_debug_throw(int kind);
 
 #ifdef __cplusplus

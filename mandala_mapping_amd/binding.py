@@ -35,7 +35,7 @@ EXPORTS = [
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
     "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error", "m3dreg_debug_multi_clouds",
-    "m3dreg_debug_fail_alloc", "m3dreg_debug_throw",
+    "m3dreg_debug_fail_alloc", "m3dreg_debug_throw", "m3dreg_debug_checks",
     "m3dloop_default_params", "m3dloop_create", "m3dloop_destroy", "m3dloop_clear", "m3dloop_add_keyframe", "m3dloop_update_pose", "m3dloop_size", "m3dloop_candidates",
     "m3dloop_make_pairs", "m3dloop_make_pair_descs", "m3dloop_gate", "m3dloop_signature", "m3dloop_last_profile",
     "m3dreg_debug_candidates", "m3dreg_host_alloc", "m3dreg_host_free", "m3dreg_host_register", "m3dreg_host_unregister",
@@ -147,6 +147,7 @@ def lib():
     L.m3dloop_gate.argtypes = [C.POINTER(abi.LoopCandidate), C.POINTER(abi.Stats), sz, C.c_int64, C.c_double, C.POINTER(C.c_uint8)]
     L.m3dloop_signature.argtypes = [vp, C.c_int32, u32p, u32p]
     L.m3dloop_last_profile.argtypes = [vp, f64p, C.POINTER(C.c_uint64)]
+    L.m3dreg_debug_checks.argtypes = [vp, u32p, C.c_int]
     L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
     L.m3dreg_debug_throw.argtypes = [C.c_int]
     _lib = L
@@ -424,6 +425,12 @@ class Registrar:
         out = (C.c_uint64 * 2)()
         self._check(lib().m3dreg_debug_counters(self._h, out), "debug_counters")
         return int(out[0]), int(out[1])
+
+    def checks(self, reset=False):
+        """the diagnosis build's report (libm3dreg_checked.so): {"icp": (offences, site, index, bound), "bucket": (...)}; raises on the shipped library"""
+        out = (C.c_uint32 * 8)()
+        self._check(lib().m3dreg_debug_checks(self._h, out, int(reset)), "debug_checks")
+        return {"icp": tuple(out[0:4]), "bucket": tuple(out[4:8])}
 
     def trace(self, cap=256):
         buf = np.zeros((cap, 16), np.float64)

@@ -10,6 +10,7 @@
 // work: coalesced 4-B/16-B streams, LDS histograms and wave64 ballots for the stable in-block ranks;
 // no MFMA (nothing here is a contraction).
 #include "m3d_kernels.h"
+M3D_CHK_READER(m3d_chk_read_bucket)
 
 // Workgroup -> (row, block) of the batched launches below (a row = one cloud or one grid of the batch; 1-D grids of rows * bpr workgroups).
 // Consecutive workgroups of a row go to consecutive XCDs (the dispatcher deals workgroups round-robin by linear id). Round 4 measured the
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_rekey(const M3dBuild* __restrict__ buil
     if (B.fine < 0) return;
     const int i = rb.blk * (int)blockDim.x + (int)threadIdx.x;
     if (i >= B.n) return;
-    const uint32_t v = builds[B.fine].perm_out[i];
+    const uint32_t v = M3D_CHK(201, builds[B.fine].perm_out[i], B.n);
     B.ka[i] = B.keys[v]; B.va[i] = v;
 }
 
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const M3dBuild* __res
         if (i < n) {
             const uint32_t d = (key[r] >> shift) & 255u;
             const uint32_t pos = cnt[r * RS_WAVES + wave][d] + rank[r];
-            kout[pos] = key[r]; vout[pos] = val[r];
+            { const uint32_t pc = M3D_CHK(202, pos, n); kout[pc] = key[r]; vout[pc] = val[r]; }
         }
     }
 }
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
     const uint32_t hmask = B.dyn[1];
     const int hshift = (int)B.dyn[2];
     const uint32_t k = inb ? skey[j] : M3D_INVALID_KEY;
-    const uint32_t oi = inb ? sval[j] : 0u;
+    const uint32_t oi = inb ? M3D_CHK(203, sval[j], n) : 0u;
     const bool valid = k != M3D_INVALID_KEY;
     const uint32_t kp = (inb && j) ? skey[j - 1] : M3D_INVALID_KEY;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void k_finalize_level(const M3dBuild* __restri
         uint32_t off = 0u, tot = 0u;
 #pragma unroll
         for (int w = 0; w < 4; w++) { if (w < wave) off += s_wc[w]; tot += s_wc[w]; }
-        if (won) G.nlist[(size_t)rb.blk * 256u + off + (uint32_t)__popcll(bw & ((1ull << lane) - 1ull))] = h;
+        if (won) G.nlist[(size_t)rb.blk * 256u + M3D_CHK(204, off + (uint32_t)__popcll(bw & ((1ull << lane) - 1ull)), 256u)] = h;
         if (threadIdx.x == 0) G.nvcnt[rb.blk] = tot;
     }
     if (!inb) return;
@@ -759,7 +760,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     }
     __syncthreads();
     for (uint32_t hd = (uint32_t)tid; hd < nheads; hd += 256u) {
-        const float4 p = B.pts[s_head[hd]];
+        const float4 p = B.pts[M3D_CHK(208, s_head[hd], B.n)];
         // (packed with the grid's own bit widths — the bucket key: sum of the widths <= 28; fixed 11 / 11 / 10-bit fields lost the top bit of z on a grid
         // of more than 2048 voxels in z)
         s_head[hd] = m3d_bucket_key(g, (int)m3d_cell_f(p.x, g.mn[0], g.inv_leaf) >> 1, (int)m3d_cell_f(p.y, g.mn[1], g.inv_leaf) >> 1, (int)m3d_cell_f(p.z, g.mn[2], g.inv_leaf) >> 1);
@@ -947,7 +948,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     }
     for (uint32_t j = 0; j < n_img; j++) {
         const uint32_t image = j == 0u ? (uint32_t)t : extra + j - 1u;
-        uint8_t* img = B.timg + (size_t)image * M3D_TILE_IMG_BYTES;
+        uint8_t* img = B.timg + (size_t)M3D_CHK(209, image, m3d_tiles_of(B.n) + m3d_tile_pool(m3d_tiles_of(B.n))) * M3D_TILE_IMG_BYTES;
         float4* ipts = reinterpret_cast<float4*>(img + M3D_TILE_IMG_PTS);
         if (tid == 0) s_nv = 0u;
         __syncthreads();
@@ -962,13 +963,13 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
                 const uint32_t c1 = (uint32_t)(((sub < 4) ? cumA : cumB) >> (16 * (sub & 3))) & 0xFFFFu;
                 if (c1 > c0) {
                     const uint32_t vkey = (2u * cx + (uint32_t)(sub & 1)) | ((2u * cy + (uint32_t)((sub >> 1) & 1)) << sh1) | ((2u * cz + (uint32_t)(sub >> 2)) << sh2);
-                    const uint32_t vi = atomicAdd(&s_nv, 1u);   // (at most VCAP per image: the cut above)
+                    const uint32_t vi = M3D_CHK(206, atomicAdd(&s_nv, 1u), M3D_TILE_VCAP);   // (at most VCAP per image: the cut above)
                     s_vk[vi] = vkey;
                     s_vv[vi] = (off[q] + c0) | ((c1 - c0 - 1u) << 11) | ((uint32_t)(tid + 256 * q) << 22);
                 }
                 c0 = c1;
             }
-            for (uint32_t k = 0; k < cnt[q]; k++) s_src[off[q] + k] = gst[q] + k;   // (LDS: the copy below is then one coalesced pass of the whole workgroup)
+            for (uint32_t k = 0; k < cnt[q]; k++) s_src[M3D_CHK(207, off[q] + k, M3D_TILE_PCAP)] = gst[q] + k;   // (LDS: the copy below is then one coalesced pass of the whole workgroup)
         }
         __syncthreads();
         if (j == 0u) TB_STAMP(6);
@@ -980,7 +981,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
                 // points went through 64 bytes of scratch per lane, 80 with the rest: the kernel's only private memory)
                 const uint32_t pa = q0 + (uint32_t)tid, pb = pa + 256u, pc = pa + 512u, pd = pa + 768u;
                 const uint32_t ga = pa < np ? s_src[pa] : 0u, gb = pb < np ? s_src[pb] : 0u, gc = pc < np ? s_src[pc] : 0u, gd = pd < np ? s_src[pd] : 0u;
-                const m3d_f32x4 va = gpts[ga], vb = gpts[gb], vc = gpts[gc], vd = gpts[gd];
+                const m3d_f32x4 va = gpts[M3D_CHK(205, ga, B.n)], vb = gpts[M3D_CHK(205, gb, B.n)], vc = gpts[M3D_CHK(205, gc, B.n)], vd = gpts[M3D_CHK(205, gd, B.n)];
                 if (pa < np) gout[pa] = va;
                 if (pb < np) gout[pb] = vb;
                 if (pc < np) gout[pc] = vc;

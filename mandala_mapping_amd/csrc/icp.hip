@@ -13,6 +13,7 @@
 // result does not depend on launch geometry. Two launches per Gauss-Newton iteration (k_nn_iter,
 // k_accumulate_matches). No MFMA: there is no contraction.
 #include "m3d_kernels.h"
+M3D_CHK_READER(m3d_chk_read_icp)
 
 // -DM3D_STATS: instrumented build (scripts/walk_stats.py): counts, per Gauss-Newton iteration of pair 0's clock, what the
 // search does — one wave-aggregated atomic per event. Never defined in the shipped library.
@@ -895,7 +896,7 @@ __device__ __forceinline__ int m3d_classify(const M3dGrid& g, m3d_gf4 pts, M3D_G
     const int mp = e.x;
     m3d_f32x4 s0 = (m3d_f32x4){ 0.f, 0.f, 0.f, 0.f };
     q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mp >= 0) { q1 = m3d_ld(pts, (size_t)mp); s0 = m3d_cert_state(e.y, itq, s_ring, p); }
+    if (mp >= 0) { q1 = m3d_ld(pts, (size_t)M3D_CHK(104, mp, g.n_valid)); s0 = m3d_cert_state(e.y, itq, s_ring, p); }
     return m3d_classify_loaded(g, out, cache, i, mp, ux, uy, uz, dmax2, certify, seed_reach, s0, q1, dseed, certified, sit);
 }
 
@@ -1165,7 +1166,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
     if (!LEAN && A.coop_kernel && J.coop_always) return;   // (block-uniform) a crowded level: k_nn_coop, launched right behind, answers this pair
     {   // the source's crowded blocks first (they run several times as long as the rest: started last they were the kernel's tail)
         const uint32_t* ord = J.src_order;
-        if (ord && blk < J.src_nblk) blk = (int)ord[blk];
+        if (ord && blk < J.src_nblk) blk = (int)M3D_CHK(101, ord[blk], J.src_nblk);
     }
     M3D_BT_BEGIN();
     __shared__ int s_cnt[4];
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
             if (m3d_finite3(ux, uy, uz)) {
                 cls = 2;
                 if (!LEAN && J.prev_pts && e.x >= 0) {   // the coarser level's match seeds this level's first search when it lies inside the new neighbourhood
-                    const float4 q1 = m3d_ld(prev, (size_t)e.x);
+                    const float4 q1 = m3d_ld(prev, (size_t)M3D_CHK(105, e.x, g.n_valid));
                     const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
                     const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const float reach = A.seed_reach * g.leaf;
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     uint32_t slot = m3d_hash_slot(hkey, g.hshift);
                     uint4 lo = m3d_ld(tab, 2 * (size_t)slot);
                     while (lo.x != hkey) { slot = (slot + 1) & g.hmask; lo = m3d_ld(tab, 2 * (size_t)slot); }   // (the bucket exists)
-                    tile = (int)(lo.y / (uint32_t)M3D_TILE_PTS);
+                    tile = (int)M3D_CHK(107, lo.y / (uint32_t)M3D_TILE_PTS, A.ntile_max);
                 }
             }
         }
@@ -1329,6 +1330,7 @@ __global__ __launch_bounds__(256) M3D_NN_OCC void k_nn_iter(const M3dJob* __rest
                     const uint32_t wl = ((uint32_t)t0 + c + (uint32_t)pair) & (uint32_t)(M3D_TILE_LISTS - 1);   // (per item, not per workgroup: a crowded tile's chunks spread over all lists)
                     const uint32_t w = atomicAdd(A.wcount + 32u * wl, 1u);
                     if (w < (uint32_t)A.wcap) A.witems[(size_t)wl * (size_t)A.wcap + w] = make_uint2((uint32_t)pair, (uint32_t)t0 | (c << 20));
+                    else (void)M3D_CHK(108, w, A.wcap);   // (a dropped work item: its records would never be answered)
                 }
             }
             s_tb[tid] = base;
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
     {   // the crowded 256-point blocks first, like k_nn_iter: this workgroup is an eighth of one
         const uint32_t* ord = J.src_order;
         const int b256 = blk >> 3;
-        if (ord && b256 < J.src_nblk) blk = (int)ord[b256] * 8 + (blk & 7);
+        if (ord && b256 < J.src_nblk) blk = (int)M3D_CHK(102, ord[b256], J.src_nblk) * 8 + (blk & 7);
     }
     const int tid = (int)threadIdx.x, sub = tid & 7;
     const int i = blk * 32 + (tid >> 3);
@@ -1436,7 +1438,7 @@ __global__ __launch_bounds__(256) void k_nn_coop(const M3dJob* __restrict__ jobs
             if (m3d_finite3(ux, uy, uz)) {
                 cls = 2;
                 if (J.prev_pts && e.x >= 0) {   // (as in k_nn_iter: the coarser level's match as a seed)
-                    const float4 q1 = m3d_ld(prev, (size_t)e.x);
+                    const float4 q1 = m3d_ld(prev, (size_t)M3D_CHK(105, e.x, g.n_valid));
                     const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
                     const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const float reach = A.seed_reach * g.leaf;
@@ -1476,7 +1478,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop_list(const M3dJob* __restric
         const uint32_t* ord = J.src_order;
         constexpr int PER = 256 / QPB;
         const int b256 = blk / PER;
-        if (ord && b256 < J.src_nblk) blk = (int)ord[b256] * PER + (blk % PER);
+        if (ord && b256 < J.src_nblk) blk = (int)M3D_CHK(103, ord[b256], J.src_nblk) * PER + (blk % PER);
     }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_ring[M3D_RING_FLOATS];
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop_list(const M3dJob* __restric
             if (m3d_finite3(ux, uy, uz)) {
                 cls = 2;
                 if (J.prev_pts && e.x >= 0) {
-                    const float4 q1 = m3d_ld(m3d_as_global(J.prev_pts), (size_t)e.x);
+                    const float4 q1 = m3d_ld(m3d_as_global(J.prev_pts), (size_t)M3D_CHK(106, e.x, g.n_valid));
                     const float ex = ux - q1.x, ey = uy - q1.y, ez = uz - q1.z;
                     const float dd1 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
                     const float reach = A.seed_reach * g.leaf;
@@ -1568,7 +1570,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const uint2 item = witems[it];
-        const int pair = (int)item.x, blk = (int)(item.y & 0xFFFFFu);
+        const int pair = (int)M3D_CHK(109, item.x, 65536u), blk = (int)M3D_CHK(110, item.y & 0xFFFFFu, A.ntile_max);
         const unsigned int chunk = item.y >> 20;
         const M3dJob& J = jobs[pair];
         const M3dPairState* st = A.states + pair;
@@ -1619,13 +1621,13 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
         const bool seeded = (w >> 31) != 0u;
         M3dTileQ Q;
         int m = -1;
-        for (unsigned int j = 0; j < H.n_img; j++) {
-            const unsigned int image = j == 0u ? (unsigned int)blk : H.extra + j - 1u;
+        for (unsigned int j = 0; j < M3D_CHK_LE(116, H.n_img, M3D_TILE_MAXIMG); j++) {
+            const unsigned int image = M3D_CHK(111, j == 0u ? (unsigned int)blk : H.extra + j - 1u, A.ntile_max + m3d_tile_pool(A.ntile_max));
             const uint8_t* img = J.tgt.timg + (size_t)image * M3D_TILE_IMG_BYTES;
             {   // stage: the voxel list is hashed into the LDS directory here (the image stores the list, not 16 KB of mostly empty slots)
                 if (j != 0u) __syncthreads();   // everybody is done with the previous image
                 const M3dTileImgMeta IM = J.tgt.timeta[image];
-                const unsigned int n_points = IM.n_points, n_vox = IM.n_voxels & 0x7FFFFFFFu;
+                const unsigned int n_points = M3D_CHK_LE(112, IM.n_points, M3D_TILE_PCAP), n_vox = M3D_CHK_LE(113, IM.n_voxels & 0x7FFFFFFFu, M3D_TILE_VCAP);
                 const M3D_GLOBAL m3d_u32x2* gl = (const M3D_GLOBAL m3d_u32x2*)(const void M3D_GLOBAL*)img;
                 const m3d_gf4 gp = m3d_as_global(reinterpret_cast<const float4*>(img + M3D_TILE_IMG_PTS));
                 static_assert(M3D_TILE_VCAP <= 3 * M3D_TILE_THREADS && M3D_TILE_PCAP == 4 * M3D_TILE_THREADS && M3D_TILE_VS == 4 * M3D_TILE_THREADS && M3D_TILE_ECAP <= M3D_TILE_THREADS,
@@ -1680,7 +1682,8 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
             // of a "nothing around" verdict were the last values the kernel kept in scratch across the images of an item)
             const float4 re = m3d_ld(rec, (size_t)q);
             const uint32_t we = __float_as_uint(re.w);
-            const int qi = (int)(we & 0x7FFFFFFFu);
+            const int qi = (int)M3D_CHK(114, we & 0x7FFFFFFFu, A.match_stride);
+            if (m >= 0) m = (int)M3D_CHK(115, m, g.n_valid);
             const float d2 = m3d_key_d2(Q.bkey);
             // "nothing at all in the 27 voxels" may be cached only when every existing voxel was looked up and found empty
             if (!(m >= 0 && d2 <= dmax2)) m = ((we >> 31) != 0u || m >= 0 || Q.sec != M3D_INF_BITS) ? -1 : M3D_NN_NONE_CACHED;
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
             const int itq = st->iters & 31;
             if (nW > 2 * ICP_THREADS) {   // (uniform) many: one query per lane
                 for (int w = (int)threadIdx.x; w < nW; w += ICP_THREADS) {
-                    const int qi = s_pend[w];
+                    const int qi = M3D_CHK(119, s_pend[w], n);
                     const float4 ps = m3d_ld3(src, (size_t)qi);
                     const float vx = fmaf(R[0], ps.x, fmaf(R[1], ps.y, fmaf(R[2], ps.z, tt[0])));
                     const float vy = fmaf(R[3], ps.x, fmaf(R[4], ps.y, fmaf(R[5], ps.z, tt[1])));
@@ -2049,7 +2052,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_accumulate_matches(   // (WALK:
         for (int k = 0; k < NB; k++) { const int i = i0 + k * stride; p[k] = (i < n) ? m3d_ld3(src, (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const size_t mm = (size_t)max(m[k], 0);
+            const size_t mm = (size_t)M3D_CHK(117, max(m[k], 0), max(L.g.n_valid, 1));
             q[k] = m3d_ld(pts, mm);
             nq[k] = (METRIC == 1) ? m3d_ld(nrm, mm) : make_float4(0.f, 0.f, 0.f, 0.f);   // sorted order: neighbouring matches share cache lines
         }
@@ -2145,7 +2148,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_late(const M3dJob* __restri
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const int i = i0 + k * stride;
-            const size_t mm = (size_t)max(m[k], 0);
+            const size_t mm = (size_t)M3D_CHK(118, max(m[k], 0), max(g.n_valid, 1));
             s0[k] = (m3d_f32x4){ 0.f, 0.f, 0.f, 0.f }; q[k] = make_float4(0.f, 0.f, 0.f, 0.f); nq[k] = q[k];
             if (i < n && m[k] >= 0) {
                 q[k] = m3d_ld(pts, mm);

@@ -188,6 +188,32 @@ __host__ __device__ inline bool m3d_dense_level(uint32_t n_tgt, uint32_t occupie
            (n > (unsigned long long)M3D_COOP_DENSITY_MAP * v && n >= (unsigned long long)M3D_COOP_MAP_RATIO * (unsigned long long)n_src);
 }
 
+
+// ---- -DM3D_CHECKED (diagnosis build, `make checked` -> libm3dreg_checked.so; DESIGN.md §8 "the unexplained GPU memory fault") --------------------------------
+// Every index that a kernel takes out of MEMORY before it addresses global memory with it — match indices, permutation values, tile / image numbers, staged
+// counts, work-item fields, block orders — goes through M3D_CHK(site, index, bound): out of range, the FIRST offence is recorded {count, site, index, bound} in
+// a per-translation-unit device word (read back by m3dreg_debug_checks) and the index is clamped to 0, so the run goes on and reports instead of faulting.
+// In the shipped build the macro is the identity.
+#ifdef M3D_CHECKED
+static __device__ unsigned int g_m3d_chk[4];
+__device__ __forceinline__ unsigned long long m3d_chk_fail(unsigned int site, unsigned long long idx, unsigned long long bound) {
+    if (atomicAdd(&g_m3d_chk[0], 1u) == 0u) { g_m3d_chk[1] = site; g_m3d_chk[2] = (unsigned int)(idx > 0xFFFFFFFFull ? 0xFFFFFFFFull : idx); g_m3d_chk[3] = (unsigned int)bound; }
+    return 0ull;
+}
+template <typename T> __device__ __forceinline__ T m3d_chk(unsigned int site, T idx, unsigned long long bound) {
+    return (unsigned long long)idx < bound ? idx : (T)m3d_chk_fail(site, (unsigned long long)idx, bound);   // (a negative index converts to a huge one: caught)
+}
+#define M3D_CHK(site, idx, bound) m3d_chk((site), (idx), (unsigned long long)(bound))
+#define M3D_CHK_LE(site, idx, bound) M3D_CHK(site, idx, (unsigned long long)(bound) + 1ull)
+#define M3D_CHK_READER(name) extern "C" hipError_t name(unsigned int* out, int reset) { \
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m3d_chk), sizeof(unsigned int) * 4); \
+    if (e == hipSuccess && reset) { const unsigned int z[4] = { 0u, 0u, 0u, 0u }; e = hipMemcpyToSymbol(HIP_SYMBOL(g_m3d_chk), z, sizeof(z)); } return e; }
+#else
+#define M3D_CHK(site, idx, bound) (idx)
+#define M3D_CHK_LE(site, idx, bound) (idx)
+#define M3D_CHK_READER(name)
+#endif
+
 // ---- spec primitives shared by every kernel (operation order is normative) --------
 __device__ __forceinline__ bool m3d_finite3(float x, float y, float z) {
     return isfinite(x) && isfinite(y) && isfinite(z);

@@ -155,6 +155,9 @@ struct M3dLoopScoreArgs {
 hipError_t m3d_launch_loop_sign(hipStream_t s, const M3dLoopSignArgs& A, float4* pos_k);
 hipError_t m3d_launch_loop_score(hipStream_t s, M3dLoopScoreArgs A, uint2* d_out /* [n_rows][top_k] {j or ~0, overlap} */, int top_k, uint32_t thr_q16);
 
+// debug.hip (diagnosis only: M3DREG_POISON)
+hipError_t m3d_launch_poison(hipStream_t s, void* p, size_t bytes, uint32_t seed);
+
 // icp.hip: one Gauss-Newton iteration = k_nn_iter (classify + search / bin), k_nn_tiles (binned searches from LDS), k_accumulate_matches
 // (residuals + reduction; its last block per pair also solves and updates the pose)
 struct M3dNnWork {               // workspace of the batch, all per pair with the same stride (a whole number of 256-query blocks)

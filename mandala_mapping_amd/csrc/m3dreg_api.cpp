@@ -222,6 +222,33 @@ inline void alloc_point() { int v = g_fail_alloc.load(); if (v > 0 && g_fail_all
 inline bool stream_usable(const m3dreg_handle* h) { return h->own_stream || !h->closed; }
 inline hipError_t sync_handle(m3dreg_handle* h) { return stream_usable(h) ? hipStreamSynchronize(h->stream) : hipDeviceSynchronize(); }
 
+// ---- M3DREG_POISON (diagnosis only): every device allocation of the library — and every pooled block handed out again — is filled with a hostile
+// pattern before use: "rand" = pseudo-random words (a hash of the word's index), or a hex word ("ffffffff", "7fc00000", "0"). A kernel that reads memory the
+// library never wrote then meets the same garbage in every run: the parity tests fail or the process faults deterministically, instead of one run in hundreds
+// depending on what the allocation held before. Unset (the default): no fill, no cost.
+struct PoisonMode { bool on = false, rnd = false; uint32_t word = 0; };
+const PoisonMode& poison_mode() {
+    static const PoisonMode m = [] {
+        PoisonMode q;
+        const char* v = getenv("M3DREG_POISON");
+        if (v && *v) { q.on = true; if (!strcmp(v, "rand")) q.rnd = true; else q.word = uint32_t(strtoul(v, nullptr, 16)); }
+        return q;
+    }();
+    return m;
+}
+hipError_t poison(void* p, size_t bytes, hipStream_t s) {   // (s == nullptr: synchronous)
+    const PoisonMode& m = poison_mode();
+    if (!m.on || !p || bytes < 4) return hipSuccess;
+    hipError_t e = m.rnd ? m3d_launch_poison(s, p, bytes, 0x6D3Du) : hipMemsetD32Async(static_cast<hipDeviceptr_t>(p), int(m.word), bytes / 4, s);
+    if (e == hipSuccess && !s) e = hipDeviceSynchronize();
+    return e;
+}
+hipError_t m3d_malloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) e = poison(*p, bytes, nullptr);
+    return e;
+}
+
 const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
 
 int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
@@ -232,16 +259,17 @@ int pool_get(m3dreg_handle* h, size_t bytes, Block& out) {
         out = h->pool[size_t(best)];
         h->pool_bytes -= out.bytes;
         h->pool.erase(h->pool.begin() + best);
+        if (poison_mode().on) HIPCHK(h, poison(out.p, out.bytes, h->stream));   // (diagnosis: a recycled block holds the previous cloud)
         return M3DREG_OK;
     }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = m3d_malloc(&p, bytes);
     if (e != hipSuccess) {   // make room: drop the cache and retry once
         hipStreamSynchronize(h->stream);
         for (Block& b : h->pool) hipFree(b.p);
         h->pool.clear(); h->pool_bytes = 0;
-        e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "hipMalloc(cloud block)", e);
+        e = m3d_malloc(&p, bytes);
+        if (e != hipSuccess) return fail(h, M3DREG_ERR_HIP, "m3d_malloc(cloud block)", e);
     }
     out.p = p; out.bytes = bytes;
     return M3DREG_OK;
@@ -261,7 +289,7 @@ int ensure_ws(m3dreg_handle* h, size_t dev_bytes, size_t host_bytes) {
         if (h->ws.p) hipFree(h->ws.p);
         h->ws = Block();
         const size_t cap = dev_bytes + dev_bytes / 4;
-        HIPCHK(h, hipMalloc(&h->ws.p, cap));
+        HIPCHK(h, m3d_malloc(&h->ws.p, cap));
         h->ws.bytes = cap;
     }
     if (host_bytes > h->h_ws_bytes) {
@@ -425,6 +453,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     int rc = ensure_ws(h, ws_bytes, host_bytes);
     if (rc) { cleanup(); return rc; }
     layout(h->ws.p);
+    if (poison_mode().on) { hipError_t e = poison(h->ws.p, h->ws.bytes, h->stream); if (e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, "poison(workspace)", e); } }   // (diagnosis: the workspace holds the previous batch)
     if (h->staged) { hipError_t e = hipEventSynchronize(h->staged); if (e != hipSuccess) { cleanup(); return fail(h, M3DREG_ERR_HIP, "hipEventSynchronize(staging)", e); } }
     Carver hw(h->h_ws);   // the same sequence of takes as the device layout above: the staging block mirrors it byte for byte
     M3dDecode* h_dec = hw.take<M3dDecode>(k);
@@ -605,13 +634,13 @@ int ensure_batch(m3dreg_handle* h, size_t n_pairs) {
     size_t cap = n_pairs < 8 ? 8 : n_pairs;
     static_assert(sizeof(M3dJob) % 8 == 0, "the pair states follow the jobs in one block");
     const size_t block = sizeof(M3dJob) * cap * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * cap;
-    HIPCHK(h, hipMalloc((void**)&h->d_jobs, block));
+    HIPCHK(h, m3d_malloc((void**)&h->d_jobs, block));
     HIPCHK(h, hipHostMalloc((void**)&h->h_jobs, block, hipHostMallocDefault));
-    HIPCHK(h, hipMalloc((void**)&h->d_ring, sizeof(float) * 32 * 12 * cap));
+    HIPCHK(h, m3d_malloc((void**)&h->d_ring, sizeof(float) * 32 * 12 * cap));
     h->d_states = reinterpret_cast<M3dPairState*>(h->d_jobs + cap * M3DREG_MAX_LEVELS);
     h->h_states = reinterpret_cast<M3dPairState*>(h->h_jobs + cap * M3DREG_MAX_LEVELS);
     if (!h->d_trace) {
-        HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE));
+        HIPCHK(h, m3d_malloc((void**)&h->d_trace, sizeof(double) * 16 * M3D_MAX_TRACE));
         HIPCHK(h, hipHostMalloc((void**)&h->h_trace, sizeof(double) * 16 * M3D_MAX_TRACE, hipHostMallocDefault));
     }
     if (!h->h_progress) {
@@ -639,7 +668,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         if (h->d_match) hipFree(h->d_match);
         h->d_match = nullptr; h->match_cap = 0;
         const size_t cap = n_pairs * stride + n_pairs * stride / 4;
-        HIPCHK(h, hipMalloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // {match, certificate word} (8 B) | cache (int64)
+        HIPCHK(h, m3d_malloc((void**)&h->d_match, sizeof(int) * 4 * cap));   // {match, certificate word} (8 B) | cache (int64)
         h->match_cap = cap;
     }
     // (sized for either setting of m3dreg_set_latency_mode: the mode may change between batches)
@@ -648,7 +677,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_partials) hipFree(h->d_partials);
         h->d_partials = nullptr; h->partials_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_partials, sizeof(long long) * (n_part + n_part / 4)));
+        HIPCHK(h, m3d_malloc((void**)&h->d_partials, sizeof(long long) * (n_part + n_part / 4)));
         h->partials_cap = n_part + n_part / 4;
     }
     const size_t n_tk = size_t(std::max(m3d_ticket_words(int(n_pairs), max_n_src, 0), m3d_ticket_words(int(n_pairs), max_n_src, 1)));
@@ -656,7 +685,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->d_tickets) hipFree(h->d_tickets);
         h->d_tickets = nullptr; h->tickets_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_tickets, sizeof(unsigned int) * (n_tk + n_tk / 4)));
+        HIPCHK(h, m3d_malloc((void**)&h->d_tickets, sizeof(unsigned int) * (n_tk + n_tk / 4)));
         h->tickets_cap = n_tk + n_tk / 4;
         HIPCHK(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned int) * h->tickets_cap, h->stream));   // once: every launch leaves its arrival counters at zero
     }
@@ -671,7 +700,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
             if (h->d_rec) hipFree(h->d_rec);
             h->d_rec = nullptr; h->rec_cap = 0;
             const size_t cap = n_pairs * rec_stride + n_pairs * rec_stride / 8;
-            HIPCHK(h, hipMalloc((void**)&h->d_rec, (sizeof(float4) + sizeof(float)) * cap));
+            HIPCHK(h, m3d_malloc((void**)&h->d_rec, (sizeof(float4) + sizeof(float)) * cap));
             h->rec_cap = cap;
         }
         if (n_pairs * cnt_stride > h->tcnt_cap) {
@@ -679,7 +708,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
             if (h->d_tcnt) hipFree(h->d_tcnt);
             h->d_tcnt = nullptr; h->tcnt_cap = 0;
             const size_t cap = n_pairs * cnt_stride + n_pairs * cnt_stride / 4;
-            HIPCHK(h, hipMalloc((void**)&h->d_tcnt, sizeof(unsigned int) * cap));
+            HIPCHK(h, m3d_malloc((void**)&h->d_tcnt, sizeof(unsigned int) * cap));
             h->tcnt_cap = cap;
             HIPCHK(h, hipMemsetAsync(h->d_tcnt, 0, sizeof(unsigned int) * cap, h->stream));   // once: every iteration leaves its counters at zero
         }
@@ -690,7 +719,7 @@ int ensure_match(m3dreg_handle* h, size_t n_pairs, int max_n_src, int max_n_tgt)
             h->d_witems = nullptr; h->witems_cap = 0;
             // M3D_TILE_LISTS lists, each able to hold every item (which workgroups of k_nn_iter publish is data dependent); the
             // first 128 * M3D_TILE_LISTS bytes hold the lists' counters, one per 128-B line
-            HIPCHK(h, hipMalloc((void**)&h->d_witems, sizeof(uint2) * (wcap + wcap / 4) * M3D_TILE_LISTS + 128 * M3D_TILE_LISTS));
+            HIPCHK(h, m3d_malloc((void**)&h->d_witems, sizeof(uint2) * (wcap + wcap / 4) * M3D_TILE_LISTS + 128 * M3D_TILE_LISTS));
             h->witems_cap = wcap + wcap / 4;
             HIPCHK(h, hipMemsetAsync(h->d_witems, 0, 128 * M3D_TILE_LISTS, h->stream));
         }
@@ -1072,6 +1101,14 @@ static int batch_begin(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pair
     if ((rc = build_jobs(h, pairs, n_pairs, max_n_src, max_n_tgt))) return rc;
     const m3dreg_params& P = h->params;
     if ((rc = ensure_match(h, n_pairs, max_n_src, max_n_tgt))) return rc;
+    if (poison_mode().on) {   // (diagnosis: nothing is carried across registrations — per-query records, query slabs, partial sums and pose rings may hold anything; the
+        // counters that every launch leaves at zero — tickets, per-tile counts, work-item counts — are part of the protocol and stay)
+        HIPCHK(h, poison(h->d_match, sizeof(int) * 4 * h->match_cap, h->stream));
+        HIPCHK(h, poison(h->d_partials, sizeof(long long) * h->partials_cap, h->stream));
+        HIPCHK(h, poison(h->d_ring, sizeof(float) * 32 * 12 * h->cap_pairs, h->stream));
+        if (h->d_rec) HIPCHK(h, poison(h->d_rec, (sizeof(float4) + sizeof(float)) * h->rec_cap, h->stream));
+        if (h->d_witems) HIPCHK(h, poison(reinterpret_cast<uint8_t*>(h->d_witems) + 128 * M3D_TILE_LISTS, sizeof(uint2) * h->witems_cap * M3D_TILE_LISTS, h->stream));
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_jobs, h->h_jobs, sizeof(M3dJob) * h->cap_pairs * M3DREG_MAX_LEVELS + sizeof(M3dPairState) * n_pairs, hipMemcpyHostToDevice, h->stream));   // jobs + states: one block, one copy
     HIPCHK(h, m3d_launch_patch_jobs(h->stream, h->d_jobs, int(n_pairs), int(h->cap_pairs), P.n_levels));   // table geometry, device to device
     m3dreg_handle::Run& R = h->run;
@@ -1410,7 +1447,7 @@ int agg_add(m3dagg* a, M3dAggArgs& A, const void* host_payload, size_t payload_b
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (a->d_stage) hipFree(a->d_stage);
         a->d_stage = nullptr; a->stage_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&a->d_stage, payload_bytes + payload_bytes / 2));
+        HIPCHK(h, m3d_malloc((void**)&a->d_stage, payload_bytes + payload_bytes / 2));
         a->stage_bytes = payload_bytes + payload_bytes / 2;
     }
     const size_t nblocks = (size_t(A.n) + 255) / 256;
@@ -1418,7 +1455,7 @@ int agg_add(m3dagg* a, M3dAggArgs& A, const void* host_payload, size_t payload_b
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (a->d_blocks) hipFree(a->d_blocks);
         a->d_blocks = nullptr; a->blocks_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&a->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 2 + 16)));
+        HIPCHK(h, m3d_malloc((void**)&a->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 2 + 16)));
         a->blocks_cap = nblocks + nblocks / 2 + 16;
     }
     HIPCHK(h, hipMemcpyAsync(a->d_stage, host_payload, payload_bytes, hipMemcpyHostToDevice, h->stream));
@@ -1449,8 +1486,8 @@ int m3dagg_create(m3dreg_handle* h, const double bbox[6], size_t capacity, m3dag
     m3dagg* a = new m3dagg();
     a->h = h; a->capacity = capacity;
     memcpy(a->bb, bbox, sizeof(a->bb));
-    hipError_t e = hipMalloc((void**)&a->d_pts, sizeof(float4) * capacity);
-    if (e == hipSuccess) e = hipMalloc((void**)&a->d_count, sizeof(uint32_t) * 2);
+    hipError_t e = m3d_malloc((void**)&a->d_pts, sizeof(float4) * capacity);
+    if (e == hipSuccess) e = m3d_malloc((void**)&a->d_count, sizeof(uint32_t) * 2);
     if (e == hipSuccess) e = hipMemsetAsync(a->d_count, 0, sizeof(uint32_t) * 2, h->stream);
     if (e != hipSuccess) { if (a->d_pts) hipFree(a->d_pts); if (a->d_count) hipFree(a->d_count); delete a; return fail(h, M3DREG_ERR_HIP, "m3dagg_create", e); }
     *out = a;
@@ -1619,7 +1656,7 @@ template <typename T> int cal_grow(m3dreg_handle* h, T*& p, size_t& cap, size_t 
     p = nullptr; cap = 0;
     const size_t c = need + need / 4 + 16;
     if (pinned) HIPCHK(h, hipHostMalloc((void**)&p, sizeof(T) * c, hipHostMallocDefault));
-    else HIPCHK(h, hipMalloc((void**)&p, sizeof(T) * c));
+    else HIPCHK(h, m3d_malloc((void**)&p, sizeof(T) * c));
     cap = c;
     return M3DREG_OK;
 }
@@ -1837,12 +1874,12 @@ int m3dmap_create(m3dreg_handle* h, float dedup_leaf, size_t capacity, m3dmap** 
     m->h = h; m->leaf = dedup_leaf; m->capacity = capacity;
     m->tsize = 1024; m->tbits = 10;
     while (m->tsize < 2u * uint32_t(capacity)) { m->tsize <<= 1; m->tbits++; }   // one voxel per kept point: load factor <= 1/2
-    hipError_t e = hipMalloc((void**)&m->d_pts, sizeof(float4) * capacity);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_count, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_flags, sizeof(uint32_t) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_keys, sizeof(unsigned long long) * m->tsize);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_epoch, sizeof(uint32_t) * m->tsize);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_owner, sizeof(uint32_t) * m->tsize);
+    hipError_t e = m3d_malloc((void**)&m->d_pts, sizeof(float4) * capacity);
+    if (e == hipSuccess) e = m3d_malloc((void**)&m->d_count, sizeof(uint32_t));
+    if (e == hipSuccess) e = m3d_malloc((void**)&m->d_flags, sizeof(uint32_t) * 4);
+    if (e == hipSuccess) e = m3d_malloc((void**)&m->d_keys, sizeof(unsigned long long) * m->tsize);
+    if (e == hipSuccess) e = m3d_malloc((void**)&m->d_epoch, sizeof(uint32_t) * m->tsize);
+    if (e == hipSuccess) e = m3d_malloc((void**)&m->d_owner, sizeof(uint32_t) * m->tsize);
     if (e != hipSuccess) { m3dmap_destroy(m); return fail(h, M3DREG_ERR_HIP, "m3dmap_create", e); }
     int rc = map_clear_device(m);
     if (rc) { m3dmap_destroy(m); return rc; }
@@ -1874,14 +1911,14 @@ int m3dmap_insert(m3dmap* m, const m3dreg_cloud* scan, const float T[16], size_t
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (m->d_slot_of) hipFree(m->d_slot_of);
         m->d_slot_of = nullptr; m->slot_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&m->d_slot_of, sizeof(uint32_t) * (n + n / 4 + 16)));
+        HIPCHK(h, m3d_malloc((void**)&m->d_slot_of, sizeof(uint32_t) * (n + n / 4 + 16)));
         m->slot_cap = n + n / 4 + 16;
     }
     if (nblocks > m->blocks_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (m->d_blocks) hipFree(m->d_blocks);
         m->d_blocks = nullptr; m->blocks_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&m->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 4 + 16)));
+        HIPCHK(h, m3d_malloc((void**)&m->d_blocks, sizeof(uint32_t) * (nblocks + nblocks / 4 + 16)));
         m->blocks_cap = nblocks + nblocks / 4 + 16;
     }
     if (scan->owner && scan->owner != h && scan->ready) HIPCHK(h, hipStreamWaitEvent(h->stream, scan->ready->ev, 0));
@@ -2018,10 +2055,10 @@ int m3dloop_create(m3dreg_handle* h, const m3dloop_params* P, m3dloop** out) {
     m3dloop* l = new m3dloop();
     l->h = h; l->P = *P; l->W = 1 << (P->sig_log2_bits - 5);
     const size_t cap = size_t(P->max_keyframes);
-    hipError_t e = hipMalloc((void**)&l->d_sig, sizeof(uint32_t) * cap * size_t(l->W));
-    if (e == hipSuccess) e = hipMalloc((void**)&l->d_pos, sizeof(float4) * cap);
-    if (e == hipSuccess) e = hipMalloc((void**)&l->d_ov, sizeof(uint32_t) * cap * size_t(LOOP_ROWS));
-    if (e == hipSuccess) e = hipMalloc((void**)&l->d_out, sizeof(uint2) * size_t(LOOP_ROWS) * size_t(P->top_k));
+    hipError_t e = m3d_malloc((void**)&l->d_sig, sizeof(uint32_t) * cap * size_t(l->W));
+    if (e == hipSuccess) e = m3d_malloc((void**)&l->d_pos, sizeof(float4) * cap);
+    if (e == hipSuccess) e = m3d_malloc((void**)&l->d_ov, sizeof(uint32_t) * cap * size_t(LOOP_ROWS));
+    if (e == hipSuccess) e = m3d_malloc((void**)&l->d_out, sizeof(uint2) * size_t(LOOP_ROWS) * size_t(P->top_k));
     if (e == hipSuccess) e = hipEventCreate(&l->ev0);
     if (e == hipSuccess) e = hipEventCreate(&l->ev1);
     if (e != hipSuccess) { m3dloop_destroy(l); return fail(h, M3DREG_ERR_HIP, "m3dloop_create", e); }
@@ -2270,8 +2307,8 @@ int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint
     if (pm_host) HIPCHK(h, hipMemcpyAsync(pm_host, L.perm, 4 * n, hipMemcpyDeviceToHost, h->stream));
     float *dx = nullptr, *dn = nullptr;
     if (sorted_xyz || normals) {
-        HIPCHK(h, hipMalloc((void**)&dx, 12 * n));
-        if (normals) { hipError_t e = hipMalloc((void**)&dn, 12 * n); if (e != hipSuccess) { hipFree(dx); return fail(h, M3DREG_ERR_HIP, "hipMalloc", e); } }
+        HIPCHK(h, m3d_malloc((void**)&dx, 12 * n));
+        if (normals) { hipError_t e = m3d_malloc((void**)&dn, 12 * n); if (e != hipSuccess) { hipFree(dx); return fail(h, M3DREG_ERR_HIP, "hipMalloc", e); } }
         hipError_t e = m3d_launch_export_sorted(h->stream, L.pts, normals ? L.nrm : nullptr, int(n), dx, dn);
         if (e == hipSuccess && sorted_xyz) e = hipMemcpyAsync(sorted_xyz, dx, 12 * n, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && normals) e = hipMemcpyAsync(normals, dn, 12 * n, hipMemcpyDeviceToHost, h->stream);
@@ -2312,9 +2349,9 @@ int m3dreg_debug_nn(m3dreg_handle* h, const m3dreg_cloud* target, int level, con
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     float* dq = nullptr; int32_t* di = nullptr; float* dd = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dq, 12 * nq));
-    hipError_t e = hipMalloc((void**)&di, 4 * nq);
-    if (e == hipSuccess) e = hipMalloc((void**)&dd, 4 * nq);
+    HIPCHK(h, m3d_malloc((void**)&dq, 12 * nq));
+    hipError_t e = m3d_malloc((void**)&di, 4 * nq);
+    if (e == hipSuccess) e = m3d_malloc((void**)&dd, 4 * nq);
     if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = m3d_launch_debug_nn(h->stream, level_dev(target->lv[level]), dq, int(nq), max_corr_dist * max_corr_dist, di, dd);
     if (e == hipSuccess) e = hipMemcpyAsync(out_idx, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
@@ -2335,8 +2372,8 @@ int m3dreg_debug_candidates(m3dreg_handle* h, const m3dreg_cloud* target, int le
     { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(target)); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     float* dq = nullptr; int32_t* di = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dq, 12 * nq));
-    hipError_t e = hipMalloc((void**)&di, 4 * nq);
+    HIPCHK(h, m3d_malloc((void**)&dq, 12 * nq));
+    hipError_t e = m3d_malloc((void**)&di, 4 * nq);
     if (e == hipSuccess) e = hipMemcpyAsync(dq, queries_xyz, 12 * nq, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = m3d_launch_debug_candidates(h->stream, level_dev(target->lv[level]), dq, int(nq), di);
     if (e == hipSuccess) e = hipMemcpyAsync(out_count, di, 4 * nq, hipMemcpyDeviceToHost, h->stream);
@@ -2417,6 +2454,30 @@ int m3dreg_debug_trace(m3dreg_handle* h, double* poses, size_t cap, size_t* n_ou
     });
 }
 
+#ifdef M3D_CHECKED
+}  // extern "C"
+extern "C" hipError_t m3d_chk_read_icp(unsigned int* out, int reset);
+extern "C" hipError_t m3d_chk_read_bucket(unsigned int* out, int reset);
+extern "C" {
+#endif
+// The diagnosis build's report (libm3dreg_checked.so: -DM3D_CHECKED): out[0..3] = {offences, site, index, bound} of the iteration kernels (icp.hip), out[4..7] of the
+// bucketing pipeline (bucket.hip); the first offence of each is kept. The shipped library has no checks compiled in and answers M3DREG_ERR_INVALID_ARG.
+int m3dreg_debug_checks(m3dreg_handle* h, uint32_t out[8], int reset) {
+    return m3d_guarded(h, "m3dreg_debug_checks", [&]() -> int {
+    if (!h || !out) return M3DREG_ERR_INVALID_ARG;
+#ifdef M3D_CHECKED
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, m3d_chk_read_icp(out, reset));
+    HIPCHK(h, m3d_chk_read_bucket(out + 4, reset));
+    return M3DREG_OK;
+#else
+    (void)reset;
+    for (int i = 0; i < 8; i++) out[i] = 0u;
+    return fail(h, M3DREG_ERR_INVALID_ARG, "m3dreg_debug_checks: this is not the checked build (make checked: libm3dreg_checked.so)");
+#endif
+    });
+}
 int m3dreg_debug_fail_alloc(int nth) { g_fail_alloc.store(nth > 0 ? nth : 0); return M3DREG_OK; }
 int m3dreg_debug_throw(int kind) {
     return m3d_guarded(nullptr, "m3dreg_debug_throw", [&]() -> int {

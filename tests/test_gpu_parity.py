@@ -851,7 +851,7 @@ def _config4_shards(world=8, per_rank=8):
     import json, os
     from mandala_mapping_amd import sharding
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    costs = json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json")))["costs"][: world * per_rank]
+    costs, _ = sharding.table_costs(json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json"))), world * per_rank)   # (the measured costs where the table has them)
     return sharding.lpt_assign(costs, world, capacity=per_rank)
 
 

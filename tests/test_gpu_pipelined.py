@@ -20,7 +20,7 @@ def _shards():
     import json, os
     from mandala_mapping_amd import sharding
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    costs = json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json")))["costs"][:64]
+    costs, _ = sharding.table_costs(json.load(open(os.path.join(root, "mandala_mapping_amd", "config4_costs.json"))), 64)
     return sharding.lpt_assign(costs, 8, capacity=8)
 
 
@@ -78,14 +78,18 @@ def _resident(torch, pairs):
     return out
 
 
-@pytest.mark.parametrize("which", [6, 0])
+R5_SHARDS = {"r5_shard6": [8, 10, 15, 22, 29, 41, 51, 52], "r5_shard0": [2, 19, 20, 24, 31, 35, 50, 59]}   # profiles/r05_shards.txt
+
+
+@pytest.mark.parametrize("which", ["r5_shard6", "r5_shard0", "heaviest_now"])
 def test_headline_schedule_every_step_equals_the_single_handle(reg, which):
-    """Shard 6 (the shard of round 5's one unexplained GPU memory fault) and shard 0 (the heaviest: pair 31) of BASELINE config 4 at full size,
-    240 steps of the headline schedule each: eight handles / four streams / two queued per stream, brackets every 7th iteration. Every step ==
-    the single-handle synchronous result, poses and statistics, byte for byte; and the poses are on the generator's ground truth."""
+    """BASELINE config 4 at full size under the headline's schedule, 240 steps per shard: the shard round 5's one unexplained GPU memory fault happened on
+    (its shard 6), that round's heaviest (shard 0: pair 31) and the shard that holds pair 31 in the table `bench.py --gpus 8` uses now. Eight handles / four
+    streams / two queued per stream, brackets every 7th iteration. Every step == the single-handle synchronous result, poses and statistics, byte for byte;
+    and the poses are on the generator's ground truth."""
     import torch
     p = abi.Params.make(leaf=0.1, iterations=20, max_corr_dist=0.5, metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
-    shard = _shards()[which]
+    shard = R5_SHARDS[which] if which in R5_SHARDS else [x for x in _shards() if 31 in x][0]
     data = [synth.config4_pair(k) for k in shard]
     pay = _resident(torch, data)
     R = reg.Registrar(p)
