@@ -85,7 +85,6 @@ def parse():
     ap.add_argument("--async-calls", action="store_true", help="serial steps (--inflight 1 --queue-depth 1) through m3dreg_align_batch_async + m3dreg_batch_wait instead of the synchronous "
                                                                "m3dreg_align_batch: one launch chain per step, no internal chains (the figure rounds 1-4 called `serial`)")
     ap.add_argument("--no-latency-mode", action="store_true", help="serial synchronous steps WITHOUT m3dreg_set_latency_mode (the serial caller's statement that its batches have the GPU to themselves, ABI 7)")
-    ap.add_argument("--batch-chains", type=int, default=None, help="m3dreg_set_batch_chains for every handle (the synchronous call's internal chains: 1 = none, default: the library's)")
     ap.add_argument("--no-extra", action="store_true", help="headline only: do not run the other configurations / variants as child runs")
     ap.add_argument("--all-legs", action="store_true", help="also the legs the default run leaves out to stay short (batch16 / batch32 / batch64 with two chains, from_host_converge)")
     ap.add_argument("--verify-steps", action="store_true",
@@ -392,9 +391,6 @@ def main():
     sync_result = [None]
     if serial_calls and not args.no_latency_mode:   # what a serial caller — the ROS node — tells the library (include/m3dreg.h, ABI 7); never in the headline: its handles share the GPU
         regs[0].set_latency_mode(True)
-    if args.batch_chains is not None:
-        for r_ in regs:
-            r_.set_batch_chains(args.batch_chains)
 
     force_shard = [None]   # per-shard timing of --rotate-pairs: every step registers this shard
 
@@ -407,7 +403,7 @@ def main():
         clouds = make_clouds(bregs[i % len(bregs)], shard_of(i))
         tb = time.perf_counter()
         arr = r._pairs([(s_, t_, inits[j]) for j, (s_, t_) in enumerate(clouds)])
-        if serial_calls:   # a serial caller's call: the synchronous m3dreg_align_batch (which spreads a batch over internal chains: include/m3dreg.h)
+        if serial_calls:   # a serial caller's call: the synchronous m3dreg_align_batch 
             sync_result[0] = r.align_batch_arr(arr, B)
         else:
             r.align_batch_async(arr, B)

@@ -17,19 +17,12 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no exceptions cross the boundary, every function
  *     returns an int status (0 = M3DREG_OK, <0 = m3dreg_error).
- *   - Threading: one handle = one device + one HIP stream + the state of one batch (with m3dreg_set_batch_chains the synchronous
- *     m3dreg_align_batch also drives up to three internal child handles, forked from and joined to the handle's stream); a handle is not
- *     thread-safe, different handles are independent. No global mutable state shapes a result or a
- *     schedule (ABI 5; the only process-wide word is a creation counter that places a handle's pairs
- *     on the XCDs). What a registration launches is a function of the batch — with one documented
- *     exception, per handle: it remembers at which levels its last finished batch met a dense target
- *     (more than 24 points per voxel; more than 8 on a level that starts from a coarser one; or a map:
- *     more than 6 and at least 4 x the source) in some / in
- *     every pair and launches the dense-level search kernel only there (alone where it was every pair;
- *     a handle's first batch: behind the ordinary one at every level). A batch whose SHAPE differs from the
- *     last one's (every target >= 4 x its source / none / mixed: host-known sizes) is scheduled like a first batch.
- *     A wrong guess costs time — at worst one empty 5 us launch per iteration, or an ordinary pair answered by
- *     the dense-level kernel at roughly twice its usual search time — never a bit.
+ *   - Threading: one handle = one device + one HIP stream + the state of one batch; a handle is not thread-safe, different handles are
+ *     independent. No global mutable state shapes a result or a schedule (the only process-wide word is a creation counter that places a
+ *     handle's pairs on the XCDs), and (ABI 8) no per-handle history does either: what a registration launches is a function of the batch —
+ *     its sizes, levels, whether its targets have tiles, and, for the dense-level search kernel, the clouds' own voxel counts where the host
+ *     has read them back (every synchronous creation call does); for clouds it has not, both search kernels are launched and the device
+ *     decides pair by pair (an empty launch costs ~5 us, never a bit).
  *   - Poses map SOURCE-frame points into the TARGET frame: p_target = T * p_source.
  *   - All results are bit-reproducible: they do not depend on launch geometry, scheduling or
  *     atomics order (integer fixed-point normal-equation sums).
@@ -55,9 +48,10 @@ extern "C" {
                                      per device; m3dreg_default_params is a coarse-to-fine pyramid (see there)
                                   5: + m3dreg_pair_desc.target_group (shared targets are co-located and bucketed once), m3dagg_set_scan_trig,
                                      m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight
-                                  6: + m3dreg_set_batch_chains (opt-in: the SYNCHRONOUS m3dreg_align_batch may cut a batch of >= 4 pairs into internal
-                                     launch chains, same results); m3dreg_pair_desc.reserved must be 0
-                                  7: + m3dreg_set_latency_mode (a serial caller states that its batches have the GPU to themselves) */
+                                  6: m3dreg_pair_desc.reserved must be 0 (+ m3dreg_set_batch_chains, removed again in 8)
+                                  7: + m3dreg_set_latency_mode (a serial caller states that its batches have the GPU to themselves)
+                                  8: + m3dloop_* (loop-closure candidate generation), m3dagg_set_rearm, m3dreg_debug_checks; - m3dreg_set_batch_chains (internal launch chains
+                                     lost on every workload measured); the dense-level schedule is decided per batch, no longer from the handle's previous batch */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
 
@@ -210,30 +204,17 @@ int m3dreg_cloud_create_pc2(m3dreg_handle* h, const void* data, size_t data_byte
 int m3dreg_cloud_destroy(m3dreg_handle* h, m3dreg_cloud* c);
 int m3dreg_align_clouds(m3dreg_handle* h, const m3dreg_cloud* source, const m3dreg_cloud* target,
                         const float init_T[16], float out_T[16], m3dreg_stats* stats);
-/* Registers n_pairs independent pairs on this handle's device and waits for them: one launch chain, one launch per stage and
- * Gauss-Newton iteration for the whole batch. out_T: 16*n_pairs floats.
- * (ABI 6, opt-in) m3dreg_set_batch_chains(h, k), 2 <= k <= 4: this synchronous call cuts a batch of >= 4 pairs into up to k
- * contiguous parts (at least two pairs each) that run as independent launch chains, the first on the handle's stream, the others
- * on streams of internal child handles, forked from and joined to the handle's stream with events: work enqueued on that stream
- * before the call is complete before any part starts, work enqueued after it starts after every part. Bit-identical results for
- * every cut. Default (k = 0 or 1, environment M3DREG_BATCH_CHAINS): no cut — measured on 8 x 100 k-point pairs the cut LOSES (4982
- * registrations/s as one chain, 4642 as two, 3233 as four: the iteration kernels are latency-bound at a duration that does not
- * shrink with the batch); it exists for callers with many small pairs. To keep the GPU busy across calls use the asynchronous
- * pair below with two handles: the bucketing of the next batch then runs under the iterations of this one (bench.py's headline).
- * m3dreg_align_batch_async never cuts; while event brackets are on (m3dreg_profile_enable) a batch runs as one chain.
- * Convergence-terminated batches (eps_rot / eps_trans > 0): this call — it waits for the batch anyway — keeps its enqueue four iterations
- * ahead of the device and stops a level as soon as the device reports it finished; m3dreg_align_batch_async, which must not block,
- * enqueues on and lets the launches behind a finished level leave at once (~5 us each). Same results. */
+/* Registers n_pairs independent pairs on this handle's device and waits for them: one launch chain, one launch per stage and Gauss-Newton iteration for the
+ * whole batch. out_T: 16 * n_pairs floats. To keep the GPU busy ACROSS calls use the asynchronous pair below with several handles (bench.py's headline: the
+ * bucketing of the next batch runs under the iterations of this one). Convergence-terminated batches (eps_rot / eps_trans > 0): this call — it waits for the
+ * batch anyway — keeps its enqueue four iterations ahead of the device and stops a level as soon as the device reports it finished;
+ * m3dreg_align_batch_async, which must not block, enqueues on and lets the launches behind a finished level leave at once (~5 us each). Same results. */
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T,
                        m3dreg_stats* stats);
-int m3dreg_set_batch_chains(m3dreg_handle* h, int chains);
 /* (ABI 7) A caller that makes ONE call at a time on this GPU — the ROS node: one spin thread, one registration or one batch per sweep
- * (m3d_aggregator.cpp:185) — says so: on != 0 sizes this handle's launch grids for a GPU it has to itself (the reduction pass takes all
- * three workgroups a CU holds — 768 per batch — where the default, sized for a GPU that other batches share, takes 448): +6 % for
- * synchronous 8-pair steps, measured; -4 % when other handles' batches DO share the GPU (bench.py's headline keeps four in flight:
- * leave it off there). Same results either way (the sums are
- * integers). The library never guesses this from what the process has in flight. Refused (M3DREG_ERR_INVALID_ARG) between
- * m3dreg_align_batch_async and its wait. Default off. */
+ * (m3d_aggregator.cpp:185) — says so: on != 0 sizes this handle's launch grids for a GPU it has to itself (measurements: DESIGN.md §5). Leave it off when
+ * other handles' batches share the GPU. Same results either way (the sums are integers); the library never guesses this from what the process has in
+ * flight. Refused (M3DREG_ERR_INVALID_ARG) between m3dreg_align_batch_async and its wait. Default off. */
 int m3dreg_set_latency_mode(m3dreg_handle* h, int on);
 /* Enqueue only (no host sync); results are fetched by m3dreg_batch_wait. A handle holds the state of ONE batch: a second
  * m3dreg_align_batch_async before the wait is refused (M3DREG_ERR_INVALID_ARG) — to queue batches behind each other, give

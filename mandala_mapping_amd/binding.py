@@ -25,7 +25,7 @@ _lib = None
 EXPORTS = [
     "m3dreg_default_params", "m3dreg_create", "m3dreg_destroy", "m3dreg_backend_name", "m3dreg_last_error",
     "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
-    "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_set_batch_chains", "m3dreg_set_latency_mode", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
+    "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_set_latency_mode", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
     "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
@@ -124,7 +124,6 @@ def lib():
     L.m3dcal_twiddle.argtypes = [vp, C.c_int, f32p, f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.m3dcal_anneal.argtypes = [vp, C.c_uint, f32p, f32p, C.POINTER(C.c_int)]
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.m3dreg_set_batch_chains.argtypes = [vp, C.c_int]
     L.m3dreg_set_latency_mode.argtypes = [vp, C.c_int]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
@@ -379,10 +378,6 @@ class Registrar:
         st = (abi.Stats * k)()
         self._check(lib().m3dreg_align_batch(self._h, pairs_arr, k, _ptr(out, C.c_float), st), "align_batch")
         return np.stack([colmajor16_to_T(out[i]) for i in range(k)]), list(st)
-
-    def set_batch_chains(self, chains):
-        """internal launch chains of the synchronous align_batch (opt-in): 0 / 1 = one chain (the default), k <= 4"""
-        self._check(lib().m3dreg_set_batch_chains(self._h, int(chains)), "set_batch_chains")
 
     def set_latency_mode(self, on=True):
         """ABI 7: this handle's batches have the GPU to themselves (a serial caller — the ROS node): launch grids sized for latency; same results"""

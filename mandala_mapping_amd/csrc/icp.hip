@@ -2418,7 +2418,6 @@ __global__ void k_patch_jobs(M3dJob* __restrict__ jobs, int n_pairs, int cap_pai
     J.tgt.g = g;
     if (M->dyn[7] == 0u) J.tgt.occ = nullptr;   // the grid has more bucket positions than the occupancy bitmap covers
     J.coop_always = m3d_dense_level((uint32_t)M->g.n_valid, M->dyn[0], (uint32_t)MS->g.n_valid, t / n_pairs) ? 1 : 0;
-    if (J.coop_always) atomicOr(&J.st->coop_levels, 1u << (t / n_pairs));
     J.n_src = MS->g.n_valid;
     int32_t e[6]; float S[6];
     m3d_fixed_exps(M->lbound, J.dmax, e, S);

@@ -136,7 +136,7 @@ struct M3dPairState {      // per-registration state, lives in HBM for the whole
     int32_t status;
     int32_t done;                  // final: no further iteration may run
     int32_t level_done;            // current level converged: skip its remaining iterations
-    uint32_t coop_levels;          // bit l: this pair's target level l is crowded (k_patch_jobs: J.coop_always) — read back with the state, the handle launches k_nn_coop at a level only where the last batch had such a pair
+    uint32_t pad0;
     uint32_t ctr[2];               // diagnostics: searches answered from LDS tiles / by the global walk of the fallback blocks
     uint32_t gsync[2];             // pair 0 only: {pairs that reported this iteration, of which still active} (k_solve_update)
 };

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -119,12 +120,11 @@ struct m3dreg_handle {
     M3dPairState* h_states = nullptr;  // pinned
     double* h_trace = nullptr;         // pinned
     size_t pending_pairs = 0;
-    bool coop_known = false;       // a batch of this handle has finished: coop_seen holds the levels at which one of its pairs had a crowded target (M3dPairState::coop_levels)
-    uint32_t coop_seen = 0;
-    uint32_t coop_all = 0;         // ... and the levels at which EVERY pair of that batch had one
-    int coop_shape = -1;           // ... and that batch's SHAPE (host-known sizes): 0 = every target smaller than 4 x its source, 1 = every target a map (>= 4 x), 2 = mixed. A batch of
-                                   // another shape (scan-to-map after scan pairs or the other way round) is scheduled like a handle's first batch: what the last one met says nothing about it
-    int batch_shape = -1;          // shape of the batch being enqueued (build_jobs)
+    // The dense-level schedule of the batch being enqueued, per level (build_jobs; ABI 8: a function of the batch alone — rounds 4-5 remembered the handle's LAST batch):
+    // 0 = no pair's target level is dense (k_nn_coop is not launched), 2 = every pair's is (k_nn_coop is the only search launch), 1 = some are — or the host
+    // cannot tell: a cloud of the batch came out of the enqueue-only bucketing and nobody has read its counts back yet (then both kernels are launched and the
+    // device-side flags decide, pair by pair: an empty launch costs ~5 us, never a bit).
+    uint8_t dense_level[M3DREG_MAX_LEVELS] = { 1, 1, 1, 1 };
     size_t last_trace_n = 0;
     // gpu_6dslam_node surface
     m3dreg_cloud* target = nullptr;
@@ -167,21 +167,12 @@ struct m3dreg_handle {
     uint64_t prof_launches[5] = { 0, 0, 0, 0, 0 };   // M3DREG_PROFILE_*: iteration, correspondence step, bucketing batch, reduce + solve, all iterations of a batch (launches = iterations enqueued)
     double prof_ms[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
     uint64_t chain_iters = 0;          // iterations enqueued between the open kind-5 event and its kind-6 partner
-    // the batch being enqueued (batch_begin / batch_step / batch_end): m3dreg_align_batch_async runs them back to back, the synchronous m3dreg_align_batch
-    // interleaves the steps of several internal chains
-    struct Run { size_t n_pairs = 0; int max_n_src = 0; int l = 0, it = 0; bool can_stop_early = false, prev_sampled = false; uint64_t iters_before = 0; unsigned int level_first_seq = 0; } run;
-    // internal chains of the SYNCHRONOUS m3dreg_align_batch (include/m3dreg.h): child handles with streams of their own, created on first use; a child never
-    // owns a cloud and is released with its parent
-    std::vector<m3dreg_handle*> lanes;
-    hipEvent_t fork_ev = nullptr;      // recorded on this handle's stream in front of a split batch: the lanes' streams wait for it
-    std::vector<hipEvent_t> join_ev;   // recorded behind a lane's part of the batch: this handle's stream waits for them
-    std::vector<size_t> split;         // pairs per chain of the split batch awaiting m3dreg_batch_wait (empty: not split)
+    // the batch being enqueued (batch_begin / batch_step / batch_end)
+    struct Run { size_t n_pairs = 0; int max_n_src = 0; int l = 0, it = 0; bool can_stop_early = false, prev_sampled = false, throttle_off = false; uint64_t iters_before = 0; unsigned int level_first_seq = 0; } run;
     hipEvent_t done_ev = nullptr;      // recorded behind a batch's last operation (m3dreg_batch_wait waits for it, not for the whole stream)
     bool done_recorded = false;
     bool throttle = false;             // inside the synchronous m3dreg_align_batch: the enqueue of a convergence-terminated batch stays a few iterations ahead of the device, not a level
     int alone = 0;                     // m3dreg_set_latency_mode: this handle's batches have the GPU to themselves (grids sized for latency)
-    int batch_chains = 0;              // m3dreg_set_batch_chains: 0 = library default, 1 = never split, k = at most k chains
-    bool is_lane = false;
 };
 
 namespace {
@@ -247,6 +238,17 @@ hipError_t m3d_malloc(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) e = poison(*p, bytes, nullptr);
     return e;
+}
+
+// one polite busy-wait step of the synchronous call's throttle (x86: pause; aarch64: yield; anything else: the scheduler's yield)
+inline void m3d_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
 }
 
 const size_t POOL_CAP_BYTES = size_t(16) << 30;   // cached, unused cloud blocks kept for reuse
@@ -745,14 +747,9 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     // every one of their iterations — 16 launches of a config-5 registration, 60 of config 2's)
     w.tiles = (h->tiles && (level < 0 || level == h->params.n_levels - 1)) ? 1 : 0;
     w.lean = (h->lean && h->batch_all_tiles && lean_here) ? 1 : 0;
-    // k_nn_coop behind k_nn_iter<false> on a pyramid's coarser levels, where the handle's last finished batch had a crowded target level (and on a handle's
-    // first batch: it is not known yet) — on ordinary clouds the launch is empty and costs its 5 us in every iteration of the level. The ONE piece of
-    // adaptive state the library keeps (per handle, include/m3dreg.h "Threading"): a wrong guess costs time, never a bit — without the launch
-    // k_nn_iter<false> answers the crowded pairs itself, in eight passes per workgroup.
-    // (round 4: on every level, the finest included — a 2 M-point map is dense for a 100 k-point scan at 0.1 m too, m3d_dense_level — and alone where every
-    // pair of the last batch was dense: k_nn_coop answers ordinary pairs as well, only slower)
-    const bool coop_level = level >= 0;
-    w.coop_kernel = !coop_level ? 0 : (h->coop_known && ((h->coop_all >> level) & 1u)) ? 2 : (!h->coop_known || ((h->coop_seen >> level) & 1u)) ? 1 : 0;
+    // k_nn_coop (icp.hip) answers the pairs whose target level is DENSE (m3d_dense_level: a coarse level of a pyramid, a map): behind k_nn_iter<false> where some
+    // pairs of the batch are dense, alone where all are, not at all where none is — decided per batch and level in build_jobs from the clouds' own counts.
+    w.coop_kernel = level >= 0 ? int(h->dense_level[level]) : 0;
     // a dense level's later iterations: most queries are certified (config 5: 74 % at the end of its first level, 93-98 % on the levels that start from a coarser
     // level's result) — from the 4th iteration of a registration's first level (1: per 64 queries) and the 2nd of every other one (2: per 128) the searchers
     // are compacted (k_nn_coop_list).
@@ -780,13 +777,8 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
     const m3dreg_params& P = h->params;
     max_n_src = 0; max_n_tgt = 0;
     h->batch_all_tiles = h->tiles != 0;
-    {   // the batch's shape; a change of shape forgets the dense-level memory (the latency of an ordinary batch behind a scan-to-map batch)
-        bool any_map = false, any_plain = false;
-        for (size_t i = 0; i < n_pairs; i++)
-            if (pairs[i].source && pairs[i].target) { if ((long long)pairs[i].target->n >= 4ll * (long long)pairs[i].source->n) any_map = true; else any_plain = true; }
-        h->batch_shape = any_map ? (any_plain ? 2 : 1) : 0;
-        if (h->coop_known && h->batch_shape != h->coop_shape) h->coop_known = false;
-    }
+    bool dense_any[M3DREG_MAX_LEVELS] = {}, dense_all[M3DREG_MAX_LEVELS], dense_unknown = false;
+    for (int l = 0; l < M3DREG_MAX_LEVELS; l++) dense_all[l] = true;
     for (size_t i = 0; i < n_pairs; i++) {
         const m3dreg_cloud* s = pairs[i].source;
         const m3dreg_cloud* t = pairs[i].target;
@@ -800,6 +792,14 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         if (s->n > max_n_src) max_n_src = s->n;   // launch geometry only (the finite count stays on the device; results do not depend on it)
         if (t->n > max_n_tgt) max_n_tgt = t->n;
         if (!t->has_tiles) h->batch_all_tiles = false;   // (then the tile iterations keep the full k_nn_iter, which walks such a pair's searches itself)
+        // the dense-level schedule: the same rule on the same numbers as the device's (k_patch_jobs: J.coop_always), when the host has them — a cloud whose geometry
+        // and counts were read back (every synchronous creation call does; m3dreg_cloud_status / _grid_info / _density do) — else "unknown"
+        if (s->meta_ready && t->meta_ready && !s->err && !t->err) {
+            for (int l = 0; l < P.n_levels; l++) {
+                const bool d = m3d_dense_level(uint32_t(t->n_valid), t->lv[l].n_cells_host, uint32_t(s->n_valid), l);
+                dense_any[l] = dense_any[l] || d; dense_all[l] = dense_all[l] && d;
+            }
+        } else dense_unknown = true;
         for (int l = 0; l < P.n_levels; l++) {
             M3dJob& J = h->h_jobs[size_t(l) * h->cap_pairs + i];
             memset(&J, 0, sizeof(J));
@@ -824,6 +824,7 @@ int build_jobs(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, int& 
         for (int k = 0; k < 16; k++) S.T[k] = double(pairs[i].init_T[k]);
         S.status = M3DREG_MAX_ITERATIONS;
     }
+    for (int l = 0; l < M3DREG_MAX_LEVELS; l++) h->dense_level[l] = uint8_t(dense_unknown ? 1 : (dense_all[l] ? 2 : (dense_any[l] ? 1 : 0)));
     return M3DREG_OK;
 }
 
@@ -883,11 +884,7 @@ void roctx_pop() {
 void release_handle(m3dreg_handle* h) {
     hipSetDevice(h->device);
     sync_handle(h);
-    for (m3dreg_handle* lane : h->lanes) release_handle(lane);   // (a lane owns no cloud)
-    h->lanes.clear();
     if (h->done_ev) hipEventDestroy(h->done_ev);
-    if (h->fork_ev) hipEventDestroy(h->fork_ev);
-    for (hipEvent_t e : h->join_ev) hipEventDestroy(e);
     for (Block& b : h->pool) hipFree(b.p);
     if (h->ws.p) hipFree(h->ws.p);
     if (h->h_ws) hipHostFree(h->h_ws);
@@ -1138,10 +1135,16 @@ static int batch_step(m3dreg_handle* h) {
 #define M3D_AHEAD_ITERS 4
 #endif
                 constexpr unsigned int M3D_AHEAD = M3D_AHEAD_ITERS;
-                for (int spin = 0; spin < 200000; spin++) {   // (bounded: a device that stopped reporting only costs the wait)
-                    const unsigned int done = (unsigned int)(*h->h_progress >> 32);
-                    if (h->seq - done <= M3D_AHEAD || done > h->seq) break;   // (done > seq: a word of an earlier life of the counter)
-                    __builtin_ia32_pause();
+                // (bounded by TIME, ADVICE r5: a GPU that is busy with other handles' work — a batch queued ahead on a shared stream — must not cost this caller a
+                // core for milliseconds per iteration: after one wait of more than 2 ms the rest of this batch is enqueued unthrottled)
+                if (!R.throttle_off) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (unsigned int spin = 1;; spin++) {
+                        const unsigned int done = (unsigned int)(*h->h_progress >> 32);
+                        if (h->seq - done <= M3D_AHEAD || done > h->seq) break;   // (done > seq: a word of an earlier life of the counter)
+                        m3d_cpu_relax();
+                        if ((spin & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { R.throttle_off = true; break; }
+                    }
                 }
             }
             const unsigned long long v = *h->h_progress;
@@ -1215,26 +1218,11 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     if (!h || h->pending_pairs == 0) return fail(h, M3DREG_ERR_INVALID_ARG, "batch_wait: nothing pending");
     if (h->done_recorded) { HIPCHK(h, hipEventSynchronize(h->done_ev)); h->done_recorded = false; }
     else HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (!h->split.empty()) {   // a batch the synchronous call spread over internal chains: this stream has waited for the lanes' (join events)
-        size_t off = h->split[0];
-        for (size_t c = 1; c < h->split.size(); c++) {
-            m3dreg_handle* lane = h->lanes[c - 1];
-            const int rc = m3dreg_batch_wait(lane, out_T ? out_T + 16 * off : nullptr, stats ? stats + off : nullptr);
-            if (rc) { h->err = lane->err; h->split.clear(); h->pending_pairs = 0; return rc; }
-            off += h->split[c];
-        }
-        h->split.clear();
-    }
     if (h->ev_used) drain_events(h);
     for (size_t i = 0; i < h->pending_pairs; i++) {
         const M3dPairState& S = h->h_states[i];
         if (out_T) for (int k = 0; k < 16; k++) out_T[16 * i + k] = float(S.T[k]);
         if (stats) stats_from_state(S, &stats[i]);
-    }
-    {
-        uint32_t seen = 0, all = 0xFFFFFFFFu;
-        for (size_t i = 0; i < h->pending_pairs; i++) { seen |= h->h_states[i].coop_levels; all &= h->h_states[i].coop_levels; }
-        h->coop_seen = seen; h->coop_all = h->pending_pairs ? all : 0u; h->coop_known = true; h->coop_shape = h->batch_shape;
     }
     int it0 = h->h_states[0].iters;
     h->last_trace_n = size_t(it0 < M3D_MAX_TRACE ? it0 : M3D_MAX_TRACE);
@@ -1243,93 +1231,21 @@ int m3dreg_batch_wait(m3dreg_handle* h, float* out_T, m3dreg_stats* stats) {
     });
 }
 
-// Internal launch chains of the SYNCHRONOUS call (ABI 6, opt-in: m3dreg_set_batch_chains / M3DREG_BATCH_CHAINS): a batch of >= 4 pairs is cut into up to 4
-// contiguous parts that run as independent launch chains, the first on the handle's stream, the others on streams of internal child handles (fork / join
-// with events on the handle's stream: everything enqueued on it before the call is done before any part starts, everything enqueued after the call starts
-// after all parts). Results do not depend on the cut: every pair's sums are integers, its schedule inside a chain is the schedule of a smaller batch, which
-// gives the same bits (tests/test_gpu_parity.py: test_internal_chains_...). MEASURED (profiles/r05_batch_chains.txt, 8 pairs x 100 k per call, serial
-// calls): 1 chain 4982 registrations/s, 2 chains 4642, 3 chains 4430, 4 chains 3233; 64 pairs: 7179 / 7110 / - / 6449. The iteration kernels of one chain
-// are latency-bound at a duration that hardly shrinks with the batch (k_nn_tiles' persistent grid, the reduction's few hundred workgroups, the serial solve tail), so
-// two half-size chains each take ~85 % of the full chain's time and share the chip: the split loses. What round 4 measured as "two 4-pair chains beat one
-// 8-pair chain" (5553 vs 4755) was two STEPS in flight — the bucketing of step i + 1 under the iterations of step i — which a caller gets from the
-// asynchronous API (two handles), not from a cut inside one call. Hence the default: one chain.
-static int chains_for(const m3dreg_handle* h, size_t n_pairs) {
-    if (h->is_lane || h->profiling || n_pairs < 4) return 1;   // (event brackets describe ONE chain)
-    int want = h->batch_chains;
-    if (want == 0) { static const int env = [] { const char* v = getenv("M3DREG_BATCH_CHAINS"); return v ? atoi(v) : 0; }(); want = env > 0 ? env : 1; }
-    if (want > 4) want = 4;
-    const int by_size = int(n_pairs / 2);   // at least two pairs per chain
-    return want < by_size ? want : by_size;
-}
-
 int m3dreg_set_latency_mode(m3dreg_handle* h, int on) {
     if (!h || h->pending_pairs) return M3DREG_ERR_INVALID_ARG;   // (not between an asynchronous call and its wait: the batch's grids are laid out)
     h->alone = on ? 1 : 0;
     return M3DREG_OK;
 }
 
-int m3dreg_set_batch_chains(m3dreg_handle* h, int chains) {
-    if (!h || chains < 0) return M3DREG_ERR_INVALID_ARG;
-    h->batch_chains = chains;
-    return M3DREG_OK;
-}
-
 int m3dreg_align_batch(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pairs, float* out_T, m3dreg_stats* stats) {
     return m3d_guarded(h, "m3dreg_align_batch", [&]() -> int {
     if (!h || !pairs || n_pairs == 0 || n_pairs > 65535) return fail(h, M3DREG_ERR_INVALID_ARG, "align_batch: bad argument");
-    const int K = chains_for(h, n_pairs);
-    if (K <= 1) {
-        h->throttle = true;
-        int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
-        h->throttle = false;
-        if (rc) return rc;
-        return m3dreg_batch_wait(h, out_T, stats);
-    }
-    HIPCHK(h, hipSetDevice(h->device));
-    while (int(h->lanes.size()) < K - 1) {   // child handles: same parameters and device, a stream of their own
-        m3dreg_handle* lane = nullptr;
-        int rc = m3dreg_create(&h->params, h->device, nullptr, &lane);
-        if (rc) return fail(h, rc, "align_batch: could not create an internal chain");
-        lane->is_lane = true; lane->certify = h->certify; lane->tiles = h->tiles; lane->lean = h->lean; lane->fuse_from = h->fuse_from; lane->tile_iters = h->tile_iters;
-        alloc_point();
-        h->lanes.push_back(lane);
-        hipEvent_t e = nullptr;
-        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->join_ev.push_back(e);
-    }
-    if (!h->fork_ev) HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-    std::vector<size_t> part(size_t(K), n_pairs / size_t(K));   // contiguous parts, the first n % K one pair longer: a function of n_pairs and K alone
-    for (size_t c = 0; c < n_pairs % size_t(K); c++) part[c]++;
-    std::vector<m3dreg_handle*> ch(size_t(K), h);
-    for (int c = 1; c < K; c++) ch[size_t(c)] = h->lanes[size_t(c - 1)];
-    // any failure below: drain every stream, leave nothing pending
-    auto abort_all = [&](int rc, const std::string& msg) { for (m3dreg_handle* x : ch) { hipStreamSynchronize(x->stream); x->pending_pairs = 0; if (x->ev_used) drain_events(x); } h->split.clear(); h->err = msg; return rc; };
-    HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
-    for (int c = 1; c < K; c++) HIPCHK(h, hipStreamWaitEvent(ch[size_t(c)]->stream, h->fork_ev, 0));
-    std::vector<size_t> first(size_t(K), 0);
-    for (int c = 1; c < K; c++) first[size_t(c)] = first[size_t(c - 1)] + part[size_t(c - 1)];
-    for (int c = 0; c < K; c++) {
-        const int rc = batch_begin(ch[size_t(c)], pairs + first[size_t(c)], part[size_t(c)]);
-        if (rc) return abort_all(rc, ch[size_t(c)]->err);
-    }
-    for (bool any = true; any;) {   // the chains' iterations enqueued round-robin: no chain's launches queue up behind another chain's host-side work
-        any = false;
-        for (int c = 0; c < K; c++) {
-            const int rc = batch_step(ch[size_t(c)]);
-            if (rc < 0) return abort_all(rc, ch[size_t(c)]->err);
-            any = any || rc > 0;
-        }
-    }
-    for (int c = 0; c < K; c++) {
-        const int rc = batch_end(ch[size_t(c)], pairs + first[size_t(c)]);
-        if (rc) return abort_all(rc, ch[size_t(c)]->err);
-    }
-    for (int c = 1; c < K; c++) {
-        hipError_t e = hipEventRecord(h->join_ev[size_t(c - 1)], ch[size_t(c)]->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->join_ev[size_t(c - 1)], 0);
-        if (e != hipSuccess) return abort_all(M3DREG_ERR_HIP, "align_batch: join of an internal chain");
-    }
-    h->split = part;
+    // ONE launch chain per batch. (ABI 6-7 could cut a batch into internal chains on child handles' streams, m3dreg_set_batch_chains: measured to lose for 100 k-point
+    // pairs in round 5 and for 10 k / 32 k-point pairs in round 6 — profiles/r05_batch_chains.txt, profiles/r06_batch_chains.txt — and removed in ABI 8.)
+    h->throttle = true;   // this call waits for the batch anyway: the enqueue of a convergence-terminated batch stays a few iterations ahead of the device (batch_step)
+    int rc = m3dreg_align_batch_async(h, pairs, n_pairs);
+    h->throttle = false;
+    if (rc) return rc;
     return m3dreg_batch_wait(h, out_T, stats);
     });
 }

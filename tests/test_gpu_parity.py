@@ -169,63 +169,60 @@ def test_batch_equals_single_and_oracle(reg, orc):
         assert np.array_equal(T1, Tb[k])
 
 
-def test_internal_chains_of_the_synchronous_call_give_the_same_bits(reg, orc):
-    """ABI 6 (opt-in, m3dreg_set_batch_chains): m3dreg_align_batch cuts a batch of >= 4 pairs into internal launch chains (at most 4). Every cut — none, 2, 3, 4 chains,
-    even and uneven parts, fixed iteration counts and convergence-terminated (every chain polls its own progress word) — gives the oracle's bits, the
-    asynchronous call's bits, and leaves the handle usable for single registrations and further batches; work queued on the handle's stream right before
-    the call (the bucketing of its clouds) is complete before any chain starts."""
-    for eps in (0.0, 1e-5):
-        p = _params(leaf=0.25, iterations=12, metric=abi.POINT_TO_PLANE, normal_leaf=0.5, eps_rot=eps, eps_trans=eps)
-        R = reg.Registrar(p)
-        raw, ref = [], []
-        for k in range(9):
-            tgt = synth.planes_cloud(3000 + 400 * k, 150 + k)
-            Tg = synth.random_T(np.random.default_rng(100 + k), 2.0, 0.1)
-            src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(2500 + 300 * k, 180 + k)).astype(np.float32)
-            raw.append((src, tgt))
-            ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
-        for n in (9, 8, 5, 4, 3):
-            for chains in (0, 1, 2, 3, 4):
-                R.set_batch_chains(chains)
+def test_synchronous_and_asynchronous_calls_give_the_same_bits(reg, orc):
+    """m3dreg_align_batch (waits; convergence-terminated batches are enqueued a few iterations ahead of the device and a level is cut short as soon as the device
+    reports it finished) and m3dreg_align_batch_async + m3dreg_batch_wait (enqueues everything; launches behind a finished level leave at once): batches of 9 ... 1
+    pairs that finish after different numbers of iterations, fixed iteration counts and eps-terminated, one level and a pyramid, the bucketing of the clouds still in
+    flight when the call is made — the oracle's bits from either call, and the handle stays usable for single registrations in between."""
+    for levels in (dict(leaf=0.25, iterations=12), dict(leaf=(0.5, 0.25), iterations=(6, 10), max_corr_dist=(1.5, 0.6))):
+        for eps in (0.0, 1e-5):
+            p = _params(metric=abi.POINT_TO_PLANE, normal_leaf=0.5, eps_rot=eps, eps_trans=eps, **levels)
+            R = reg.Registrar(p)
+            raw, ref = [], []
+            for k in range(9):
+                tgt = synth.planes_cloud(3000 + 400 * k, 150 + k)
+                Tg = synth.random_T(np.random.default_rng(100 + k), 1.0 + 0.2 * k, 0.1)
+                src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(2500 + 300 * k, 180 + k)).astype(np.float32)
+                raw.append((src, tgt))
+                ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
+            for n in (9, 5, 2, 1):
                 cl = R.clouds([a for s_, t_ in raw[:n] for a in (s_, t_)], wait=False)      # bucketing still in flight when the call is made
                 pairs = [(cl[2 * i], cl[2 * i + 1], None) for i in range(n)]
                 Tb, stb = R.align_batch(pairs)
+                R.align_batch_async(R._pairs(pairs), n)
+                Ta, sta = R.batch_wait(n)
                 for k in range(n):
-                    assert np.array_equal(Tb[k], ref[k][0]), (eps, n, chains, k)
-                    _same_stats(stb[k], ref[k][1])
-                if chains == 3 and n == 9:
-                    R.align_batch_async(R._pairs(pairs), n)
-                    Ta, sta = R.batch_wait(n)
-                    assert np.array_equal(Ta, Tb) and [s_.iterations for s_ in sta] == [s_.iterations for s_ in stb]
-                    T1, _ = R.align(pairs[7][0], pairs[7][1])
-                    assert np.array_equal(T1, Tb[7])
+                    assert np.array_equal(Tb[k], ref[k][0]) and np.array_equal(Ta[k], ref[k][0]), (levels, eps, n, k)
+                    _same_stats(stb[k], ref[k][1]); _same_stats(sta[k], ref[k][1])
+                T1, _ = R.align(pairs[n - 1][0], pairs[n - 1][1])
+                assert np.array_equal(T1, Tb[n - 1])
                 for c in cl:
                     c.free()
 
 
-@pytest.mark.parametrize("metric", [abi.POINT_TO_POINT, abi.POINT_TO_PLANE])
-def test_internal_chains_on_a_pyramid(reg, orc, metric):
-    """The same cut on a two-level registration (every chain runs its own level loop and polls its own progress word), both metrics, convergence-terminated:
-    pairs of a batch finish their levels after different numbers of iterations, chains of a batch therefore enqueue different numbers of launches."""
-    p = _params(leaf=(0.5, 0.25), iterations=(6, 10), max_corr_dist=(1.5, 0.6), metric=metric, normal_leaf=0.5, eps_rot=1e-5, eps_trans=1e-5)
-    R = reg.Registrar(p)
-    raw, ref = [], []
-    for k in range(6):
-        tgt = synth.planes_cloud(3500 + 500 * k, 250 + k)
-        Tg = synth.random_T(np.random.default_rng(300 + k), 1.5 + 0.3 * k, 0.08)
-        src = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(3000 + 350 * k, 280 + k)).astype(np.float32)
-        raw.append((src, tgt))
-        ref.append(orc.align(p, orc.Cloud(p, src), orc.Cloud(p, tgt)))
-    for n, chains in ((6, 2), (6, 3), (5, 4), (4, 2)):
-        R.set_batch_chains(chains)
-        cl = R.clouds([a for s_, t_ in raw[:n] for a in (s_, t_)], wait=False)
-        Tb, stb = R.align_batch([(cl[2 * i], cl[2 * i + 1], None) for i in range(n)])
-        for k in range(n):
-            assert np.array_equal(Tb[k], ref[k][0]), (metric, n, chains, k)
-            _same_stats(stb[k], ref[k][1])
-        for c in cl:
-            c.free()
-    R.set_batch_chains(0)
+def test_dense_level_schedule_is_a_function_of_the_batch(reg, orc):
+    """ABI 8: which search kernels a level launches (k_nn_iter alone / k_nn_iter + k_nn_coop / k_nn_coop alone) is decided per batch — from the clouds' own counts
+    where the host has read them back (synchronous creation), "launch both, the device decides" where it has not (enqueue-only creation) — and no longer from what
+    the handle's previous batch looked like. A dense pair (60 000-point target, hundreds of points per coarse voxel) and an ordinary one, alone and mixed, through
+    both creation paths, in every order on ONE handle, and on a fresh handle each: always the oracle's bits."""
+    p = _params(leaf=(0.4, 0.1), iterations=(8, 6), max_corr_dist=(1.0, 0.5), metric=abi.POINT_TO_PLANE, normal_leaf=0.4, eps_rot=0.0, eps_trans=0.0)
+    dense_t = synth.planes_cloud(60000, 3100, sigma=0.01, size=3.0)
+    Tg = synth.make_T(synth.rot_z(np.radians(2.0)) @ synth.rot_x(np.radians(-1.0)), np.array([0.12, -0.08, 0.05]))
+    dense_s = synth.apply_T(synth.inv_T(Tg), synth.planes_cloud(20000, 3101, sigma=0.01, size=3.0).astype(np.float64)).astype(np.float32)
+    plain_s, plain_t, _ = synth.hdl32_pair(500, 71, 72, dx=0.2, dy=0.05, dyaw_deg=1.5)
+    data = {"dense": (dense_s, dense_t), "plain": (plain_s, plain_t)}
+    ref = {k: orc.align(p, orc.Cloud(p, s, omp=True, source_only=True), orc.Cloud(p, t, omp=True)) for k, (s, t) in data.items()}
+    shared = reg.Registrar(p)
+    for order in (("dense",), ("plain",), ("dense", "plain"), ("plain", "plain"), ("dense", "dense"), ("plain", "dense"), ("dense",)):
+        for wait in (True, False):
+            for R in (shared, reg.Registrar(p)):
+                cl = R.clouds([a for k in order for a in data[k]], wait=wait, source_only=[True, False] * len(order))
+                T, st = R.align_batch([(cl[2 * i], cl[2 * i + 1], None) for i in range(len(order))])
+                for i, k in enumerate(order):
+                    assert np.array_equal(T[i], ref[k][0]), (order, wait, R is shared, i)
+                    _same_stats(st[i], ref[k][1])
+                for c in cl:
+                    c.free()
 
 
 def test_latency_mode_gives_the_same_bits(reg, orc):
@@ -456,10 +453,11 @@ def test_config5_dense_map_multiresolution(reg, orc):
     _same_stats(st1, st2)
     rot, tra = synth.pose_error(T1, Tgt)
     assert rot < 0.05 and tra < 0.01, (rot, tra)
-    # the SAME handle again: it now knows at which levels every pair of its last batch had a dense target (m3d_dense_level: the coarse levels of this map),
-    # and k_nn_coop is the only search kernel of their iterations (no classifying launch, no tile launch) — a different schedule, the same bits
+    # the other schedule: clouds out of the enqueue-only bucketing, whose counts the host has not read back — both search kernels are launched on every level and the
+    # device decides pair by pair (ABI 8: the schedule is a function of the batch, not of the handle's previous one) — the same bits
+    ca, cta = R.clouds([live, mp], wait=False, source_only=[True, False])
     for _ in range(2):
-        T3, st3 = R.align(cs, ct, T0)
+        T3, st3 = R.align(ca, cta, T0)
         assert np.array_equal(R.trace(), tr2) and np.array_equal(T3, T2)
         _same_stats(st3, st2)
 
@@ -549,8 +547,8 @@ def test_batch_mixing_crowded_and_ordinary_coarse_levels(reg, orc, n_pairs):
             To, sto, _ = orc.align(p, orc.Cloud(p, src, omp=True, source_only=True), orc.Cloud(p, tgt, omp=True))
             assert np.array_equal(Tb[k], To), k
             _same_stats(stb[k], sto)
-    # the dense pairs as a batch of their own, twice: the second time the handle knows that EVERY pair of its last batch had a dense coarse level and
-    # launches k_nn_coop alone there (no classifying launch) — several pairs in that schedule, the same bits
+    # the dense pairs as a batch of their own: EVERY pair has a dense coarse level and the host knows it (synchronous creation read the counts back), so
+    # k_nn_coop is launched alone there (no classifying launch) — several pairs in that schedule, the same bits
     dense = [k for k in range(n_pairs) if k % 2 == 0]
     for _ in range(2):
         Td, std = R.align_batch([(clouds[k][0], clouds[k][1], None) for k in dense])
