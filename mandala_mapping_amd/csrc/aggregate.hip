@@ -20,9 +20,9 @@ __device__ __forceinline__ bool agg_point(const M3dAggArgs& A, int i, float4& pp
         const float ang = A.angle_min + (float)i * A.angle_inc;   // :272
         const float dist = A.ranges[i];
         // :281-283 `cos(ang)*dist` with float operands: mode 1 = C's double cos(double), the product formed in double and rounded once into the
-        // float field (the default: what the pre-GCC-6 toolchains of this ROS1 code resolve the unqualified call to); mode 2 = the float overload
+        // float field (the default: what the pre-GCC-6 toolchains of this ROS1 code resolve the unqualified call to); mode 2 = the float overload (Spec §Trig, m3d_device.h: m3d_sincosf_spec)
         if (A.mode == 1) { px = (float)(cos((double)ang) * (double)dist); py = (float)(sin((double)ang) * (double)dist); }
-        else { px = cosf(ang) * dist; py = sinf(ang) * dist; }
+        else { float sn, cs; m3d_sincosf_spec(ang, sn, cs); px = cs * dist; py = sn * dist; }   // (Spec §Trig: the library's own float sine / cosine, bit-identical to the oracle's)
         pz = 0.0f;
     }
     const double x = (double)px, y = (double)py, z = (double)pz;

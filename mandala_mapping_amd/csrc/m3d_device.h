@@ -303,6 +303,30 @@ __host__ __device__ inline void m3d_fixed_exps(float lbound, float max_corr_dist
     for (int k = 0; k < 6; k++) { union { uint32_t u; float f; } c; c.u = (uint32_t)(e[k] + 127) << 23; S[k] = c.f; }   // 2^e, -126 <= e <= 127
 }
 
+
+// ---- Spec §Trig (round 6): sin / cos of a float angle for the LaserScan path's float-overload reading (m3d_aggregator.cpp:281-282 with ::cos(float) in sight:
+// m3dagg_set_scan_trig(1)). The C library's cosf / sinf are not one function — glibc's and the device's differ in the last bit for a few per cent of the arguments —
+// so the reading is SPECIFIED: double arithmetic only (+, -, x, rint: correctly rounded on both sides of the bus, this file is built with -ffp-contract=off),
+// a two-word Cody-Waite reduction by pi/2 (exact products for |x| < 2^19), the classic degree-13 / degree-12 minimax kernels on [-pi/4, pi/4], ONE rounding to float
+// at the end. The result is the correctly rounded sine / cosine for all but ~1 argument in 10^8, i.e. within 1 ulp of any C library's (side check in the tests).
+// oracle/m3d_agg_oracle.c restates it: same constants, same order, same bits.
+__host__ __device__ inline void m3d_sincosf_spec(float xf, float& s_out, float& c_out) {
+    const double x = (double)xf;
+    const double fn = rint(x * 6.36619772367581382433e-01);                       // x * 2 / pi, to the nearest integer
+    const double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;   // pi/2 = its first 33 bits + the next 53
+    const double z = r * r;
+    const double sp = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double sn = r + r * z * (-1.66666666666666324348e-01 + z * sp);
+    const double cp = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double cs = 1.0 - (0.5 * z - z * cp);
+    const long long q = (long long)fn & 3ll;                                       // quadrant (two's complement: also for negative fn)
+    const double sv = (q == 0) ? sn : ((q == 1) ? cs : ((q == 2) ? -sn : -cs));
+    const double cv = (q == 0) ? cs : ((q == 1) ? -sn : ((q == 2) ? -cs : sn));
+    const bool fin = (xf - xf) == 0.0f;                                            // NaN / infinity in: NaN out
+    s_out = fin ? (float)sv : (xf - xf);
+    c_out = fin ? (float)cv : (xf - xf);
+}
+
 // Pointers that arrive inside descriptors loaded from memory are "generic" to the compiler, which then
 // emits flat_load (slower, and every wait drains both counters). They all point to hipMalloc'ed HBM,
 // so the kernels re-type them as global (address space 1) before use.

@@ -136,6 +136,24 @@ void orc_agg_add_cloud(orc_agg* a, const uint8_t* data, size_t n, size_t step, s
  *     (dist promoted) and rounded ONCE when it is stored into the float field;
  *   float_overload == 1 (GCC >= 6 with the C++ <math.h> wrapper in sight: ::cos(float) exists and wins): cosf(ang) * dist in float.
  * The two differ in the last bit of about a third of the coordinates. */
+/* Spec §Trig: the float sine / cosine of the float-overload reading, restated: double arithmetic only, two-word reduction by pi/2, degree-13 / -12
+ * kernels, one rounding to float. (float_overload == 2 below keeps the C library's cosf / sinf: the side check that the specified functions stay within 1 ulp of them.) */
+static void orc_sincosf_spec(float xf, float* s_out, float* c_out) {
+    const double x = (double)xf;
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    const double r = (x - fn * 1.57079632673412561417e+00) - fn * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double sp = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double sn = r + r * z * (-1.66666666666666324348e-01 + z * sp);
+    const double cp = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double cs = 1.0 - (0.5 * z - z * cp);
+    const long long q = (long long)fn & 3ll;
+    const double sv = (q == 0) ? sn : ((q == 1) ? cs : ((q == 2) ? -sn : -cs));
+    const double cv = (q == 0) ? cs : ((q == 1) ? -sn : ((q == 2) ? -cs : sn));
+    if ((xf - xf) == 0.0f) { *s_out = (float)sv; *c_out = (float)cv; } else { *s_out = xf - xf; *c_out = xf - xf; }
+}
+void orc_sincosf(float x, float* s, float* c) { orc_sincosf_spec(x, s, c); }   /* (tests: accuracy against the C library) */
+
 void orc_agg_add_scan2(orc_agg* a, const float* ranges, size_t n, float angle_min, float angle_increment, const double tf[7], int float_overload) {
     double m[9], o[3], q[4];
     make_tf(tf, m, o, q);
@@ -143,7 +161,8 @@ void orc_agg_add_scan2(orc_agg* a, const float* ranges, size_t n, float angle_mi
         const float ang = angle_min + (float)i * angle_increment;   /* :272 (size_t -> float, float arithmetic) */
         const float dist = ranges[i];
         float x, y;                                                 /* :281-283, z = 0 */
-        if (float_overload) { x = cosf(ang) * dist; y = sinf(ang) * dist; }
+        if (float_overload == 1) { float sn, cs; orc_sincosf_spec(ang, &sn, &cs); x = cs * dist; y = sn * dist; }
+        else if (float_overload) { x = cosf(ang) * dist; y = sinf(ang) * dist; }
         else { x = (float)(cos((double)ang) * (double)dist); y = (float)(sin((double)ang) * (double)dist); }
         add_point(a, x, y, 0.0f, m, o, q);
     }

@@ -77,6 +77,8 @@ def _lib(omp=False):
         L.orc_map_points.restype = None
         L.orc_map_insert.argtypes = [vp, f32p, C.c_size_t, f32p]
         L.orc_map_insert.restype = C.c_size_t
+        L.orc_sincosf.argtypes = [C.c_float, f32p, f32p]
+        L.orc_sincosf.restype = None
         L.orc_loop_create.argtypes = [C.POINTER(abi.LoopParams)]
         L.orc_loop_create.restype = vp
         L.orc_loop_destroy.argtypes = [vp]
@@ -218,7 +220,7 @@ class Aggregator:
         """float_overload: which cos / sin `m3d_aggregator.cpp:281-282` resolves to (m3d_agg_oracle.c: orc_agg_add_scan2)"""
         r = np.ascontiguousarray(ranges, np.float32)
         t = np.asarray(tf7, np.float64)
-        self._L.orc_agg_add_scan2(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double), int(bool(float_overload)))
+        self._L.orc_agg_add_scan2(self._a, _ptr(r, C.c_float), len(r), angle_min, angle_increment, _ptr(t, C.c_double), int(float_overload))   # (1 / True: Spec §Trig; 2: the C library's cosf / sinf)
 
     def status(self):
         return {"progress": self._L.orc_agg_progress(self._a), "ready": bool(self._L.orc_agg_ready(self._a)),
@@ -323,6 +325,18 @@ class Map:
         out = np.zeros((max(n, 1), 3), np.float32)
         self._L.orc_map_points(self._m, _ptr(out, C.c_float))
         return out[:n]
+
+
+def sincosf_spec(x):
+    """Spec §Trig (oracle/m3d_agg_oracle.c: orc_sincosf_spec): (sin, cos) of float32 values, as float32 arrays"""
+    a = np.ascontiguousarray(np.atleast_1d(x), np.float32)
+    s_, c_ = np.empty_like(a), np.empty_like(a)
+    L = _lib()
+    sv, cv = C.c_float(), C.c_float()
+    for i, v in enumerate(a):
+        L.orc_sincosf(float(v), C.byref(sv), C.byref(cv))
+        s_[i], c_[i] = sv.value, cv.value
+    return s_, c_
 
 
 class Loop:
