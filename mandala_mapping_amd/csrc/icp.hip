@@ -351,12 +351,15 @@ __device__ __forceinline__ void m3d_load_pose(const M3dPairState* st, float (&R)
 }
 
 __device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, int& blk, int rot = 0) {
-    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so with a multiple of 8 pairs the
-    // blocks of one pair are kept on one XCD (its L2 then holds one pair's clouds, not all eight).
+    // Workgroups are dealt round-robin over the 8 XCDs by their linear id. Two maps (round 6, profiles/r06_map_spread.txt):
+    //   rot >= 0 (the caller's latency mode, m3dreg_set_latency_mode: this batch has the GPU to itself) and a batch of eight pairs: the blocks of one pair are kept on
+    //     ONE XCD — its L2 then holds one pair's clouds, not all eight: serial 8-pair steps 5500 registrations/s against 5200 with the other map. rot (per handle)
+    //     rotates which XCD the k-th pair lands on.
+    //   rot < 0 (the default: other batches share the GPU): every pair's blocks go over ALL eight XCDs. A pair that is slower than the rest of its batch (a surface
+    //     close to the sensor) then loads the whole chip instead of being the one XCD every launch of the batch waits for: the eight LPT shards of config 4 run
+    //     3 - 9 % faster each, steps with rotating inputs +3.8 %, one 64-pair call +1 %, the headline's own eight pairs +0.4 % (same box, interleaved).
     const int id = blockIdx.x;
-    // rot (per handle): concurrent batches on different handles put their k-th pairs on different XCDs — a pair that is slower than
-    // the rest of its batch (a surface close to the sensor) then does not share its XCD with the other batch's slow pair
-    if ((n_pairs & 7) == 0) { const int slot = id >> 3; pair = (slot / bpp) * 8 + ((id + rot) & 7); blk = slot % bpp; }
+    if (rot >= 0 && n_pairs == 8) { const int slot = id >> 3; pair = (id + rot) & 7; blk = slot; }   // (one 64-pair call is 1.3 % faster with the other map)
     else { pair = id / bpp; blk = id % bpp; }
 }
 

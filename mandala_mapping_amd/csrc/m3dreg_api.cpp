@@ -737,7 +737,7 @@ M3dNnWork nn_work(const m3dreg_handle* h, int level = -1, int it = 0) {
     w.certify = h->certify;
     w.lane_min = h->lane_min;
     w.seed_reach = h->seed_reach;
-    w.rot = h->xcd_rot;
+    w.rot = h->alone ? h->xcd_rot : -1;   // (icp.hip m3d_map_block: one pair per XCD only when the caller said the batch has the GPU to itself)
     w.alone = h->alone;
     // (lean per LEVEL: only on the finest level of a registration — a pyramid's coarse levels put more points into a bucket than a tile image holds,
     // their queries would all take the fallback list: config 5 with lean on every level took 6.5 instead of 5.9 ms)
