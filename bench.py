@@ -90,7 +90,8 @@ def parse():
     ap.add_argument("--verify-steps", action="store_true",
                     help="compare EVERY step's poses and statistics (timed steps included) byte for byte with the first result of the same shard; the default run "
                          "verifies --verify-extra untimed steps of the same schedule right after the timed region instead")
-    ap.add_argument("--verify-extra", type=int, default=64, help="untimed steps of the headline schedule whose results are checked byte for byte after the timed region (0 = none)")
+    ap.add_argument("--verify-extra", type=int, default=None, help="untimed steps of the same schedule whose results are checked byte for byte after the timed region (default: 64 in the "
+                                                                     "full run — the driver's command —, 0 in the child legs and with --no-extra / --no-cpu-baseline: scripts that count launches per step)")
     ap.add_argument("--rotate-pairs", action="store_true",
                     help="step k registers shard k mod 8 of the 64 config-4 pairs (the eight LPT shards bench.py --gpus 8 forms) instead of the same 8 pairs every step: "
                          "64 pairs' payloads resident, inputs no longer repeat from step to step")
@@ -98,7 +99,10 @@ def parse():
                     help="the block of --steps timed steps is repeated (each block bracketed by barrier + synchronize on both sides, exactly --steps steps) "
                          "until the blocks add up to this much wall time; the MEDIAN block is reported (0 = one block)")
     ap.add_argument("--max-blocks", type=int, default=200)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.verify_extra is None:
+        a.verify_extra = 64 if (a.workload == "config4" and not a.no_extra and not a.no_cpu_baseline) else 0
+    return a
 
 
 def run_multi(args):
