@@ -544,10 +544,17 @@ def main():
     gather_model = None
     if not args.no_events and world == 1:
         last_T, last_st = last.get("T"), last.get("st")
+        # (this step HAS the GPU to itself, and says so — m3dreg_set_latency_mode: since round 6 the statement also selects the one-XCD-per-pair map that a lone batch wants;
+        #  the timed region's handles never make it)
+        alone_stated = not serial_calls and not args.no_latency_mode and not os.environ.get("M3D_BENCH_ALONE_DEFAULT")   # (the variable: A/B of the two maps on the lone step)
+        if alone_stated:
+            regs[0].set_latency_mode(True)
         regs[0].profile_enable(True, every=1)
         for w_ in range(4):
             regs[0].profile_read(w_, reset=True)
         c_ = make_clouds(regs[0])
+        for s_, t_ in c_:   # (a lone caller's clouds come out of the synchronous creation calls, which read their counts back: the dense-level schedule is then decided on the host —
+            s_.status(); t_.status()   # no empty k_nn_coop launch behind the bracketed late iterations, which the enqueue-only clouds of the timed region get: include/m3dreg.h "Threading")
         regs[0].align_batch_async(regs[0]._pairs([(s_, t_, inits[j]) for j, (s_, t_) in enumerate(c_)]), B)
         regs[0].batch_wait(B)
         a_, b_ = regs[0].profile_read(1, reset=True)
@@ -563,6 +570,8 @@ def main():
         regs[0].batch_wait(B)
         ac_, bc_ = regs[0].profile_read(4, reset=True)
         regs[0].profile_enable(False)
+        if alone_stated:
+            regs[0].set_latency_mode(False)
         alone_chain_ms = bc_ / max(1, ac_)
         # SURVEY 8d "gather-model bytes": 12 N k + 8 * 27 N per pair, k = mean number of candidates the spec names per query (all points of its 27
         # voxels; measured at the initial and at the final pose — the searches prune most of them, the certificates skip most searches)
@@ -688,7 +697,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "gather_model": gather_model,
                          "alone": {"avg_launch_ms": alone_ms, "achieved": alone, "frac": alone / HBM_PEAK_GBS,
-                                   "source": "one extra, untimed step after the timed region with nothing else on the GPU, every iteration bracketed: what a rocprofv3 kernel trace of serial steps shows (profiles/)"},
+                                   "source": "one extra, untimed step after the timed region with nothing else on the GPU (the handle in latency mode, as a lone caller's would be), every iteration bracketed: what a rocprofv3 kernel trace of serial steps shows (profiles/)"},
                          "iteration": {"what": "one whole linearisation of the shipped schedule: correspondence step + residuals + 29-term reduction + solve (k_icp_late where it runs)",
                                        "algorithmic_bytes": alg_bytes_iter, "avg_ms": chain_iter_ms, "achieved": iteration_gbps, "frac": iteration_gbps / HBM_PEAK_GBS,
                                        "iterations_timed": chain_n,
