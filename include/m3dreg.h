@@ -367,7 +367,7 @@ typedef struct m3dloop_params {
     int32_t min_gap;         /* >= 1: keyframes at least this many insertions apart (default 10: not the odometry's own neighbours) */
     int32_t top_k;           /* 1 .. 16 candidates per keyframe at most (default 2) */
     float min_overlap;       /* 0 .. 1 (default 0.5) */
-    int32_t max_keyframes;   /* capacity (default 4096) */
+    int32_t max_keyframes;   /* capacity, 1 .. 65536 (default 4096: 32 MB of signatures) */
     int32_t reserved;        /* must be 0 */
 } m3dloop_params;
 typedef struct m3dloop_candidate {

@@ -1964,7 +1964,7 @@ int m3dloop_create(m3dreg_handle* h, const m3dloop_params* P, m3dloop** out) {
     if (!h || !P || !out) return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_create: bad argument");
     *out = nullptr;
     if (!(P->sig_leaf > 0.f) || !std::isfinite(P->sig_leaf) || P->sig_log2_bits < 10 || P->sig_log2_bits > 18 || !(P->radius >= 0.f) || !std::isfinite(P->radius) ||
-        P->min_gap < 1 || P->top_k < 1 || P->top_k > 16 || !(P->min_overlap >= 0.f && P->min_overlap <= 1.f) || P->max_keyframes < 1 || P->max_keyframes > (1 << 20) || P->reserved != 0)
+        P->min_gap < 1 || P->top_k < 1 || P->top_k > 16 || !(P->min_overlap >= 0.f && P->min_overlap <= 1.f) || P->max_keyframes < 1 || P->max_keyframes > (1 << 16) || P->reserved != 0)   // (65 536 keyframes: 512 MB of 8 KB signatures + 64 MB of score rows)
         return fail(h, M3DREG_ERR_INVALID_ARG, "m3dloop_create: parameter out of range (see m3dloop_params)");
     HIPCHK(h, hipSetDevice(h->device));
     alloc_point();
