@@ -10,7 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* ---- the oracle's C interface (oracle/m3d_oracle.c, m3d_agg_oracle.c, m3d_cal_oracle.c, m3d_map_oracle.c, m3d_kdtree_icp.c) ---- */
+/* ---- the oracle's C interface (oracle/m3d_oracle.c, m3d_agg_oracle.c, m3d_cal_oracle.c, m3d_map_oracle.c, m3d_loop_oracle.c, m3d_kdtree_icp.c) ---- */
 #define ORC_MAX_LEVELS 4
 typedef struct {
     int32_t n_levels;
@@ -36,6 +36,17 @@ typedef struct {
 typedef struct orc_cloud orc_cloud;
 typedef struct orc_agg orc_agg;
 typedef struct orc_map orc_map;
+typedef struct orc_loop orc_loop;
+typedef struct { float sig_leaf; int32_t sig_log2_bits; float radius; int32_t min_gap; int32_t top_k; float min_overlap; int32_t max_keyframes; int32_t reserved; } orc_loop_params;
+typedef struct { int32_t source, target; uint32_t overlap, pop_source, pop_target; float dist2; float init_T[16]; } orc_loop_candidate;
+orc_loop* orc_loop_create(const orc_loop_params* P);
+void orc_loop_destroy(orc_loop* l);
+int orc_loop_size(const orc_loop* l);
+int orc_loop_add(orc_loop* l, const float* xyz, size_t n, const float T[16]);
+void orc_loop_update(orc_loop* l, int k, const float* xyz, size_t n, const float T[16]);
+void orc_loop_signature(const orc_loop* l, int k, uint32_t* words, uint32_t* pop);
+size_t orc_loop_candidates(const orc_loop* l, int first, int count, orc_loop_candidate* out, size_t cap);
+void orc_sincosf(float x, float* s, float* c);
 int orc_default_params(orc_params* p);
 int orc_set_threads(int n);
 int orc_cloud_create(const orc_params* p, const void* data, size_t n, size_t step, size_t ox, size_t oy, size_t oz, orc_cloud** out);
@@ -220,6 +231,36 @@ int main(void) {
         orc_map_points(m, out);
         free(out);
         orc_map_destroy(m);
+    }
+    /* ---- loop-closure candidates (m3d_loop_oracle.c) and the specified float sine / cosine (m3d_agg_oracle.c) ---- */
+    {
+        orc_loop_params lp = { 1.0f, 10, 6.0f, 2, 3, 0.3f, 6, 0 };   /* 1024-bit signatures, capacity 6: the seventh keyframe is refused */
+        orc_loop* L = orc_loop_create(&lp);
+        CHECK(L != NULL);
+        for (int k = 0; k < 7; k++) {
+            const float Tk[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, (k == 3) ? 100.f : 0.5f * (float)k, 0, 0, 1 };
+            const int idx = orc_loop_add(L, (k & 1) ? src : tgt, N, Tk);
+            CHECK(idx == (k < 6 ? k : -1));
+        }
+        CHECK(orc_loop_size(L) == 6);
+        orc_loop_candidate cand[18];
+        const size_t n_all = orc_loop_candidates(L, 0, -1, cand, 18);
+        const size_t n_cut = orc_loop_candidates(L, 0, -1, cand, 2);            /* a short output array */
+        CHECK(n_all == n_cut && n_all <= 18);
+        for (size_t i = 0; i < (n_all < 2 ? n_all : 2); i++) CHECK(cand[i].source - cand[i].target >= 2 && cand[i].overlap <= cand[i].pop_source);
+        uint32_t words[32], pop = 0;
+        orc_loop_signature(L, 5, words, &pop);
+        const float T5[16] = { 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 1, 0, 1.f, 2.f, 0.f, 1 };
+        orc_loop_update(L, 5, src, N, T5);
+        CHECK(orc_loop_candidates(L, 5, 1, cand, 18) <= 3);
+        orc_loop_destroy(L);
+        float sn, cs;
+        orc_sincosf(0.5f, &sn, &cs);
+        CHECK(fabsf(sn - sinf(0.5f)) < 1e-6f && fabsf(cs - cosf(0.5f)) < 1e-6f);
+        orc_sincosf(-123456.f, &sn, &cs);
+        CHECK(fabsf(sn * sn + cs * cs - 1.f) < 1e-5f);
+        orc_sincosf(INFINITY, &sn, &cs);
+        CHECK(sn != sn && cs != cs);
     }
     free(src); free(tgt);
     printf("asan_driver: ok\n");
