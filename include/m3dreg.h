@@ -474,6 +474,11 @@ int m3dreg_debug_fail_alloc(int nth);
  * bound before it addresses global memory; out[0..3] = {offences, site, index, bound} of the iteration kernels, out[4..7] of the bucketing pipeline (first offence
  * kept; reset != 0 clears). The shipped library has no checks compiled in: M3DREG_ERR_INVALID_ARG. */
 int m3dreg_debug_checks(m3dreg_handle* h, uint32_t out[8], int reset);
+/* (ABI 8) Diagnosis: the raw bytes of one of a cloud level's search structures as they lie in HBM (waits for the cloud's bucketing) — what = 0 bucket table
+ * (32 B per slot), 1 tile headers (16 B per tile), 2 tile images, 3 tile image meta (8 B per image), 4 occupancy bitmap, 5 the level's meta (dyn counters + grid),
+ * 6 the source block order. *bytes = size of the structure; copied when out != NULL and cap >= *bytes. The layouts are csrc/m3d_device.h's, not part of the ABI:
+ * scripts/r6_hunt2.py compares two clouds bucketed from the same points with it. M3DREG_ERR_LEVEL_MISMATCH when the cloud has no such structure. */
+int m3dreg_debug_cloud_raw(m3dreg_handle* h, const m3dreg_cloud* c, int level, int what, void* out, size_t cap, size_t* bytes);
 int m3dreg_debug_throw(int kind);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ EXPORTS = [
     "m3dmap_create", "m3dmap_destroy", "m3dmap_insert", "m3dmap_size", "m3dmap_as_cloud", "m3dmap_download", "m3dmap_clear",
     "m3dcal_create", "m3dcal_destroy", "m3dcal_add_segment", "m3dcal_evaluate", "m3dcal_twiddle", "m3dcal_anneal",
     "m3dreg_multi_create", "m3dreg_multi_destroy", "m3dreg_multi_align", "m3dreg_multi_last_error", "m3dreg_debug_multi_clouds",
-    "m3dreg_debug_fail_alloc", "m3dreg_debug_throw", "m3dreg_debug_checks",
+    "m3dreg_debug_fail_alloc", "m3dreg_debug_throw", "m3dreg_debug_checks", "m3dreg_debug_cloud_raw",
     "m3dloop_default_params", "m3dloop_create", "m3dloop_destroy", "m3dloop_clear", "m3dloop_add_keyframe", "m3dloop_update_pose", "m3dloop_size", "m3dloop_candidates",
     "m3dloop_make_pairs", "m3dloop_make_pair_descs", "m3dloop_gate", "m3dloop_signature", "m3dloop_last_profile",
     "m3dreg_debug_candidates", "m3dreg_host_alloc", "m3dreg_host_free", "m3dreg_host_register", "m3dreg_host_unregister",
@@ -147,6 +147,7 @@ def lib():
     L.m3dloop_signature.argtypes = [vp, C.c_int32, u32p, u32p]
     L.m3dloop_last_profile.argtypes = [vp, f64p, C.POINTER(C.c_uint64)]
     L.m3dreg_debug_checks.argtypes = [vp, u32p, C.c_int]
+    L.m3dreg_debug_cloud_raw.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.m3dreg_debug_fail_alloc.argtypes = [C.c_int]
     L.m3dreg_debug_throw.argtypes = [C.c_int]
     _lib = L
@@ -213,6 +214,16 @@ class Cloud:
         self._reg._check(lib().m3dreg_cloud_export(self._reg._h, self._p, level, _ptr(out["keys"], C.c_uint32),
                                                    _ptr(out["sorted_keys"], C.c_uint32), _ptr(out["perm"], C.c_int32),
                                                    _ptr(out["sorted_xyz"], C.c_float), _ptr(out["normals"], C.c_float)), "cloud_export")
+        return out
+
+    RAW = {"htab": 0, "thdr": 1, "timg": 2, "timeta": 3, "occ": 4, "meta": 5, "order": 6}
+
+    def raw(self, what, level=0):
+        """diagnosis: the bytes of one search structure of this level as they lie in HBM (m3dreg_debug_cloud_raw; layouts: csrc/m3d_device.h), as a uint32 array"""
+        n = C.c_size_t()
+        self._reg._check(lib().m3dreg_debug_cloud_raw(self._reg._h, self._p, level, self.RAW[what], None, 0, C.byref(n)), "debug_cloud_raw")
+        out = np.empty(n.value // 4, np.uint32)
+        self._reg._check(lib().m3dreg_debug_cloud_raw(self._reg._h, self._p, level, self.RAW[what], _ptr(out, C.c_uint32), n.value, C.byref(n)), "debug_cloud_raw")
         return out
 
     def nn(self, queries, max_corr_dist, level=0):

@@ -153,6 +153,15 @@ __global__ void k_grid_params(M3dBuild* __restrict__ builds, int n_clouds, int g
         B.sort_passes = (B.n == 0) ? 0 : ((n_valid != B.n) ? 4 : (kb + 7) / 8);   // the 0xFFFFFFFF keys of non-finite points must end up last; n = 0: a build the host switched off
         M->g = g; M->lbound = lbound;
         for (int a = 0; a < 3; a++) { M->mx[a] = mx[a]; M->bits[a] = bits[a]; }
+        if (B.nkeys) {   // a normal grid: its voxel table is allocated for the worst case (as many occupied voxels as points: a power of two > 1.25 n); it cannot hold more voxels
+            // than the grid has cells either — a 2 M-point map in a 40 x 30 x 6 m room has 112 k normal-grid cells: 262 144 slots instead of 4 194 304 (436 MB touched
+            // sparsely; the keys' clear alone was 32 MB per bucketing). Every user of the table reads ncap / nshift from this descriptor on the device.
+            const unsigned long long cells = (unsigned long long)g.dims[0] * (unsigned long long)g.dims[1] * (unsigned long long)g.dims[2];
+            const unsigned long long bound = cells < (unsigned long long)n_valid ? cells : (unsigned long long)n_valid;
+            uint32_t c = 16u; int lg = 4;
+            while ((unsigned long long)c < bound + bound / 4ull + 16ull && c < B.ncap) { c <<= 1; lg++; }
+            if (c < B.ncap) { B.ncap = c; B.nshift = 32 - lg; }
+        }
     }
     for (int gi = 0; gi < gpc; gi++) {
         M3dBuild& B = B0[gi];
@@ -725,7 +734,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     __shared__ uint32_t s_src[M3D_TILE_PCAP];     // sorted position of every staged point of the image being written
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_ip[M3D_TILE_MAXIMG];   // points | voxels << 16 of every image
-    __shared__ uint32_t s_cnt, s_over, s_nv;
+    __shared__ uint32_t s_cnt, s_over, s_nv, s_crowd;
     const int tid = threadIdx.x;
     const M3dGrid& g = B.grid;
     const uint32_t hmask = B.dyn[1];
@@ -745,7 +754,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
     const int cs_bits = occ_ok ? 10 : 12;
     const uint32_t cs_mask = (1u << cs_bits) - 1u;
     for (int i = tid; i <= (int)cs_mask; i += 256) s_ck[i] = M3D_INVALID_KEY;
-    if (tid == 0) { s_cnt = 0u; s_over = 0u; }
+    if (tid == 0) { s_cnt = 0u; s_over = 0u; s_crowd = 0u; }
     // 1. own bucket heads, in sorted order; their bucket coordinates (one point load per head)
     uint32_t nheads = 0;
 #pragma unroll
@@ -925,9 +934,14 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
         __syncthreads();
         if (s_cnt == 0xFFFFFFFFu) { if (tid == 0) *H = M3dTileHdr{ 0u, 0u, M3D_TILE_OVERSIZE, 0u }; return; }
     } else if (tid == 0) { s_ip[0] = tot_p | (tot_v << 16); s_cnt = 0u; }
-    if (crowd) atomicMax(&s_over, vmax);   // (re-used: some voxel of the tile is crowded — the tile's largest voxel population, > M3D_LONG_ROW)
+    // (a word of its own, zeroed at the top. Rounds 5-6 re-used s_over here: on the one-image path NO barrier lies between the test of s_over above and this
+    // atomic, so a wave that was late to that test could read a faster wave's maximum, take the tile for oversize and LEAVE — its share of the image's stores
+    // never happened (the block kept whatever it held before: an older image of the same tile, or anything), and when it owned staged buckets the others
+    // copied points from LDS positions nobody had written. One step in ~15 000 of the pipelined schedule, crowded tiles only: profiles/r06_fault_hunt.txt.)
+    if (crowd) atomicMax(&s_crowd, vmax);   // some voxel of the tile is crowded: the tile's largest voxel population (> M3D_LONG_ROW)
     __syncthreads();
-    const bool crowded = s_over != 0u;
+    const uint32_t crowd_max = s_crowd;
+    const bool crowded = crowd_max != 0u;
     // How crowded (round 5; rounds 2-4: one flag = eight lanes per record): the lanes that share a record of k_nn_tiles split each voxel's points, so their number follows the
     // largest voxel — 2 lanes up to 64 points, 4 up to 160, 8 beyond — and with it the records per work item (512 / lanes): an item stages the whole image whatever
     // it holds, and a tile with one 40-point voxel used to be cut into eight items of 64 records.
@@ -935,7 +949,7 @@ __device__ __forceinline__ void tile_build_role(const M3dBuild* __restrict__ bui
 #define M3D_CROWD_T1 64u
 #define M3D_CROWD_T2 160u
 #endif
-    const uint32_t crowd_level = !crowded ? 0u : (s_over > M3D_CROWD_T2 ? 3u : (s_over > M3D_CROWD_T1 ? 2u : 1u));
+    const uint32_t crowd_level = !crowded ? 0u : (crowd_max > M3D_CROWD_T2 ? 3u : (crowd_max > M3D_CROWD_T1 ? 2u : 1u));
     const uint32_t extra = s_cnt;
     const int sh1 = g.cb[0] + 1, sh2 = g.cb[0] + g.cb[1] + 2;
     // 6. the images: per image the list of its voxels {key, LDS position | population - 1 | staged bucket} and the copies of its points; per tile

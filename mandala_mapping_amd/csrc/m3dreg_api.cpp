@@ -2199,6 +2199,30 @@ int m3dreg_cloud_density(m3dreg_handle* h, const m3dreg_cloud* c, int level, dou
     });
 }
 
+int m3dreg_debug_cloud_raw(m3dreg_handle* h, const m3dreg_cloud* c, int level, int what, void* out, size_t cap, size_t* bytes) {
+    return m3d_guarded(h, "m3dreg_debug_cloud_raw", [&]() -> int {
+    if (!h || !c || !bytes || level < 0 || level >= c->n_levels) return fail(h, M3DREG_ERR_INVALID_ARG, "debug_cloud_raw: bad argument");
+    { int rc = fetch_meta(h, const_cast<m3dreg_cloud*>(c)); if (rc) return rc; }
+    const DevLevel& L = c->lv[level];
+    const size_t nt = size_t(m3d_tiles_of(c->n)), ni = nt + size_t(m3d_tile_pool(int(nt)));
+    const void* p = nullptr; size_t sz = 0;
+    switch (what) {
+    case 0: p = L.htab; sz = sizeof(M3dBucket) * (size_t(L.grid.hmask) + 1); break;
+    case 1: p = L.thdr; sz = sizeof(M3dTileHdr) * nt; break;
+    case 2: p = L.timg; sz = size_t(M3D_TILE_IMG_BYTES) * ni; break;
+    case 3: p = L.timeta; sz = sizeof(M3dTileImgMeta) * ni; break;
+    case 4: p = L.occ; sz = size_t(1) << (M3D_OCC_BITS - 3); break;
+    case 5: p = L.dyn; sz = sizeof(M3dLevelMeta); break;
+    case 6: p = L.order; sz = 4 * ((size_t(c->n) + 255) / 256); break;
+    default: return fail(h, M3DREG_ERR_INVALID_ARG, "debug_cloud_raw: unknown structure");
+    }
+    if (!p) return fail(h, M3DREG_ERR_LEVEL_MISMATCH, "debug_cloud_raw: the cloud has no such structure at this level");
+    *bytes = sz;
+    if (out && cap >= sz) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipMemcpy(out, p, sz, hipMemcpyDeviceToHost)); }
+    return M3DREG_OK;
+    });
+}
+
 int m3dreg_cloud_export(m3dreg_handle* h, const m3dreg_cloud* c, int level, uint32_t* keys, uint32_t* sorted_keys, int32_t* perm,
                         float* sorted_xyz, float* normals) {
     return m3d_guarded(h, "m3dreg_cloud_export", [&]() -> int {
