@@ -189,6 +189,23 @@ __host__ __device__ inline bool m3d_dense_level(uint32_t n_tgt, uint32_t occupie
 }
 
 
+// ---- -DM3D_JITTER (diagnosis build, `make jitter` -> libm3dreg_jitter.so) ---------------------------------------------------------------------
+// Behind EVERY __syncthreads() about one wave in four pauses for 0.2 - 4 us (wave-uniform, pseudo-random from the clock, the wave and the workgroup): the waves
+// of a workgroup leave every barrier far apart instead of a few cycles apart. A word of LDS that one wave still tests while another already re-uses it — the
+// race rounds 5-6 shipped in tile_build_role, one pipelined step in ~10 000 — then goes wrong in nearly every workgroup that has the pattern; code that is
+// correctly fenced returns the same bits, only later. The GPU suite runs against this build (M3DREG_LIB selects it): profiles/r06_fault_hunt.txt.
+#ifdef M3D_JITTER
+__device__ __forceinline__ void m3d_sync_jitter() {
+    __syncthreads();
+    unsigned int t = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)clock64());
+    t ^= (threadIdx.x >> 6) * 0x9E3779B1u ^ blockIdx.x * 0x85EBCA6Bu;
+    t ^= t >> 15; t *= 0x2C1B3C6Du; t ^= t >> 12; t *= 0x297A2D39u; t ^= t >> 15;
+    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    if ((t & 3u) == 0u) { const int n = 1 + (int)((t >> 4) & 15u); for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(8); }
+}
+#define __syncthreads() m3d_sync_jitter()
+#endif
+
 // ---- -DM3D_CHECKED (diagnosis build, `make checked` -> libm3dreg_checked.so; DESIGN.md §8 "the unexplained GPU memory fault") --------------------------------
 // Every index that a kernel takes out of MEMORY before it addresses global memory with it — match indices, permutation values, tile / image numbers, staged
 // counts, work-item fields, block orders — goes through M3D_CHK(site, index, bound): out of range, the FIRST offence is recorded {count, site, index, bound} in
