@@ -27,6 +27,7 @@ __device__ __forceinline__ int m3d_row_build(int row, int rows) {
     return (row / lv) * gpc + (gpc - lv) + (row % lv);
 }
 __device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr, int id = (int)blockIdx.x) {
+    M3D_ENTRY_JITTER();
     M3dRB r;
     r.row = id / bpr; r.blk = id - r.row * bpr;
     (void)rows;
@@ -37,6 +38,7 @@ __device__ __forceinline__ M3dRB m3d_row_block(int rows, int bpr, int id = (int)
 // blocks. A cloud is still spread over all eight XCDs, but each XCD's L2 sees one compact stretch of the sorted order — one region of space, whose points
 // also sit close together in the input (scan) order — instead of every eighth block of the whole cloud. blk >= bpr: a padding workgroup, nothing to do.
 __device__ __forceinline__ M3dRB m3d_row_block_sliced(int bpr, int sliced, int id = (int)blockIdx.x) {
+    M3D_ENTRY_JITTER();
     const int per = (bpr + 7) >> 3, w = per << 3;
     M3dRB r;
     r.row = id / w;

@@ -358,6 +358,7 @@ __device__ __forceinline__ void m3d_map_block(int n_pairs, int bpp, int& pair, i
     //   rot < 0 (the default: other batches share the GPU): every pair's blocks go over ALL eight XCDs. A pair that is slower than the rest of its batch (a surface
     //     close to the sensor) then loads the whole chip instead of being the one XCD every launch of the batch waits for: the eight LPT shards of config 4 run
     //     3 - 9 % faster each, steps with rotating inputs +3.8 %, one 64-pair call +1 %, the headline's own eight pairs +0.4 % (same box, interleaved).
+    M3D_ENTRY_JITTER();
     const int id = blockIdx.x;
     if (rot >= 0 && n_pairs == 8) { const int slot = id >> 3; pair = (id + rot) & 7; blk = slot; }   // (one 64-pair call is 1.3 % faster with the other map)
     else { pair = id / bpp; blk = id % bpp; }
@@ -1559,6 +1560,7 @@ __global__ __launch_bounds__(M3D_TILE_THREADS, 6) void k_nn_tiles(const M3dJob* 
     __shared__ m3d_u32x2 s_vs[M3D_TILE_VS];
     __shared__ int s_delta[M3D_TILE_ECAP];   // sorted position - LDS position of the points of every staged bucket of the tile (one table for all of its images)
     __shared__ int s_kd[32];
+    M3D_ENTRY_JITTER();
     const unsigned int wl = blockIdx.x & (unsigned int)(M3D_TILE_LISTS - 1);   // this workgroup's list of work items
     const unsigned int n_items = min(A.wcount[32u * wl], (unsigned int)A.wcap);   // (uniform; the reduction pass zeroes the counters)
     const uint2* witems = A.witems + (size_t)wl * (size_t)A.wcap;

@@ -204,6 +204,19 @@ __device__ __forceinline__ void m3d_sync_jitter() {
     if ((t & 3u) == 0u) { const int n = 1 + (int)((t >> 4) & 15u); for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(8); }
 }
 #define __syncthreads() m3d_sync_jitter()
+// ... and at the ENTRY of the kernels (called from the block -> work maps every kernel starts with: icp.hip m3d_map_block, bucket.hip m3d_row_block*; k_nn_tiles itself):
+// a wave in four starts up to 8 us late, so the workgroups of a launch — and the waves of a workgroup before its first barrier — arrive at every cross-workgroup
+// protocol (arrival tickets, partial sums, work-item lists, table inserts) in orders an undisturbed launch hardly ever produces.
+__device__ __forceinline__ void m3d_entry_jitter() {
+    unsigned int t = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)clock64());
+    t ^= (threadIdx.x >> 6) * 0x9E3779B1u ^ blockIdx.x * 0xC2B2AE35u;
+    t ^= t >> 16; t *= 0x7FEB352Du; t ^= t >> 15; t *= 0x846CA68Bu; t ^= t >> 16;
+    t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    if ((t & 3u) == 0u) { const int n = 1 + (int)((t >> 4) & 31u); for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(8); }
+}
+#define M3D_ENTRY_JITTER() m3d_entry_jitter()
+#else
+#define M3D_ENTRY_JITTER() ((void)0)
 #endif
 
 // ---- -DM3D_CHECKED (diagnosis build, `make checked` -> libm3dreg_checked.so; DESIGN.md §8 "the unexplained GPU memory fault") --------------------------------
