@@ -244,10 +244,29 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else None   # where the collectives' tensors live
+    collectives = "none (one rank)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        collectives = args.dist_backend
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL for the run's three control-plane collectives (barrier, max of the ranks' times, the pose / per-rank gather): nothing of a step's data path is a
+            # collective. Should the RCCL group not come up on this node (it has never run with two ranks: no multi-GPU box in six rounds), the SAME
+            # three collectives go through gloo on host tensors instead of the run ending without its line; every rank takes the same decision (the eager
+            # communicator set-up below fails or succeeds for the group), the line says which backend carried them.
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] rank {rank}: the RCCL process group failed ({e!r}); the barrier / max / gather go through gloo (no collective is on the data path)", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo", rank=rank, world_size=world)   # (the same rendezvous store — under torchrun the agent hosts it —, a fresh key prefix)
+                cdev, collectives = None, "gloo (RCCL group failed)"
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -668,7 +687,7 @@ def main():
                        "payload": "host (pinned PointCloud2 buffers cross PCIe inside the timed region)" if args.from_host else "hbm-resident",
                        "pipelining": ("none: one synchronous call per step" if serial_calls else f"caller-side: {len(regs)} handles / {D} streams" + (", the same 8 pairs every step" if n_rot == 1 else f", step k registers shard k mod {n_rot}")),
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
-                       "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step",
+                       "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step" + (f"; collectives: {collectives}" if world > 1 else ""),
                        "overlap": ((("none (serial steps, synchronous calls" + ("" if args.no_latency_mode else ", m3dreg_set_latency_mode on: the caller says its batches have the GPU to themselves") + ")") if serial_calls else "none (serial steps, one chain)") if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
                                   (f"; {Q} steps queued per stream" if Q > 1 else "")},
             "ms_per_icp_iter_batch": chain_iter_ms if chain_iter_ms > 0 else iter_ms / max(1, iters_timed),

@@ -251,3 +251,25 @@ def test_bench_launcher_runs_two_ranks_end_to_end(extra, pts):
     assert not set(pr[0]["pairs"]) & set(pr[1]["pairs"]) and sorted(pr[0]["pairs"] + pr[1]["pairs"]) == list(range(2 * B))
     assert abs(d["config"]["points_per_cloud"] - pts) < 0.1 * pts
     assert d["max_rot_err_deg"] < 0.2 and d["max_trans_err_m"] < 0.02
+
+
+def test_bench_line_survives_an_rccl_group_that_does_not_come_up():
+    """Round 6: the N > 1 line must not depend on RCCL coming up (it has never run with two ranks: no multi-GPU box in six rounds). Two ranks on this box's ONE GPU
+    with the default backend: RCCL refuses ("Duplicate GPU detected"), every rank takes the same decision, the run's three control-plane collectives (barrier, max
+    of the ranks' times, gather) go through gloo on host tensors, rank 0 prints the line and the line says so. Under the real launcher (torch.distributed.run:
+    the agent hosts the rendezvous store)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "M3D_BENCH_RANK_PROCESS", "M3D_BENCH_FULL_LINE")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--azimuth", "800", "--pairs-per-gpu", "3",
+                        "--no-extra", "--no-cpu-baseline", "--min-seconds", "0"], capture_output=True, text=True, timeout=170, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank"]) == 2
+    assert "gloo (RCCL group failed)" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert "the RCCL process group failed" in r.stderr
