@@ -28,6 +28,10 @@ def tile_image_problems(cloud, level=0, max_report=8):
         if flags & OVERSIZE:
             continue
         n_b = flags >> 16
+        if n_b == 0:   # a tile that owns no bucket (its 512 positions lie inside a bucket that starts in an earlier tile): an empty image nobody is sent to
+            if not (n_img == 1 and (meta0 & 0xFFFF) == 0 and int(meta[t][0]) == 0 and (int(meta[t][1]) & 0x7FFFFFFF) == 0):
+                out.append(f"tile {t}: no staged bucket but header {thdr[t].tolist()}, image meta {meta[t].tolist()}")
+            continue
         if not (1 <= n_img <= 32 and 1 <= n_b <= ECAP):
             out.append(f"tile {t}: header {thdr[t].tolist()}")
             continue
