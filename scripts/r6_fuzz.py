@@ -125,10 +125,69 @@ def outcome_orc(p, src, tgt, init):
     return out, (os_, ot)
 
 
+def batch_case(seed):
+    """FUZZ_BATCH=1: one m3dreg_align_batch of 2 ... 12 pairs of very different sizes (one parameter set), pipelined like bench.py (clouds created without a wait, the
+    asynchronous call), every pair against the oracle"""
+    rng = np.random.default_rng(seed)
+    p, _, _, _, what = case(seed)
+    B = int(rng.integers(2, 13))
+    pairs = []
+    for b in range(B):
+        _, src, tgt, init, _ = case(seed * 131 + b + 1)
+        pairs.append((src, tgt, init))
+    return p, pairs, f"seed {seed}: batch of {B} pairs, sizes {[(len(s_), len(t_)) for s_, t_, _ in pairs]}, {what.split(', leaf')[1] if ', leaf' in what else what}"
+
+
+def run_batch(R, p, pairs):
+    arrays, so = [], []
+    for s_, t_, _ in pairs:
+        arrays += [s_, t_]; so += [True, False]
+    try:
+        cl = R.clouds(arrays, wait=False, source_only=so)
+    except abi.M3dregError as e:
+        return [("cloud_error", e.code)] * len(pairs), None
+    T, st = R.align_batch([(cl[2 * j], cl[2 * j + 1], pairs[j][2]) for j in range(len(pairs))])
+    out = [("ok", np.asarray(T[j], np.float64).tobytes(), st[j].status, st[j].iterations, st[j].n_corr, float(st[j].rms)) for j in range(len(pairs))]
+    return out, cl
+
+
 t0, n_cases, bad, regs = time.time(), 0, 0, {}
 seed = seed0
 stats = {"ok": 0, "cloud_error": 0, "align_error": 0}
-while time.time() - t0 < budget:
+BATCH = os.environ.get("FUZZ_BATCH", "0") == "1"
+while BATCH and time.time() - t0 < budget:
+    p, pairs, what = batch_case(seed)
+    key = bytes(p)
+    R = regs.get(key)
+    if R is None:
+        if len(regs) > 12:
+            for r in regs.values():
+                r.close()
+            regs.clear()
+        R = regs[key] = binding.Registrar(p)
+    hs, cl = run_batch(R, p, pairs)
+    msgs = []
+    for j, (src, tgt, init) in enumerate(pairs):
+        o, _ = outcome_orc(p, src, tgt, init)
+        h = hs[j]
+        if o[0] == "cloud_error":   # (a bad cloud in a batch created without a wait: the pair comes back M3DREG_BAD_CLOUD with the initial pose)
+            if not (h[0] == "ok" and h[2] == abi.BAD_CLOUD) and h[0] != "cloud_error":
+                msgs.append(f"pair {j}: the oracle refuses a cloud ({o[1]}), HIP returns {h[0], h[2:] if h[0] == 'ok' else h[1]}")
+        elif h != o:
+            msgs.append(f"pair {j}: HIP {h[0], h[2:] if h[0] == 'ok' else h[1]} oracle {o[0], o[2:] if o[0] == 'ok' else o[1]}" +
+                        (f", max |dT| {np.abs(np.frombuffer(h[1], np.float64) - np.frombuffer(o[1], np.float64)).max():.3e}" if h[0] == o[0] == "ok" else ""))
+    if cl is not None:
+        for c in cl:
+            c.free()
+    stats[hs[0][0]] += 1
+    n_cases += 1
+    if msgs:
+        bad += 1
+        print(f"DIFF {what}\n     " + "\n     ".join(msgs), flush=True)
+    if n_cases % 20 == 0:
+        print(f"{n_cases} batches, {bad} with differences, {time.time() - t0:.0f} s", flush=True)
+    seed += 1
+while not BATCH and time.time() - t0 < budget:
     p, src, tgt, init, what = case(seed)
     key = bytes(p)
     R = regs.get(key)
