@@ -156,3 +156,18 @@ def test_hip_degenerate_clouds_end_in_a_status_like_the_oracle(reg, orc, seed, m
     Th, sh = _Hip(reg).align(p, plane + np.float32(0.01), plane)
     To, so = _Oracle(orc).align(p, plane + np.float32(0.01), plane)
     assert np.array_equal(Th, To) and sh.status == so.status and sh.n_corr == so.n_corr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", ["0", "1"])
+def test_random_scenes_and_parameters_equal_the_oracle(batch):
+    """scripts/r6_fuzz.py for a few seconds: random scenes (walls, floors, blobs denser than a voxel, lines, boxes, exact duplicates, NaN / inf points, 1 ... 60 000 points, extents
+    1 ... 80 m) under random parameters (one to three levels, both metrics, thresholds on / off, random initial poses) — error codes, poses, statistics, every level's exported
+    sort and every tile image, bit for bit against the CPU oracle; batch = "1": heterogeneous batches through the asynchronous creation + m3dreg_align_batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_BATCH=batch)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r6_fuzz.py"), "25" if batch == "0" else "30", "424242"], capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    assert r.returncode == 0 and ", 0 with differences" in r.stdout, (r.stdout[-1500:], r.stderr[-800:])
