@@ -50,7 +50,7 @@ extern "C" {
                                      m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight
                                   6: m3dreg_pair_desc.reserved must be 0 (+ m3dreg_set_batch_chains, removed again in 8)
                                   7: + m3dreg_set_latency_mode (a serial caller states that its batches have the GPU to themselves)
-                                  8: + m3dloop_* (loop-closure candidate generation), m3dagg_set_rearm, m3dreg_debug_checks; - m3dreg_set_batch_chains (internal launch chains
+                                  8: + m3dloop_* (loop-closure candidate generation), m3dagg_set_rearm, m3dreg_debug_checks, m3dreg_debug_cloud_raw; - m3dreg_set_batch_chains (internal launch chains
                                      lost on every workload measured); the dense-level schedule is decided per batch, no longer from the handle's previous batch */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
