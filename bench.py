@@ -60,7 +60,10 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --share-gpu = rehearsal of the N > 1 flow on a single-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--event-every", type=int, default=7, help="bracket every n-th iteration with hipEvents (n should not divide --iters)")
+    ap.add_argument("--event-every", type=int, default=13, help="bracket every n-th iteration with hipEvents (n should not divide --iters: every iteration index is then sampled over the steps). "
+                    "Round 6: 13 (rounds 1-5 and profiles/r06_v1/v2: 7) — an event record is a barrier packet, the brackets of every 7th iteration + four per-batch ones cost the "
+                    "headline 5 %% of what it measures without any (profiles/r06_event_density.txt)")
+    ap.add_argument("--batch-brackets-every", type=int, default=4, help="the per-batch brackets (bucketing, whole chain of iterations) on every n-th batch of a handle only (m3dreg_profile_batches)")
     ap.add_argument("--no-events", action="store_true", help="do not record hipEvents in the timed region (A/B of their cost; roofline then reads 0)")
     ap.add_argument("--trace-host", action="store_true", help="print the host-side time of every enqueue (bucketing / launch) and wait of the timed region to stderr")
     ap.add_argument("--pair-offset", type=int, default=None,
@@ -479,7 +482,8 @@ def main():
         torch.cuda.synchronize()
 
     for r in regs:
-        r.profile_enable(not args.no_events and not serial_calls, every=args.event_every)   # 7 does not divide the 20 iterations of a step: every iteration index gets sampled (synchronous calls: no brackets — a bracketed batch runs as ONE chain; `alone` is measured below)
+        r.profile_batches(args.batch_brackets_every)
+        r.profile_enable(not args.no_events and not serial_calls, every=args.event_every)   # 13 (7) does not divide the 20 iterations of a step: every iteration index gets sampled (synchronous calls: no brackets — a bracketed batch runs as ONE chain; `alone` is measured below)
         r.profile_read(0, reset=True)
         r.profile_read(1, reset=True)
     import gc
@@ -568,6 +572,7 @@ def main():
         alone_stated = not serial_calls and not args.no_latency_mode and not os.environ.get("M3D_BENCH_ALONE_DEFAULT")   # (the variable: A/B of the two maps on the lone step)
         if alone_stated:
             regs[0].set_latency_mode(True)
+        regs[0].profile_batches(1)   # (the per-batch brackets of EVERY batch again: this leg is a handful of batches)
         regs[0].profile_enable(True, every=1)
         for w_ in range(4):
             regs[0].profile_read(w_, reset=True)
@@ -685,7 +690,8 @@ def main():
                                     f"point-to-plane, leaf 0.1 m, {args.iters} " + ("iterations at most (eps 1e-5), " if args.converge else "fixed iterations, ")) +
                                    "decode of both clouds, sort of the source (m3dreg_cloud_desc.source_only), bucketing + tile images + normals of the target inside the timed region",
                        "payload": "host (pinned PointCloud2 buffers cross PCIe inside the timed region)" if args.from_host else "hbm-resident",
-                       "pipelining": ("none: one synchronous call per step" if serial_calls else f"caller-side: {len(regs)} handles / {D} streams" + (", the same 8 pairs every step" if n_rot == 1 else f", step k registers shard k mod {n_rot}")),
+                       "pipelining": ("none: one synchronous call per step" if serial_calls else f"caller-side: {len(regs)} handles / {D} streams" + (", the same 8 pairs every step" if n_rot == 1 else f", step k registers shard k mod {n_rot}")) +
+                                     ("; no event brackets" if (args.no_events or serial_calls) else f"; brackets: iteration {args.event_every}, batch {args.batch_brackets_every}"),
                        "pairs_per_gpu": B, "points_per_cloud": n_pts, "iterations": args.iters,
                        "parallelism": f"pairs sharded over {world} GPU(s)" + (f" ({args.shard})" if world > 1 else "") + ", one all_gather of poses per step" + (f"; collectives: {collectives}" if world > 1 else ""),
                        "overlap": ((("none (serial steps, synchronous calls" + ("" if args.no_latency_mode else ", m3dreg_set_latency_mode on: the caller says its batches have the GPU to themselves") + ")") if serial_calls else "none (serial steps, one chain)") if D == 1 else f"{D} steps run concurrently, one HIP stream each") +
@@ -737,7 +743,7 @@ def main():
         if world == 1 and not args.no_extra and not args.no_cpu_baseline and args.workload == "config4" and not (args.from_host or args.converge):
             out["legs"] = extra_legs(args)
             # what a caller gets, beside the pipelined headline: one synchronous call at a time, host payloads, one 64-pair call, rotating inputs
-            for key, leg in (("value_serial", "serial"), ("value_from_host", "from_host"), ("value_batch64", "batch64_one_chain"), ("value_rotate_pairs", "rotate_pairs")):
+            for key, leg in (("value_serial", "serial"), ("value_from_host", "from_host"), ("value_batch64", "batch64_one_chain"), ("value_rotate_pairs", "rotate_pairs"), ("value_unbracketed", "unbracketed")):
                 v_ = (out["legs"].get(leg) or {}).get("value")
                 if v_ is not None:
                     out[key] = v_
@@ -774,7 +780,7 @@ def compact_line(full):
     for k, cap in (("metric", 120), ("unit", 24), ("scaling", 16), ("dtype", 48), ("data", 100)):
         if isinstance(line.get(k), str):
             line[k] = line[k][:cap]
-    line.update(pick(full, ("value_serial", "value_from_host", "value_batch64", "value_rotate_pairs")))
+    line.update(pick(full, ("value_serial", "value_from_host", "value_batch64", "value_rotate_pairs", "value_unbracketed")))
     if isinstance(full.get("verify"), dict):
         line["verify"] = pick(full["verify"], ("steps_checked", "mismatches", "timed_steps_checked"))
     if isinstance(full.get("scale_ceiling"), dict):
@@ -918,9 +924,11 @@ def extra_legs(args):
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-extra", "--iters", str(args.iters), "--azimuth", str(args.azimuth)]
     runs = {
         "serial": ["--steps", "30", "--warmup", "3", "--inflight", "1", "--queue-depth", "1"],
+        # the headline's schedule with NO event brackets in the timed region (what the instrument costs: every record is a barrier packet on its stream)
+        "unbracketed": ["--steps", "20", "--warmup", "5", "--no-events"],
         "from_host": ["--steps", "40", "--warmup", "3", "--from-host"],
         "converge": ["--steps", "40", "--warmup", "3", "--converge"],
-        # (the default bracket, every 7th iteration: with every iteration bracketed none of them runs fused, and these two legs are LATENCIES of the shipped schedule)
+        # (the default bracket, every 13th iteration: with every iteration bracketed none of them runs fused, and these two legs are LATENCIES of the shipped schedule)
         "config3": ["--workload", "config3", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config2": ["--workload", "config2", "--steps", "60", "--warmup", "5", "--inflight", "1", "--queue-depth", "1"],
         "config5": ["--workload", "config5", "--steps", "10", "--warmup", "2"],

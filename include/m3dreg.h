@@ -50,7 +50,7 @@ extern "C" {
                                      m3dreg_cloud_density; the schedule no longer depends on what else the process has in flight
                                   6: m3dreg_pair_desc.reserved must be 0 (+ m3dreg_set_batch_chains, removed again in 8)
                                   7: + m3dreg_set_latency_mode (a serial caller states that its batches have the GPU to themselves)
-                                  8: + m3dloop_* (loop-closure candidate generation), m3dagg_set_rearm, m3dreg_debug_checks, m3dreg_debug_cloud_raw; - m3dreg_set_batch_chains (internal launch chains
+                                  8: + m3dloop_* (loop-closure candidate generation), m3dagg_set_rearm, m3dreg_debug_checks, m3dreg_debug_cloud_raw, m3dreg_profile_batches; - m3dreg_set_batch_chains (internal launch chains
                                      lost on every workload measured); the dense-level schedule is decided per batch, no longer from the handle's previous batch */
 #define M3DREG_MAX_LEVELS 4
 #define M3DREG_NSUMS 29 /* 21 upper-tri JtJ + 6 Jtr + sum r^2 + correspondence count */
@@ -408,6 +408,10 @@ int m3dloop_last_profile(m3dloop* l, double* ms, uint64_t* algorithmic_bytes);
  * throughput it measured.) With M3DREG_ROCTX=1 in the environment the same stages are also marked as roctx ranges
  * ("m3dreg:bucketing", "m3dreg:iteration") for rocprofv3 --marker-trace. */
 int m3dreg_profile_enable(m3dreg_handle* h, int on);
+/* (ABI 8) The per-BATCH brackets (two events around a bucketing batch, two around a batch's whole chain of iterations) on every n-th batch of the handle only
+ * (default 1: every batch; m3dreg_profile_enable does not change it). An event record is a barrier packet on the queue: with 4 per step + the iteration brackets
+ * of every 7th iteration the headline measured 5 % less than without any (profiles/r06_event_density.txt); bench.py samples every 4th batch and every 13th iteration. */
+int m3dreg_profile_batches(m3dreg_handle* h, int every);
 #define M3DREG_PROFILE_ITERATION 0        /* one Gauss-Newton iteration of the batch: correspondence step + reduction + solve */
 #define M3DREG_PROFILE_DOMINANT_KERNEL 1  /* its correspondence step (a6) */
 #define M3DREG_PROFILE_BUCKETING 2        /* one bucketing batch (a2-a4, a9, tiles): m3dreg_cloud_create* */

@@ -27,7 +27,7 @@ EXPORTS = [
     "m3dreg_abi_version", "m3dreg_set_target_xyz", "m3dreg_align", "m3dreg_cloud_create", "m3dreg_cloud_destroy",
     "m3dreg_align_clouds", "m3dreg_align_batch", "m3dreg_set_latency_mode", "m3dreg_align_batch_async", "m3dreg_batch_wait", "m3dreg_synchronize",
     "m3dreg_get_stream", "m3dreg_cloud_levels", "m3dreg_cloud_grid_info", "m3dreg_cloud_export", "m3dreg_debug_nn",
-    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
+    "m3dreg_debug_accumulate", "m3dreg_debug_trace", "m3dreg_profile_enable", "m3dreg_profile_batches", "m3dreg_profile_read", "m3dreg_debug_counters", "m3dreg_cloud_create_batch",
     "m3dreg_cloud_create_batch_async", "m3dreg_cloud_status",
     "m3dreg_cloud_create_pc2", "m3dreg_cloud_density",
     "m3dagg_create", "m3dagg_destroy", "m3dagg_add_cloud", "m3dagg_add_scan", "m3dagg_set_scan_trig", "m3dagg_set_rearm", "m3dagg_status", "m3dagg_take_cloud", "m3dagg_restart",
@@ -126,6 +126,7 @@ def lib():
     L.m3dreg_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.m3dreg_set_latency_mode.argtypes = [vp, C.c_int]
     L.m3dreg_profile_enable.argtypes = [vp, C.c_int]
+    L.m3dreg_profile_batches.argtypes = [vp, C.c_int]
     L.m3dreg_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_int]
     L.m3dreg_multi_create.argtypes = [C.POINTER(abi.Params), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.m3dreg_multi_destroy.argtypes = [vp]
@@ -279,6 +280,10 @@ class Registrar:
     def profile_enable(self, on=True, every=1):
         """every = n: bracket every n-th iteration only (each event record is a barrier packet on the stream)"""
         self._check(lib().m3dreg_profile_enable(self._h, max(1, int(every)) if on else 0), "profile_enable")
+
+    def profile_batches(self, every=1):
+        """the per-batch brackets (bucketing, whole chain) on every n-th batch only (m3dreg_profile_batches; default: every batch)"""
+        self._check(lib().m3dreg_profile_batches(self._h, max(1, int(every))), "profile_batches")
 
     def profile_read(self, what=1, reset=True):
         """(launches, total ms) since the last reset, from hipEvents on the stream.

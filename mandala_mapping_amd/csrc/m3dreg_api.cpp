@@ -161,6 +161,9 @@ struct m3dreg_handle {
     // measurement: event pairs around the dominant kernel
     bool profiling = false;
     int prof_every = 1;                // every n-th iteration is bracketed by events (m3dreg_profile_enable(h, n))
+    int prof_batch_every = 1;          // every n-th bucketing batch / registration batch carries its per-batch brackets (m3dreg_profile_batches)
+    uint64_t prof_bucketings = 0, prof_batches = 0;   // batches seen while profiling (the sampling counters)
+    bool chain_bracketed = false;      // this batch's chain bracket was opened (batch_begin): batch_end closes it
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_kind;          // per recorded event: 0 = before the dominant kernel (= start of an iteration), 1 = after it, 2 = end of the batch
     size_t ev_used = 0;
@@ -549,7 +552,7 @@ int create_clouds(m3dreg_handle* h, const CloudInput* in, size_t k, m3dreg_cloud
     }
     roctx_push("m3dreg:bucketing");
     hipEvent_t pb0 = nullptr;
-    if (h->profiling) { pb0 = next_event(h); if (pb0) { h->ev_kind.push_back(3); (void)hipEventRecord(pb0, h->stream); } }
+    if (h->profiling && (h->prof_bucketings++ % uint64_t(h->prof_batch_every)) == 0) { pb0 = next_event(h); if (pb0) { h->ev_kind.push_back(3); (void)hipEventRecord(pb0, h->stream); } }
     B_HIP(m3d_launch_decode_aabb(h->stream, d_dec, int(k), int(max_n)));
     if (!h->staged) B_HIP(hipEventCreateWithFlags(&h->staged, hipEventDisableTiming));
     B_HIP(hipEventRecord(h->staged, h->stream));
@@ -1113,7 +1116,11 @@ static int batch_begin(m3dreg_handle* h, const m3dreg_pair* pairs, size_t n_pair
     R.n_pairs = n_pairs; R.max_n_src = max_n_src;
     R.can_stop_early = h->h_progress && (P.eps_rot > 0.0 || P.eps_trans > 0.0);
     R.iters_before = h->launched_iters;
-    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(5); (void)hipEventRecord(e, h->stream); } }   // the whole chain of this batch's iterations as it ships
+    h->chain_bracketed = false;
+    if (h->profiling && (h->prof_batches++ % uint64_t(h->prof_batch_every)) == 0) {   // the whole chain of this batch's iterations as it ships
+        hipEvent_t e = next_event(h);
+        if (e) { h->ev_kind.push_back(5); (void)hipEventRecord(e, h->stream); h->chain_bracketed = true; }
+    }
     return M3DREG_OK;
 }
 
@@ -1187,7 +1194,7 @@ static int batch_end(m3dreg_handle* h, const m3dreg_pair* pairs) {
     const size_t n_pairs = R.n_pairs;
     int rc;
     if (h->profiling && R.prev_sampled) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(2); (void)hipEventRecord(e, h->stream); } }
-    if (h->profiling) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(6 + int(h->launched_iters - R.iters_before)); (void)hipEventRecord(e, h->stream); } }
+    if (h->chain_bracketed) { hipEvent_t e = next_event(h); if (e) { h->ev_kind.push_back(6 + int(h->launched_iters - R.iters_before)); (void)hipEventRecord(e, h->stream); } h->chain_bracketed = false; }
     for (size_t i = 0; i < n_pairs; i++) {   // clouds of other handles: their owners' streams wait for this batch before the blocks are re-used
         if ((rc = note_foreign_use(h, pairs[i].source))) return rc;
         if ((rc = note_foreign_use(h, pairs[i].target))) return rc;
@@ -2153,6 +2160,14 @@ int m3dreg_profile_enable(m3dreg_handle* h, int on) {
     if (!h) return M3DREG_ERR_INVALID_ARG;
     h->profiling = on != 0;
     h->prof_every = on > 1 ? on : 1;
+    return M3DREG_OK;
+    });
+}
+
+int m3dreg_profile_batches(m3dreg_handle* h, int every) {
+    return m3d_guarded(h, "m3dreg_profile_batches", [&]() -> int {
+    if (!h || every < 1) return M3DREG_ERR_INVALID_ARG;
+    h->prof_batch_every = every;
     return M3DREG_OK;
     });
 }
