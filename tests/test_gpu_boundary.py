@@ -178,6 +178,34 @@ def test_stage_timers(reg):
     assert abs((ms[1] + ms[3]) - ms[0]) < 0.05 * ms[0] + 0.05     # correspondence step + reduce/solve = iteration
 
 
+def test_per_batch_brackets_can_be_sampled(reg):
+    """m3dreg_profile_batches (ABI 8): the two events around a bucketing batch and the two around a batch's chain of iterations on every n-th batch only (bench.py: every 4th —
+    an event record is a barrier packet on the stream); the default stays every batch, the results do not depend on it."""
+    p = abi.Params.make(leaf=0.2, iterations=5, max_corr_dist=0.6, metric=abi.POINT_TO_PLANE, normal_leaf=0.5, eps_rot=0.0, eps_trans=0.0)
+    src, tgt, _ = synth.hdl32_pair(700, 1, 2)
+    out = {}
+    for every in (1, 3):
+        R = reg.Registrar(p)
+        R.profile_batches(every)
+        R.profile_enable(True, every=1 << 30)      # (no iteration brackets: only the per-batch ones)
+        Ts = []
+        for _ in range(7):
+            cs, ct = R.clouds([src, tgt], source_only=[True, False])
+            T, st = R.align(cs, ct)
+            Ts.append(T.tobytes() + bytes(st))
+            cs.free(); ct.free()
+        nb, msb = R.profile_read(2, reset=True)
+        nc, msc = R.profile_read(4, reset=True)
+        out[every] = (nb, nc, Ts)
+        assert msb > 0 and msc > 0 and len(set(Ts)) == 1
+        R.close()
+    assert out[1][0] == 7 and out[1][1] == 7 * 5          # every batch: 7 bucketing brackets, 7 chains of 5 iterations
+    assert out[3][0] == 3 and out[3][1] == 3 * 5          # batches 0, 3 and 6
+    assert out[1][2] == out[3][2]
+    R = reg.Registrar(p)
+    assert reg.lib().m3dreg_profile_batches(R._h, 0) == abi.ERR_INVALID_ARG and reg.lib().m3dreg_profile_batches(None, 2) == abi.ERR_INVALID_ARG
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
